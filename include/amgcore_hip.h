@@ -1,0 +1,214 @@
+/*
+ * amgcore_hip -- MI355X (gfx950) native replacement for the solve-phase
+ * boundary of PyAMG: the `pyamg.amg_core` relaxation kernels, scipy's
+ * csr/bsr matvec at the reference's call sites, and a device-resident
+ * multigrid hierarchy that runs multilevel_solver.solve() entirely in HBM.
+ *
+ * C ABI only: plain pointers, ints and doubles; no C++/torch types.  fp64
+ * values, int32 indices (the reference instantiates `int` indices only,
+ * pyamg/amg_core/amg_core.i:108).  Every function returns 0 on success or a
+ * negative AMG_E* code; amg_last_error() gives the message.  Nothing here
+ * falls back to the CPU: without a usable HIP device every compute entry
+ * point fails with AMG_ENODEV.
+ *
+ * Section 1 mirrors the reference's SWIG table one-to-one (each (T*, int size)
+ * pair of the C++ prototype is kept, so a binding can forward numpy arrays
+ * unchanged).  All reference paths are relative to /root/reference.
+ */
+#ifndef AMGCORE_HIP_H
+#define AMGCORE_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AMG_OK        0
+#define AMG_EINVAL   -1   /* bad argument / inconsistent sizes */
+#define AMG_ENODEV   -2   /* no HIP device / HIP runtime error */
+#define AMG_ENOMEM   -3
+#define AMG_ESTATE   -4   /* hierarchy not finalised, level missing, ... */
+#define AMG_ENOTIMPL -5
+
+const char *amg_last_error(void);
+int amg_device_count(void);
+/* "gfx950:..." of the selected device, or "" */
+const char *amg_device_name(int device);
+
+/* ------------------------------------------------------------------------ */
+/* 1. amg_core drop-ins.  HOST pointers (numpy buffers), results written in  */
+/*    place exactly like the reference; x (and temp / z) are mutated.        */
+/*    Arithmetic per row is the reference's (same left-to-right sums, no     */
+/*    FMA contraction); sequential sweeps are executed by dependency-level   */
+/*    scheduling, which reproduces the sequential iterates bit for bit.      */
+/* ------------------------------------------------------------------------ */
+
+/* pyamg/amg_core/relaxation.h:33-62, called from pyamg/relaxation/relaxation.py:349 */
+int amgcore_gauss_seidel_f64(const int Ap[], int Ap_size, const int Aj[], int Aj_size,
+                             const double Ax[], int Ax_size, double x[], int x_size,
+                             const double b[], int b_size,
+                             int row_start, int row_stop, int row_step);
+/* relaxation.h:89-173, relaxation.py:353 */
+int amgcore_bsr_gauss_seidel_f64(const int Ap[], int Ap_size, const int Aj[], int Aj_size,
+                                 const double Ax[], int Ax_size, double x[], int x_size,
+                                 const double b[], int b_size,
+                                 int row_start, int row_stop, int row_step, int blocksize);
+/* relaxation.h:201-239, relaxation.py:416 */
+int amgcore_jacobi_f64(const int Ap[], int Ap_size, const int Aj[], int Aj_size,
+                       const double Ax[], int Ax_size, double x[], int x_size,
+                       const double b[], int b_size, double temp[], int temp_size,
+                       int row_start, int row_stop, int row_step,
+                       const double omega[], int omega_size);
+/* relaxation.h:267-360, relaxation.py:425 */
+int amgcore_bsr_jacobi_f64(const int Ap[], int Ap_size, const int Aj[], int Aj_size,
+                           const double Ax[], int Ax_size, double x[], int x_size,
+                           const double b[], int b_size, double temp[], int temp_size,
+                           int row_start, int row_stop, int row_step, int blocksize,
+                           const double omega[], int omega_size);
+/* relaxation.h:394-426, relaxation.py:739 */
+int amgcore_gauss_seidel_indexed_f64(const int Ap[], int Ap_size, const int Aj[], int Aj_size,
+                                     const double Ax[], int Ax_size, double x[], int x_size,
+                                     const double b[], int b_size, const int Id[], int Id_size,
+                                     int row_start, int row_stop, int row_step);
+/* relaxation.h:465-496, relaxation.py:818 */
+int amgcore_jacobi_ne_f64(const int Ap[], int Ap_size, const int Aj[], int Aj_size,
+                          const double Ax[], int Ax_size, double x[], int x_size,
+                          const double b[], int b_size, const double Tx[], int Tx_size,
+                          double temp[], int temp_size,
+                          int row_start, int row_stop, int row_step,
+                          const double omega[], int omega_size);
+/* relaxation.h:529-561, relaxation.py:907 */
+int amgcore_gauss_seidel_ne_f64(const int Ap[], int Ap_size, const int Aj[], int Aj_size,
+                                const double Ax[], int Ax_size, double x[], int x_size,
+                                const double b[], int b_size,
+                                int row_start, int row_stop, int row_step,
+                                const double Tx[], int Tx_size, double omega);
+/* relaxation.h:594-631, relaxation.py:995 (A in CSC) */
+int amgcore_gauss_seidel_nr_f64(const int Ap[], int Ap_size, const int Aj[], int Aj_size,
+                                const double Ax[], int Ax_size, double x[], int x_size,
+                                double z[], int z_size,
+                                int col_start, int col_stop, int col_step,
+                                const double Tx[], int Tx_size, double omega);
+/* relaxation.h:661-728, relaxation.py:503 */
+int amgcore_block_jacobi_f64(const int Ap[], int Ap_size, const int Aj[], int Aj_size,
+                             const double Ax[], int Ax_size, double x[], int x_size,
+                             const double b[], int b_size, const double Tx[], int Tx_size,
+                             double temp[], int temp_size,
+                             int row_start, int row_stop, int row_step,
+                             const double omega[], int omega_size, int blocksize);
+/* relaxation.h:755-810, relaxation.py:588 */
+int amgcore_block_gauss_seidel_f64(const int Ap[], int Ap_size, const int Aj[], int Aj_size,
+                                   const double Ax[], int Ax_size, double x[], int x_size,
+                                   const double b[], int b_size, const double Tx[], int Tx_size,
+                                   int row_start, int row_stop, int row_step, int blocksize);
+
+/* scipy.sparse._sparsetools.csr_matvec / bsr_matvec (third party) as used by
+ * `A * x` at pyamg/multilevel.py:496,498,544; pyamg/util/linalg.py:112;
+ * pyamg/relaxation/relaxation.py:661,666.  y is ACCUMULATED into, as scipy does. */
+int amgcore_csr_matvec_f64(int n_row, int n_col, const int Ap[], const int Aj[],
+                           const double Ax[], const double x[], double y[]);
+int amgcore_bsr_matvec_f64(int n_brow, int n_bcol, int R, int C, const int Ap[], const int Aj[],
+                           const double Ax[], const double x[], double y[]);
+/* pyamg/util/linalg.py:17-53 norm(x) (2-norm) */
+int amgcore_norm2_f64(const double x[], long n, double *result);
+
+/* ------------------------------------------------------------------------ */
+/* 2. Device-resident hierarchy: multilevel_solver.solve()/__solve()         */
+/*    (pyamg/multilevel.py:316-548) with A_l, P_l, R_l, smoother constants   */
+/*    and all work vectors in HBM.                                           */
+/* ------------------------------------------------------------------------ */
+typedef struct amg_hier amg_hier;
+
+enum { AMG_FMT_CSR = 0, AMG_FMT_BSR = 1 };
+enum { AMG_MAT_A = 0, AMG_MAT_P = 1, AMG_MAT_R = 2 };
+enum { AMG_PRE = 0, AMG_POST = 1 };
+enum { AMG_CYCLE_V = 0, AMG_CYCLE_W = 1, AMG_CYCLE_F = 2, AMG_CYCLE_AMLI = 3 };
+enum { AMG_SWEEP_FORWARD = 0, AMG_SWEEP_BACKWARD = 1, AMG_SWEEP_SYMMETRIC = 2 };
+/* smoother kinds = the relaxation.py entry points a smoothing.py closure calls */
+enum { AMG_SM_NONE = 0, AMG_SM_JACOBI = 1, AMG_SM_GAUSS_SEIDEL = 2, AMG_SM_SOR = 3,
+       AMG_SM_POLYNOMIAL = 4, AMG_SM_BLOCK_JACOBI = 5, AMG_SM_BLOCK_GAUSS_SEIDEL = 6,
+       AMG_SM_GAUSS_SEIDEL_INDEXED = 7 };
+
+typedef struct {
+    int kind;            /* AMG_SM_* */
+    int iterations;      /* >= 1 */
+    int sweep;           /* AMG_SWEEP_* (gauss_seidel, sor, block_gauss_seidel, indexed) */
+    double omega;        /* jacobi / block_jacobi: omega already divided by rho; sor: omega */
+    int ncoef;           /* polynomial: Horner coefficients (chebyshev: -coeffs[:-1]) */
+    const double *coef;  /* host pointer, copied */
+    int blocksize;       /* block_jacobi / block_gauss_seidel */
+    const double *Dinv;  /* host pointer, (n/bs)*bs*bs row-major inverse diagonal blocks, copied */
+    const int *indices;  /* gauss_seidel_indexed: row order (host pointer, copied) */
+    int nindices;
+} amg_smoother_desc;
+
+/* flags for amg_hier_solve */
+#define AMG_SOLVE_X0_ZERO        1  /* caller guarantees x is all zeros on entry */
+#define AMG_SOLVE_NO_EARLY_STOP  2  /* run exactly maxiter cycles; residual norms stay on
+                                       the device until the end (no per-iteration sync) */
+#define AMG_SOLVE_DEVICE_VECTORS 4  /* b and x are DEVICE pointers */
+
+amg_hier *amg_hier_create(int nlevels, int device);
+void amg_hier_destroy(amg_hier *h);
+
+/* Copy one operator of level `lvl` into HBM.  fmt/R/C describe the scipy
+ * container (csr_matrix, or bsr_matrix with blocksize (R,C)); nrows/ncols are
+ * scalar dimensions; Ax has nnz (CSR) or nblocks*R*C (BSR, blocks row-major)
+ * entries.  Pointers are host pointers unless on_device != 0, in which case
+ * the arrays are device pointers that the hierarchy ADOPTS (frees on destroy). */
+int amg_hier_set_matrix(amg_hier *h, int lvl, int which, int fmt, int nrows, int ncols,
+                        int R, int C, const int *Ap, const int *Aj, const double *Ax,
+                        int on_device);
+int amg_hier_set_smoother(amg_hier *h, int lvl, int which, const amg_smoother_desc *d);
+/* Block smoothers act on A re-blocked to their own blocksize
+ * (pyamg/relaxation/relaxation.py:471,563: A = A.tobsr(blocksize=(bs,bs))).  When
+ * level A is not already BSR(bs,bs), pass that re-blocked copy here AFTER
+ * amg_hier_set_smoother; which = AMG_PRE / AMG_POST, or 2 for the coarse smoother. */
+int amg_hier_set_block_matrix(amg_hier *h, int lvl, int which, int nbrows, int bs, const int *Ap,
+                              const int *Aj, const double *Ax);
+/* coarse_grid_solver('pinv'/'pinv2'/'lu'/'cholesky'/'splu'): a dense n x n
+ * row-major operator M with x = M b (multilevel.py:608-641) */
+int amg_hier_set_coarse_dense(amg_hier *h, const double *M, int n);
+/* coarse_grid_solver(<relaxation name>) (multilevel.py:662-680): x = 0, then the smoother */
+int amg_hier_set_coarse_smoother(amg_hier *h, const amg_smoother_desc *d);
+/* allocate work vectors, build Gauss-Seidel level schedules */
+int amg_hier_finalize(amg_hier *h);
+
+/* multilevel_solver.solve(b, x0, tol, maxiter, cycle) with accel=None
+ * (multilevel.py:316-471).  x holds x0 on entry and the solution on exit;
+ * residuals must have room for maxiter+1 doubles; *nres = number written. */
+int amg_hier_solve(amg_hier *h, const double *b, double *x, double tol, int maxiter, int cycle,
+                   double *residuals, int *nres, int flags);
+/* one multilevel_solver.__solve(0, x, b, cycle) (multilevel.py:473-548) on
+ * host (flags=0) or device (AMG_SOLVE_DEVICE_VECTORS) vectors */
+int amg_hier_cycle(amg_hier *h, const double *b, double *x, int cycle, int flags);
+/* levels[lvl].presmoother(A, x, b) / postsmoother on host vectors */
+int amg_hier_relax(amg_hier *h, int lvl, int which, const double *b, double *x);
+/* y = M x for a stored operator (host vectors) */
+int amg_hier_matvec(amg_hier *h, int lvl, int which, const double *x, double *y);
+
+/* bookkeeping for measurement */
+/* algorithmic bytes of one cycle per SURVEY.md section 8(d) */
+double amg_hier_cycle_bytes(amg_hier *h, int cycle);
+/* device time of the timed part of the last amg_hier_solve, ms (hipEvents on the solve stream) */
+double amg_hier_last_solve_ms(amg_hier *h);
+long amg_hier_device_bytes(amg_hier *h);
+/* the hipStream_t the hierarchy launches on, as void* */
+void *amg_hier_stream(amg_hier *h);
+/* raw device access to level work vectors for a caller that stays on the device */
+double *amg_hier_dev_x(amg_hier *h);
+double *amg_hier_dev_b(amg_hier *h);
+
+/* Stand-alone device SpMV benchmark hook: y = A x on a stored operator,
+ * `reps` back-to-back launches timed with hipEvents on the hierarchy stream;
+ * returns average ms per launch in *ms. */
+int amg_hier_time_spmv(amg_hier *h, int lvl, int which, int mode, int reps, double *ms);
+
+/* tuning knobs (speed only): 0 = scalar loads, 1 = 16-byte loads in the CSR stream kernel;
+ * XCD chunk: consecutive row blocks given to one XCD (0 = round-robin dispatch order) */
+void amg_set_stream_variant(int v);
+void amg_set_xcd_chunk(int c);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

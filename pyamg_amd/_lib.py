@@ -1,0 +1,139 @@
+"""ctypes binding of libamgcore_hip.so (include/amgcore_hip.h).
+
+The HIP library is the product: there is no CPU fallback.  If the shared
+object is missing, import fails loudly; if no GPU is present every compute
+call raises ``AmgDeviceError``.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libamgcore_hip.so")
+
+c_int_p = C.POINTER(C.c_int)
+c_dbl_p = C.POINTER(C.c_double)
+
+AMG_OK, AMG_EINVAL, AMG_ENODEV, AMG_ENOMEM, AMG_ESTATE, AMG_ENOTIMPL = 0, -1, -2, -3, -4, -5
+
+
+class AmgError(RuntimeError):
+    pass
+
+
+class AmgDeviceError(AmgError):
+    pass
+
+
+class SmootherDesc(C.Structure):
+    _fields_ = [("kind", C.c_int), ("iterations", C.c_int), ("sweep", C.c_int),
+                ("omega", C.c_double), ("ncoef", C.c_int), ("coef", c_dbl_p),
+                ("blocksize", C.c_int), ("Dinv", c_dbl_p), ("indices", c_int_p),
+                ("nindices", C.c_int)]
+
+
+def build_library():
+    """Compile the HIP sources in-tree (hipcc cross-compiles gfx950 without a GPU)."""
+    import subprocess
+    subprocess.run(["make", "-s", "-C", os.path.join(HERE, "csrc")], check=True)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "pyamg_amd: %s is missing -- build it with `make -C pyamg_amd/csrc` "
+            "(or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    I, D, V = C.c_int, C.c_double, C.c_void_p
+    arr = [c_int_p, I, c_int_p, I, c_dbl_p, I]          # Ap, Aj, Ax with sizes
+    xb = [c_dbl_p, I, c_dbl_p, I]                       # x, b with sizes
+    sig = {
+        "amgcore_gauss_seidel_f64": arr + xb + [I, I, I],
+        "amgcore_bsr_gauss_seidel_f64": arr + xb + [I, I, I, I],
+        "amgcore_jacobi_f64": arr + xb + [c_dbl_p, I, I, I, I, c_dbl_p, I],
+        "amgcore_bsr_jacobi_f64": arr + xb + [c_dbl_p, I, I, I, I, I, c_dbl_p, I],
+        "amgcore_gauss_seidel_indexed_f64": arr + xb + [c_int_p, I, I, I, I],
+        "amgcore_jacobi_ne_f64": arr + xb + [c_dbl_p, I, c_dbl_p, I, I, I, I, c_dbl_p, I],
+        "amgcore_gauss_seidel_ne_f64": arr + xb + [I, I, I, c_dbl_p, I, D],
+        "amgcore_gauss_seidel_nr_f64": arr + xb + [I, I, I, c_dbl_p, I, D],
+        "amgcore_block_jacobi_f64": arr + xb + [c_dbl_p, I, c_dbl_p, I, I, I, I, c_dbl_p, I, I],
+        "amgcore_block_gauss_seidel_f64": arr + xb + [c_dbl_p, I, I, I, I, I],
+        "amgcore_csr_matvec_f64": [I, I, c_int_p, c_int_p, c_dbl_p, c_dbl_p, c_dbl_p],
+        "amgcore_bsr_matvec_f64": [I, I, I, I, c_int_p, c_int_p, c_dbl_p, c_dbl_p, c_dbl_p],
+        "amgcore_norm2_f64": [c_dbl_p, C.c_long, c_dbl_p],
+        "amg_hier_set_matrix": [V, I, I, I, I, I, I, I, V, V, V, I],
+        "amg_hier_set_smoother": [V, I, I, C.POINTER(SmootherDesc)],
+        "amg_hier_set_block_matrix": [V, I, I, I, I, c_int_p, c_int_p, c_dbl_p],
+        "amg_hier_set_coarse_dense": [V, c_dbl_p, I],
+        "amg_hier_set_coarse_smoother": [V, C.POINTER(SmootherDesc)],
+        "amg_hier_finalize": [V],
+        "amg_hier_solve": [V, V, V, D, I, I, c_dbl_p, c_int_p, I],
+        "amg_hier_cycle": [V, V, V, I, I],
+        "amg_hier_relax": [V, I, I, c_dbl_p, c_dbl_p],
+        "amg_hier_matvec": [V, I, I, c_dbl_p, c_dbl_p],
+        "amg_hier_time_spmv": [V, I, I, I, I, c_dbl_p],
+    }
+    for name, args in sig.items():
+        f = getattr(L, name)
+        f.argtypes = args
+        f.restype = I
+    L.amg_last_error.restype = C.c_char_p
+    L.amg_device_count.restype = I
+    L.amg_device_name.argtypes = [I]
+    L.amg_device_name.restype = C.c_char_p
+    L.amg_hier_create.argtypes = [I, I]
+    L.amg_hier_create.restype = V
+    L.amg_hier_destroy.argtypes = [V]
+    L.amg_hier_destroy.restype = None
+    L.amg_hier_cycle_bytes.argtypes = [V, I]
+    L.amg_hier_cycle_bytes.restype = D
+    L.amg_hier_last_solve_ms.argtypes = [V]
+    L.amg_hier_last_solve_ms.restype = D
+    L.amg_hier_device_bytes.argtypes = [V]
+    L.amg_hier_device_bytes.restype = C.c_long
+    L.amg_hier_stream.argtypes = [V]
+    L.amg_hier_stream.restype = V
+    L.amg_hier_dev_x.argtypes = [V]
+    L.amg_hier_dev_x.restype = V
+    L.amg_hier_dev_b.argtypes = [V]
+    L.amg_hier_dev_b.restype = V
+    L.amg_set_stream_variant.argtypes = [I]
+    L.amg_set_stream_variant.restype = None
+    L.amg_set_xcd_chunk.argtypes = [I]
+    L.amg_set_xcd_chunk.restype = None
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc == 0:
+        return
+    msg = lib().amg_last_error().decode("utf-8", "replace")
+    if rc == AMG_ENODEV:
+        raise AmgDeviceError(msg)
+    if rc == AMG_ENOMEM:
+        raise MemoryError(msg)
+    if rc == AMG_ENOTIMPL:
+        raise NotImplementedError(msg)
+    if rc == AMG_EINVAL:
+        raise ValueError(msg)
+    raise AmgError(msg)
+
+
+def ip(a):
+    return a.ctypes.data_as(c_int_p)
+
+
+def dp(a):
+    return a.ctypes.data_as(c_dbl_p)
+
+
+def device_count():
+    return lib().amg_device_count()

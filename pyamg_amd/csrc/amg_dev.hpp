@@ -1,0 +1,112 @@
+// Internal declarations shared by the translation units of libamgcore_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace amg {
+
+// ---------------------------------------------------------------- errors
+void set_error(const std::string &msg);
+int hip_fail(hipError_t e, const char *what, const char *file, int line);
+#define AMG_HIP(call)                                                         \
+    do {                                                                      \
+        hipError_t e__ = (call);                                              \
+        if (e__ != hipSuccess) return amg::hip_fail(e__, #call, __FILE__, __LINE__); \
+    } while (0)
+
+// ---------------------------------------------------------------- device CSR
+// Arrays are over-allocated by PAD entries so that 16-byte vector loads that
+// start up to 3 entries before / end up to 3 entries after a row block stay in
+// bounds.
+constexpr int PAD = 16;
+
+struct DevCsr {
+    int nrows = 0, ncols = 0;
+    long nnz = 0;
+    int *Ap = nullptr;
+    int *Aj = nullptr;
+    double *Ax = nullptr;
+    bool owned = true;
+};
+
+struct DevBsr {   // block rows, for the block / point-BSR relaxation kernels
+    int nbrows = 0, bs = 1;
+    long nblocks = 0;
+    int *Ap = nullptr;
+    int *Aj = nullptr;
+    double *Ax = nullptr;
+};
+
+// ---------------------------------------------------------------- stream kernel
+// Row epilogues of the CSR-stream kernel.  `s` is the strict left-to-right sum
+// over the stored row (scipy csr_matvec order); for the relaxation modes the
+// diagonal entry is excluded from the sum (pyamg/amg_core/relaxation.h).
+enum StreamMode {
+    SM_MATVEC = 0,      // out[i]  = s                                  (scipy A*x, y pre-zeroed)
+    SM_MATVEC_ACC,      // out[i]  = out[i] + s                         (scipy csr_matvec accumulate; x += P*cx)
+    SM_RESIDUAL,        // out[i]  = b[i] - s                           (multilevel.py:496)
+    SM_POLY_FIRST,      // out[i]  = b[i] - s ; out2[i] = c0*out[i]     (relaxation.py:661-663)
+    SM_POLY_STEP,       // out[i]  = c0*b[i] + s                        (relaxation.py:666, b = residual)
+    SM_POLY_LAST,       // out[i]  = v2[i] + (c0*b[i] + s)              (relaxation.py:666,668 fused, v2 = x)
+    SM_JACOBI,          // out[i]  = (1-w)*v2[i] + w*((b[i]-s)/d)       (relaxation.h:202-239; xg = v2 = temp)
+    SM_JACOBI_BSR1,     // rs=b[i]; rs-=p..; out[i] = (1-w)*v2[i] + w*rs/d   (relaxation.h:268-360, bs=1)
+    SM_GS,              // out[row] = (b[row]-s)/d                      (relaxation.h:34-62, one level)
+    SM_GS_BSR1,         // rs=b[row]; rs-=p..; out[row] = rs/d          (relaxation.h:90-173, bs=1)
+};
+
+struct StreamArgs {
+    const int *Ap;
+    const int *Aj;
+    const double *Ax;
+    int row_lo, row_hi;      // rows [row_lo,row_hi) of the (possibly permuted) matrix
+    const double *xg;        // gathered vector
+    const double *b;         // streamed rhs / residual
+    const double *v2;        // second streamed vector
+    double *out;
+    double *out2;
+    double c0;               // coefficient / omega
+    const int *rowmap;       // GS levels: original row of permuted row i (rhs/out index), else null
+    const int *diagpos;      // GS levels: position of the diagonal entry of permuted row i (-1: none)
+    long nnz_total;          // entries in Aj/Ax (bound for 16-byte loads)
+};
+
+// variant: 0 = scalar (8 B / 4 B per lane) loads, 1 = 16-byte vector loads
+int launch_stream(StreamMode mode, const StreamArgs &a, hipStream_t st);
+void set_stream_variant(int v);
+int stream_variant();
+void set_xcd_chunk(int c);
+
+// thread-per-row fallbacks for non-unit strides / index lists (exact same arithmetic)
+int launch_jacobi_rows(const DevCsr &A, const double *temp, const double *b, double *x,
+                       int row_start, int count, int row_step, double omega, hipStream_t st);
+
+// ---------------------------------------------------------------- vector kernels
+int launch_scale(double *out, const double *in, double c, long n, hipStream_t st);          // out = c*in
+int launch_sor_combine(double *x, const double *xold, double omega, long n, hipStream_t st); // x = w*x + (1-w)*xold
+int launch_axpy_inplace(double *x, const double *h, long n, hipStream_t st);                 // x += h
+int launch_sub(double *out, const double *a, const double *b, long n, hipStream_t st);       // out = a - b
+int launch_copy_strided(double *dst, const double *src, int start, int count, int step, hipStream_t st);
+// ||x||_2 into *result_dev (deterministic two-stage reduction); scratch >= 1024 doubles
+int launch_norm2(const double *x, long n, double *scratch, double *result_dev, hipStream_t st);
+// x = M b with M given transposed (Mt[k*n+i] = M[i][k]); sequential sum per row
+int launch_dense_apply(const double *Mt, const double *b, double *x, int n, hipStream_t st);
+
+// ---------------------------------------------------------------- BSR kernels (one thread per block row)
+enum BlockMode { BM_BSR_JACOBI, BM_BLOCK_JACOBI, BM_BSR_GS, BM_BLOCK_GS };
+struct BlockArgs {
+    const int *Ap; const int *Aj; const double *Ax;   // BSR arrays (blocks row-major bs x bs)
+    int bs;
+    const int *rows;        // block rows to process (list) or null -> first + t*step
+    int first, step, count;
+    int intra_reverse;      // point-BSR kernels: reverse intra-block order (row_step < 0)
+    const double *xin;      // vector read for off-diagonal products (temp for Jacobi, x for GS)
+    double *xout;
+    const double *b;
+    const double *Dinv;
+    double omega;
+};
+int launch_block(BlockMode m, const BlockArgs &a, hipStream_t st);
+
+}  // namespace amg

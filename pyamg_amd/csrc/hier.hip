@@ -1,0 +1,935 @@
+// Device-resident multigrid hierarchy: multilevel_solver.solve()/__solve()
+// (/root/reference/pyamg/multilevel.py:316-548) with every operator, smoother
+// constant and work vector in HBM.  The host only sequences kernel launches on
+// one HIP stream; one 8-byte copy per iteration brings the residual norm back
+// when a tolerance has to be checked.
+#include "hier.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace amg {
+
+// ------------------------------------------------------------------ errors
+static thread_local std::string g_err;
+void set_error(const std::string &msg) { g_err = msg; }
+const std::string &last_error() { return g_err; }
+int hip_fail(hipError_t e, const char *what, const char *file, int line)
+{
+    g_err = std::string("HIP error: ") + hipGetErrorString(e) + " in " + what + " (" + file + ":" +
+            std::to_string(line) + ")";
+    return (e == hipErrorOutOfMemory) ? AMG_ENOMEM : AMG_ENODEV;
+}
+
+#define CHK(call)                 \
+    do {                          \
+        int rc__ = (call);        \
+        if (rc__ != 0) return rc__; \
+    } while (0)
+
+// ------------------------------------------------------------------ memory
+template <class T> static int dev_alloc(T **p, long count, long *acct)
+{
+    size_t bytes = sizeof(T) * (size_t)(count + PAD);
+    AMG_HIP(hipMalloc((void **)p, bytes));
+    AMG_HIP(hipMemset(*p, 0, bytes));
+    if (acct) *acct += (long)bytes;
+    return 0;
+}
+
+static void free_csr(DevCsr &M)
+{
+    if (M.Ap) hipFree(M.Ap);
+    if (M.Aj) hipFree(M.Aj);
+    if (M.Ax) hipFree(M.Ax);
+    M = DevCsr();
+}
+static void free_bsr(DevBsr &M)
+{
+    if (M.Ap) hipFree(M.Ap);
+    if (M.Aj) hipFree(M.Aj);
+    if (M.Ax) hipFree(M.Ax);
+    M = DevBsr();
+}
+
+int upload_csr(DevCsr &M, int nrows, int ncols, const int *Ap, const int *Aj, const double *Ax,
+               long *acct)
+{
+    long nnz = Ap[nrows];
+    M.nrows = nrows; M.ncols = ncols; M.nnz = nnz;
+    CHK(dev_alloc(&M.Ap, nrows + 1, acct));
+    CHK(dev_alloc(&M.Aj, nnz, acct));
+    CHK(dev_alloc(&M.Ax, nnz, acct));
+    AMG_HIP(hipMemcpy(M.Ap, Ap, sizeof(int) * (size_t)(nrows + 1), hipMemcpyHostToDevice));
+    if (nnz) {
+        AMG_HIP(hipMemcpy(M.Aj, Aj, sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice));
+        AMG_HIP(hipMemcpy(M.Ax, Ax, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
+int upload_bsr(DevBsr &M, int nbrows, int bs, const int *Ap, const int *Aj, const double *Ax,
+               long *acct)
+{
+    long nb = Ap[nbrows];
+    M.nbrows = nbrows; M.bs = bs; M.nblocks = nb;
+    CHK(dev_alloc(&M.Ap, nbrows + 1, acct));
+    CHK(dev_alloc(&M.Aj, nb, acct));
+    CHK(dev_alloc(&M.Ax, nb * bs * bs, acct));
+    AMG_HIP(hipMemcpy(M.Ap, Ap, sizeof(int) * (size_t)(nbrows + 1), hipMemcpyHostToDevice));
+    if (nb) {
+        AMG_HIP(hipMemcpy(M.Aj, Aj, sizeof(int) * (size_t)nb, hipMemcpyHostToDevice));
+        AMG_HIP(hipMemcpy(M.Ax, Ax, sizeof(double) * (size_t)(nb * bs * bs), hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
+// BSR (R x C blocks, row-major) -> scalar CSR keeping every stored entry, in
+// the order scipy's bsr_matvec accumulates them (block by block, then bj).
+void expand_bsr(int nbrows, int R, int C, const int *Ap, const int *Aj, const double *Ax,
+                std::vector<int> &cp, std::vector<int> &cj, std::vector<double> &cx)
+{
+    long nb = Ap[nbrows];
+    cp.assign((size_t)nbrows * R + 1, 0);
+    cj.resize((size_t)nb * R * C);
+    cx.resize((size_t)nb * R * C);
+    long pos = 0;
+    for (int i = 0; i < nbrows; ++i) {
+        for (int r = 0; r < R; ++r) {
+            cp[(size_t)i * R + r] = (int)pos;
+            for (int jj = Ap[i]; jj < Ap[i + 1]; ++jj) {
+                const double *blk = Ax + (long)jj * R * C + (long)r * C;
+                for (int c = 0; c < C; ++c) {
+                    cj[pos] = Aj[jj] * C + c;
+                    cx[pos] = blk[c];
+                    ++pos;
+                }
+            }
+        }
+    }
+    cp[(size_t)nbrows * R] = (int)pos;
+}
+
+// ------------------------------------------------------------------ schedules
+void Schedule::release()
+{
+    free_csr(G);
+    if (rowmap) hipFree(rowmap);
+    if (diagpos) hipFree(diagpos);
+    if (rows) hipFree(rows);
+    rowmap = diagpos = rows = nullptr;
+}
+
+int build_levels(int n, const int *Ap, const int *Aj, const int *tasks, int ntasks,
+                 std::vector<int> &level_ptr, std::vector<int> &order)
+{
+    std::vector<int> lastW((size_t)n, 0), lastR((size_t)n, 0), lvl((size_t)ntasks);
+    int maxl = 0;
+    for (int t = 0; t < ntasks; ++t) {
+        int i = tasks ? tasks[t] : t;
+        if (i < 0 || i >= n) { set_error("schedule: row index out of range"); return AMG_EINVAL; }
+        int l = std::max(lastW[i], lastR[i]);
+        for (int jj = Ap[i]; jj < Ap[i + 1]; ++jj) {
+            int j = Aj[jj];
+            if (j != i && j >= 0 && j < n) l = std::max(l, lastW[j]);
+        }
+        l += 1;
+        lvl[t] = l;
+        lastW[i] = l;
+        for (int jj = Ap[i]; jj < Ap[i + 1]; ++jj) {
+            int j = Aj[jj];
+            if (j != i && j >= 0 && j < n) lastR[j] = std::max(lastR[j], l);
+        }
+        maxl = std::max(maxl, l);
+    }
+    level_ptr.assign((size_t)maxl + 1, 0);
+    for (int t = 0; t < ntasks; ++t) level_ptr[lvl[t]]++;   // counts at index level (1-based)
+    // prefix: level_ptr[l] = start of level l+1 ... convert counts to offsets
+    {
+        int run = 0;
+        for (int l = 1; l <= maxl; ++l) { int c = level_ptr[l]; level_ptr[l - 1] = run; run += c; }
+        level_ptr[maxl] = run;
+    }
+    order.resize((size_t)ntasks);
+    std::vector<int> cur(level_ptr.begin(), level_ptr.end() - 1);
+    for (int t = 0; t < ntasks; ++t) order[cur[lvl[t] - 1]++] = t;
+    return 0;
+}
+
+int build_csr_schedule(const int *Ap, const int *Aj, const double *Ax, int n, const int *tasks,
+                       int ntasks, Schedule &S, hipStream_t st)
+{
+    (void)st;
+    std::vector<int> order;
+    CHK(build_levels(n, Ap, Aj, tasks, ntasks, S.level_ptr, order));
+    S.ntasks = ntasks;
+    std::vector<int> gp((size_t)ntasks + 1), rowmap((size_t)ntasks), dpos((size_t)ntasks);
+    long nnz = 0;
+    for (int k = 0; k < ntasks; ++k) {
+        int t = order[k];
+        int i = tasks ? tasks[t] : t;
+        gp[k] = (int)nnz;
+        nnz += Ap[i + 1] - Ap[i];
+        rowmap[k] = i;
+    }
+    if (nnz > 2147483647L) { set_error("schedule: nnz exceeds int32"); return AMG_EINVAL; }
+    gp[ntasks] = (int)nnz;
+    std::vector<int> gj((size_t)nnz);
+    std::vector<double> gx((size_t)nnz);
+    for (int k = 0; k < ntasks; ++k) {
+        int i = rowmap[k];
+        int len = Ap[i + 1] - Ap[i];
+        std::memcpy(gj.data() + gp[k], Aj + Ap[i], sizeof(int) * (size_t)len);
+        std::memcpy(gx.data() + gp[k], Ax + Ap[i], sizeof(double) * (size_t)len);
+        int d = -1;
+        for (int q = 0; q < len; ++q)
+            if (Aj[Ap[i] + q] == i) d = gp[k] + q;   // last diagonal entry wins, as relaxation.h:51-52
+        dpos[k] = d;
+    }
+    CHK(upload_csr(S.G, ntasks, n, gp.data(), gj.data(), gx.data(), nullptr));
+    CHK(dev_alloc(&S.rowmap, ntasks, (long *)nullptr));
+    CHK(dev_alloc(&S.diagpos, ntasks, (long *)nullptr));
+    AMG_HIP(hipMemcpy(S.rowmap, rowmap.data(), sizeof(int) * (size_t)ntasks, hipMemcpyHostToDevice));
+    AMG_HIP(hipMemcpy(S.diagpos, dpos.data(), sizeof(int) * (size_t)ntasks, hipMemcpyHostToDevice));
+    return 0;
+}
+
+int build_block_schedule(const int *Ap, const int *Aj, int nb, const int *tasks, int ntasks,
+                         Schedule &S, hipStream_t st)
+{
+    (void)st;
+    std::vector<int> order;
+    CHK(build_levels(nb, Ap, Aj, tasks, ntasks, S.level_ptr, order));
+    S.ntasks = ntasks;
+    std::vector<int> rows((size_t)ntasks);
+    for (int k = 0; k < ntasks; ++k) rows[k] = tasks ? tasks[order[k]] : order[k];
+    CHK(dev_alloc(&S.rows, ntasks, (long *)nullptr));
+    AMG_HIP(hipMemcpy(S.rows, rows.data(), sizeof(int) * (size_t)ntasks, hipMemcpyHostToDevice));
+    return 0;
+}
+
+// ------------------------------------------------------------------ operator application
+static StreamArgs base_args(const DevCsr &M)
+{
+    StreamArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.Ap = M.Ap; a.Aj = M.Aj; a.Ax = M.Ax;
+    a.row_lo = 0; a.row_hi = M.nrows;
+    a.nnz_total = M.nnz;
+    return a;
+}
+
+int spmv(const DevCsr &M, StreamMode mode, const double *xg, const double *b, const double *v2,
+         double *out, double *out2, double c0, hipStream_t st)
+{
+    StreamArgs a = base_args(M);
+    a.xg = xg; a.b = b; a.v2 = v2; a.out = out; a.out2 = out2; a.c0 = c0;
+    return launch_stream(mode, a, st);
+}
+
+// one directional sweep of a scheduled (CSR flavour) Gauss-Seidel
+static int gs_sweep_csr(const Schedule &S, bool bsr1, double *x, const double *b, bool reverse,
+                        hipStream_t st)
+{
+    StreamArgs a = base_args(S.G);
+    a.xg = x; a.b = b; a.out = x; a.rowmap = S.rowmap; a.diagpos = S.diagpos;
+    int nl = S.nlevels();
+    for (int q = 0; q < nl; ++q) {
+        int l = reverse ? nl - 1 - q : q;
+        a.row_lo = S.level_ptr[l];
+        a.row_hi = S.level_ptr[l + 1];
+        CHK(launch_stream(bsr1 ? SM_GS_BSR1 : SM_GS, a, st));
+    }
+    return 0;
+}
+
+static int gs_sweep_block(const Schedule &S, const DevBsr &Ab, BlockMode mode, const double *Dinv,
+                          double *x, const double *b, bool reverse, hipStream_t st)
+{
+    BlockArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.Ap = Ab.Ap; a.Aj = Ab.Aj; a.Ax = Ab.Ax; a.bs = Ab.bs;
+    a.xin = x; a.xout = x; a.b = b; a.Dinv = Dinv; a.omega = 1.0;
+    a.intra_reverse = reverse ? 1 : 0;
+    int nl = S.nlevels();
+    for (int q = 0; q < nl; ++q) {
+        int l = reverse ? nl - 1 - q : q;
+        a.rows = S.rows + S.level_ptr[l];
+        a.count = S.level_ptr[l + 1] - S.level_ptr[l];
+        CHK(launch_block(mode, a, st));
+    }
+    return 0;
+}
+
+}  // namespace amg
+
+using namespace amg;
+
+// ------------------------------------------------------------------ relaxation on a level
+// x may be swapped with the level's alternate buffer (Jacobi writes out of place).
+static int relax(amg_hier *h, Level &L, Smoother &s, double *&x, double *&xalt, const double *b,
+                 bool x_zero)
+{
+    hipStream_t st = h->stream;
+    const int n = L.A.nrows;
+    const bool bsr = (L.fmt == AMG_FMT_BSR);
+    switch (s.kind) {
+    case AMG_SM_NONE:
+        return 0;
+    case AMG_SM_JACOBI:
+        // relaxation.py:357-427
+        for (int it = 0; it < s.iterations; ++it) {
+            if (bsr && L.R > 1) {
+                // bsr_jacobi: temp = x (relaxation.h:303-305), then x updated in place
+                AMG_HIP(hipMemcpyAsync(xalt, x, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st));
+                BlockArgs a;
+                std::memset(&a, 0, sizeof(a));
+                a.Ap = L.Ab.Ap; a.Aj = L.Ab.Aj; a.Ax = L.Ab.Ax; a.bs = L.Ab.bs;
+                a.first = 0; a.step = 1; a.count = L.Ab.nbrows;
+                a.xin = xalt; a.xout = x; a.b = b; a.omega = s.omega;
+                CHK(launch_block(BM_BSR_JACOBI, a, st));
+            } else {
+                CHK(spmv(L.A, bsr ? SM_JACOBI_BSR1 : SM_JACOBI, x, b, x, xalt, nullptr, s.omega, st));
+                std::swap(x, xalt);
+            }
+        }
+        return 0;
+    case AMG_SM_GAUSS_SEIDEL:
+    case AMG_SM_GAUSS_SEIDEL_INDEXED:
+    case AMG_SM_SOR: {
+        // relaxation.py:280-354 (gauss_seidel), :108-169 (sor), :671-741 (indexed)
+        const bool point_block = bsr && L.R > 1 && s.kind != AMG_SM_GAUSS_SEIDEL_INDEXED;
+        auto sweep_once = [&](bool reverse) -> int {
+            if (point_block)
+                return gs_sweep_block(*s.sched, L.Ab, BM_BSR_GS, nullptr, x, b, reverse, st);
+            return gs_sweep_csr(*s.sched, bsr && s.kind != AMG_SM_GAUSS_SEIDEL_INDEXED, x, b, reverse, st);
+        };
+        auto gs = [&](int iterations, int sweep) -> int {
+            for (int it = 0; it < iterations; ++it) {
+                if (sweep == AMG_SWEEP_FORWARD) CHK(sweep_once(false));
+                else if (sweep == AMG_SWEEP_BACKWARD) CHK(sweep_once(true));
+                else { CHK(sweep_once(false)); CHK(sweep_once(true)); }
+            }
+            return 0;
+        };
+        if (s.kind != AMG_SM_SOR) return gs(s.iterations, s.sweep);
+        for (int it = 0; it < s.iterations; ++it) {
+            AMG_HIP(hipMemcpyAsync(xalt, x, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st));
+            CHK(gs(1, s.sweep));
+            CHK(launch_sor_combine(x, xalt, s.omega, n, st));
+        }
+        return 0;
+    }
+    case AMG_SM_POLYNOMIAL: {
+        // relaxation.py:593-668.  r = b when x == 0 is bitwise identical to b - A*0.
+        const int nc = (int)s.coef.size();
+        for (int it = 0; it < s.iterations; ++it) {
+            const double *r;
+            double *hh = L.h, *hn = L.h2;
+            if (x_zero) {
+                r = b;
+                CHK(launch_scale(hh, b, s.coef[0], n, st));
+            } else {
+                CHK(spmv(L.A, SM_POLY_FIRST, x, b, nullptr, L.r, hh, s.coef[0], st));
+                r = L.r;
+            }
+            if (nc == 1) {
+                CHK(launch_axpy_inplace(x, hh, n, st));
+            } else {
+                for (int c = 1; c < nc - 1; ++c) {
+                    CHK(spmv(L.A, SM_POLY_STEP, hh, r, nullptr, hn, nullptr, s.coef[c], st));
+                    std::swap(hh, hn);
+                }
+                CHK(spmv(L.A, SM_POLY_LAST, hh, r, x, x, nullptr, s.coef[nc - 1], st));
+            }
+            x_zero = false;
+        }
+        return 0;
+    }
+    case AMG_SM_BLOCK_JACOBI: {
+        // relaxation.py:430-506
+        const DevBsr &Ab = s.Ablk_owned ? s.Ablk : L.Ab;
+        for (int it = 0; it < s.iterations; ++it) {
+            BlockArgs a;
+            std::memset(&a, 0, sizeof(a));
+            a.Ap = Ab.Ap; a.Aj = Ab.Aj; a.Ax = Ab.Ax; a.bs = Ab.bs;
+            a.first = 0; a.step = 1; a.count = Ab.nbrows;
+            a.xin = x; a.xout = xalt; a.b = b; a.Dinv = s.Dinv; a.omega = s.omega;
+            CHK(launch_block(BM_BLOCK_JACOBI, a, st));
+            std::swap(x, xalt);
+        }
+        return 0;
+    }
+    case AMG_SM_BLOCK_GAUSS_SEIDEL: {
+        // relaxation.py:509-590
+        const DevBsr &Ab = s.Ablk_owned ? s.Ablk : L.Ab;
+        for (int it = 0; it < s.iterations; ++it) {
+            if (s.sweep == AMG_SWEEP_FORWARD || s.sweep == AMG_SWEEP_SYMMETRIC)
+                CHK(gs_sweep_block(*s.sched, Ab, BM_BLOCK_GS, s.Dinv, x, b, false, st));
+            if (s.sweep == AMG_SWEEP_BACKWARD || s.sweep == AMG_SWEEP_SYMMETRIC)
+                CHK(gs_sweep_block(*s.sched, Ab, BM_BLOCK_GS, s.Dinv, x, b, true, st));
+        }
+        return 0;
+    }
+    }
+    set_error("unknown smoother kind");
+    return AMG_EINVAL;
+}
+
+// coarse_grid_solver (multilevel.py:554-720) on the last level
+static int coarse_solve(amg_hier *h, const double *b, double *&x, double *&xalt)
+{
+    Level &L = h->lv[h->nlevels - 1];
+    const int n = L.A.nrows;
+    if (L.A.nnz == 0 || h->coarse_kind == 0) {
+        // generic_solver: A.nnz == 0 -> zeros (multilevel.py:699-701); solver None -> 0*b
+        AMG_HIP(hipMemsetAsync(x, 0, sizeof(double) * (size_t)n, h->stream));
+        return 0;
+    }
+    if (h->coarse_kind == 1) return launch_dense_apply(h->coarse_Mt, b, x, n, h->stream);
+    AMG_HIP(hipMemsetAsync(x, 0, sizeof(double) * (size_t)n, h->stream));   // multilevel.py:675
+    return relax(h, L, h->coarse_sm, x, xalt, b, true);
+}
+
+// multilevel_solver.__solve (multilevel.py:473-548)
+static int cycle(amg_hier *h, int lvl, double *&x, double *&xalt, const double *b, int cyc, bool x_zero)
+{
+    Level &L = h->lv[lvl];
+    Level &Lc = h->lv[lvl + 1];
+    hipStream_t st = h->stream;
+    const int nc = Lc.A.nrows;
+
+    CHK(relax(h, L, L.sm[AMG_PRE], x, xalt, b, x_zero));                                   // :494
+    CHK(spmv(L.A, SM_RESIDUAL, x, b, nullptr, L.r, nullptr, 0.0, st));                     // :496
+    CHK(spmv(L.Rm, SM_MATVEC, L.r, nullptr, nullptr, Lc.b, nullptr, 0.0, st));             // :498
+    AMG_HIP(hipMemsetAsync(Lc.x, 0, sizeof(double) * (size_t)nc, st));                     // :499
+
+    if (lvl == h->nlevels - 2) {
+        CHK(coarse_solve(h, Lc.b, Lc.x, Lc.xalt));                                         // :501-502
+    } else if (cyc == AMG_CYCLE_V) {
+        CHK(cycle(h, lvl + 1, Lc.x, Lc.xalt, Lc.b, AMG_CYCLE_V, true));                    // :504-505
+    } else if (cyc == AMG_CYCLE_W) {
+        CHK(cycle(h, lvl + 1, Lc.x, Lc.xalt, Lc.b, cyc, true));                            // :506-508
+        CHK(cycle(h, lvl + 1, Lc.x, Lc.xalt, Lc.b, cyc, false));
+    } else if (cyc == AMG_CYCLE_F) {
+        CHK(cycle(h, lvl + 1, Lc.x, Lc.xalt, Lc.b, cyc, true));                            // :509-511
+        CHK(cycle(h, lvl + 1, Lc.x, Lc.xalt, Lc.b, AMG_CYCLE_V, false));
+    } else {
+        set_error("AMLI cycles are not implemented on the device path");
+        return AMG_ENOTIMPL;
+    }
+
+    CHK(spmv(L.P, SM_MATVEC_ACC, Lc.x, nullptr, nullptr, x, nullptr, 0.0, st));            // :544
+    CHK(relax(h, L, L.sm[AMG_POST], x, xalt, b, false));                                   // :545
+    return 0;
+}
+
+static int one_iteration(amg_hier *h, int cyc, bool x_zero)
+{
+    Level &L0 = h->lv[0];
+    if (h->nlevels == 1) return coarse_solve(h, L0.b, L0.x, L0.xalt);                      // :455-457
+    return cycle(h, 0, L0.x, L0.xalt, L0.b, cyc, x_zero);                                  // :459
+}
+
+static int residual_norm_to(amg_hier *h, double *slot)
+{
+    // util/linalg.py:109-112
+    Level &L0 = h->lv[0];
+    CHK(spmv(L0.A, SM_RESIDUAL, L0.x, L0.b, nullptr, L0.r, nullptr, 0.0, h->stream));
+    return launch_norm2(L0.r, L0.A.nrows, h->norm_scratch, slot, h->stream);
+}
+
+// ------------------------------------------------------------------ C API
+extern "C" {
+
+const char *amg_last_error(void) { return amg::last_error().c_str(); }
+
+int amg_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *amg_device_name(int device)
+{
+    static thread_local std::string name;
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, device) != hipSuccess) return "";
+    name = std::string(p.gcnArchName) + " " + p.name;
+    return name.c_str();
+}
+
+amg_hier *amg_hier_create(int nlevels, int device)
+{
+    if (nlevels < 1) { set_error("nlevels < 1"); return nullptr; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        set_error("no HIP device available (amgcore_hip has no CPU fallback)");
+        return nullptr;
+    }
+    if (device < 0 || device >= ndev) { set_error("bad device index"); return nullptr; }
+    if (hipSetDevice(device) != hipSuccess) { set_error("hipSetDevice failed"); return nullptr; }
+    amg_hier *h = new amg_hier();
+    h->device = device;
+    h->nlevels = nlevels;
+    h->lv.resize((size_t)nlevels);
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
+        set_error("stream/event creation failed");
+        delete h;
+        return nullptr;
+    }
+    return h;
+}
+
+static void free_smoother(Smoother &s)
+{
+    if (s.Dinv) hipFree(s.Dinv);
+    s.Dinv = nullptr;
+    if (s.Ablk_owned) free_bsr(s.Ablk);
+    if (s.sched && s.sched.use_count() == 1) s.sched->release();
+    s.sched.reset();
+}
+
+void amg_hier_destroy(amg_hier *h)
+{
+    if (!h) return;
+    hipSetDevice(h->device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    for (auto &L : h->lv) {
+        free_smoother(L.sm[0]);
+        free_smoother(L.sm[1]);
+        if (L.sched_csr && L.sched_csr.use_count() == 1) L.sched_csr->release();
+        if (L.sched_blk && L.sched_blk.use_count() == 1) L.sched_blk->release();
+        free_csr(L.A); free_csr(L.P); free_csr(L.Rm); free_bsr(L.Ab);
+        for (double *p : {L.x, L.xalt, L.b, L.r, L.h, L.h2}) if (p) hipFree(p);
+    }
+    free_smoother(h->coarse_sm);
+    if (h->coarse_Mt) hipFree(h->coarse_Mt);
+    if (h->norm_scratch) hipFree(h->norm_scratch);
+    if (h->res_dev) hipFree(h->res_dev);
+    if (h->ev0) hipEventDestroy(h->ev0);
+    if (h->ev1) hipEventDestroy(h->ev1);
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+}
+
+#define ENTER(h)                                                        \
+    if (!(h)) { set_error("null hierarchy"); return AMG_EINVAL; }       \
+    AMG_HIP(hipSetDevice((h)->device))
+
+int amg_hier_set_matrix(amg_hier *h, int lvl, int which, int fmt, int nrows, int ncols, int R, int C,
+                        const int *Ap, const int *Aj, const double *Ax, int on_device)
+{
+    ENTER(h);
+    if (lvl < 0 || lvl >= h->nlevels || which < 0 || which > 2) { set_error("bad level/which"); return AMG_EINVAL; }
+    if (fmt == AMG_FMT_CSR) { R = 1; C = 1; }
+    if (R < 1 || C < 1 || nrows % R || ncols % C) { set_error("bad block size"); return AMG_EINVAL; }
+    Level &L = h->lv[lvl];
+    DevCsr &M = (which == AMG_MAT_A) ? L.A : (which == AMG_MAT_P ? L.P : L.Rm);
+    free_csr(M);
+    if (on_device) {
+        if (fmt != AMG_FMT_CSR) { set_error("device adoption supports CSR only"); return AMG_ENOTIMPL; }
+        int last = 0;
+        AMG_HIP(hipMemcpy(&last, Ap + nrows, sizeof(int), hipMemcpyDeviceToHost));
+        M.nrows = nrows; M.ncols = ncols; M.nnz = last;
+        M.Ap = const_cast<int *>(Ap); M.Aj = const_cast<int *>(Aj); M.Ax = const_cast<double *>(Ax);
+        h->dev_bytes += 4L * (nrows + 1) + 12L * last;
+    } else if (fmt == AMG_FMT_CSR || (R == 1 && C == 1)) {
+        CHK(upload_csr(M, nrows, ncols, Ap, Aj, Ax, &h->dev_bytes));
+    } else {
+        std::vector<int> cp, cj;
+        std::vector<double> cx;
+        expand_bsr(nrows / R, R, C, Ap, Aj, Ax, cp, cj, cx);
+        CHK(upload_csr(M, nrows, ncols, cp.data(), cj.data(), cx.data(), &h->dev_bytes));
+    }
+    if (which == AMG_MAT_A) {
+        if (nrows != ncols) { set_error("A must be square"); return AMG_EINVAL; }
+        L.fmt = fmt; L.R = R; L.C = C; L.hasA = true;
+        free_bsr(L.Ab);
+        if (fmt == AMG_FMT_BSR && R == C && R > 1)
+            CHK(upload_bsr(L.Ab, nrows / R, R, Ap, Aj, Ax, &h->dev_bytes));
+    } else if (which == AMG_MAT_P) {
+        L.hasP = true;
+    } else {
+        L.hasR = true;
+    }
+    h->finalized = false;
+    return 0;
+}
+
+static int fill_smoother(amg_hier *h, Smoother &s, const amg_smoother_desc *d, int n)
+{
+    free_smoother(s);
+    s = Smoother();
+    if (!d) return 0;
+    s.kind = d->kind;
+    s.iterations = d->iterations > 0 ? d->iterations : 1;
+    s.sweep = d->sweep;
+    s.omega = d->omega;
+    if (d->kind == AMG_SM_POLYNOMIAL) {
+        if (d->ncoef < 1 || !d->coef) { set_error("polynomial smoother needs coefficients"); return AMG_EINVAL; }
+        s.coef.assign(d->coef, d->coef + d->ncoef);
+    }
+    if (d->kind == AMG_SM_BLOCK_JACOBI || d->kind == AMG_SM_BLOCK_GAUSS_SEIDEL) {
+        if (d->blocksize < 1 || n % d->blocksize || !d->Dinv) { set_error("block smoother needs blocksize and Dinv"); return AMG_EINVAL; }
+        s.bs = d->blocksize;
+        long cnt = (long)n * s.bs;
+        CHK(dev_alloc(&s.Dinv, cnt, &h->dev_bytes));
+        AMG_HIP(hipMemcpy(s.Dinv, d->Dinv, sizeof(double) * (size_t)cnt, hipMemcpyHostToDevice));
+    }
+    if (d->kind == AMG_SM_GAUSS_SEIDEL_INDEXED) {
+        if (d->nindices < 0 || (d->nindices && !d->indices)) { set_error("indexed GS needs indices"); return AMG_EINVAL; }
+        s.indices.assign(d->indices, d->indices + d->nindices);
+    }
+    return 0;
+}
+
+int amg_hier_set_smoother(amg_hier *h, int lvl, int which, const amg_smoother_desc *d)
+{
+    ENTER(h);
+    if (lvl < 0 || lvl >= h->nlevels || which < 0 || which > 1) { set_error("bad level/which"); return AMG_EINVAL; }
+    Level &L = h->lv[lvl];
+    if (!L.hasA) { set_error("set A before its smoothers"); return AMG_ESTATE; }
+    h->finalized = false;
+    return fill_smoother(h, L.sm[which], d, L.A.nrows);
+}
+
+/* re-blocked copy of A for a block smoother: relaxation.py:471,563 A.tobsr(blocksize) */
+int amg_hier_set_block_matrix(amg_hier *h, int lvl, int which, int nbrows, int bs, const int *Ap,
+                              const int *Aj, const double *Ax)
+{
+    ENTER(h);
+    if (lvl < 0 || lvl >= h->nlevels || which < 0 || which > 2) { set_error("bad level/which"); return AMG_EINVAL; }
+    Smoother &s = (which == 2) ? h->coarse_sm : h->lv[lvl].sm[which];
+    if (s.Ablk_owned) free_bsr(s.Ablk);
+    CHK(upload_bsr(s.Ablk, nbrows, bs, Ap, Aj, Ax, &h->dev_bytes));
+    s.Ablk_owned = true;
+    h->finalized = false;
+    return 0;
+}
+
+int amg_hier_set_coarse_dense(amg_hier *h, const double *M, int n)
+{
+    ENTER(h);
+    if (n < 0 || (n && !M)) { set_error("bad coarse matrix"); return AMG_EINVAL; }
+    if (h->coarse_Mt) hipFree(h->coarse_Mt);
+    h->coarse_Mt = nullptr;
+    std::vector<double> Mt((size_t)n * n);
+    for (int i = 0; i < n; ++i)
+        for (int k = 0; k < n; ++k) Mt[(size_t)k * n + i] = M[(size_t)i * n + k];
+    CHK(dev_alloc(&h->coarse_Mt, (long)n * n, &h->dev_bytes));
+    AMG_HIP(hipMemcpy(h->coarse_Mt, Mt.data(), sizeof(double) * Mt.size(), hipMemcpyHostToDevice));
+    h->coarse_n = n;
+    h->coarse_kind = 1;
+    return 0;
+}
+
+int amg_hier_set_coarse_smoother(amg_hier *h, const amg_smoother_desc *d)
+{
+    ENTER(h);
+    Level &L = h->lv[h->nlevels - 1];
+    if (!L.hasA) { set_error("set the coarsest A first"); return AMG_ESTATE; }
+    CHK(fill_smoother(h, h->coarse_sm, d, L.A.nrows));
+    h->coarse_kind = d ? 2 : 0;
+    h->finalized = false;
+    return 0;
+}
+
+static int need_schedule(amg_hier *h, Level &L, Smoother &s)
+{
+    const int n = L.A.nrows;
+    const bool bsr_pt = (L.fmt == AMG_FMT_BSR && L.R > 1);
+    if (s.kind == AMG_SM_GAUSS_SEIDEL || s.kind == AMG_SM_SOR) {
+        if (bsr_pt) {
+            if (!L.sched_blk) {
+                std::vector<int> bp((size_t)L.Ab.nbrows + 1), bj((size_t)L.Ab.nblocks);
+                AMG_HIP(hipMemcpy(bp.data(), L.Ab.Ap, sizeof(int) * bp.size(), hipMemcpyDeviceToHost));
+                if (!bj.empty()) AMG_HIP(hipMemcpy(bj.data(), L.Ab.Aj, sizeof(int) * bj.size(), hipMemcpyDeviceToHost));
+                L.sched_blk = std::make_shared<Schedule>();
+                CHK(build_block_schedule(bp.data(), bj.data(), L.Ab.nbrows, nullptr, L.Ab.nbrows, *L.sched_blk, h->stream));
+            }
+            s.sched = L.sched_blk;
+        } else {
+            if (!L.sched_csr) {
+                std::vector<int> ap((size_t)n + 1), aj((size_t)L.A.nnz);
+                std::vector<double> ax((size_t)L.A.nnz);
+                AMG_HIP(hipMemcpy(ap.data(), L.A.Ap, sizeof(int) * ap.size(), hipMemcpyDeviceToHost));
+                if (L.A.nnz) {
+                    AMG_HIP(hipMemcpy(aj.data(), L.A.Aj, sizeof(int) * aj.size(), hipMemcpyDeviceToHost));
+                    AMG_HIP(hipMemcpy(ax.data(), L.A.Ax, sizeof(double) * ax.size(), hipMemcpyDeviceToHost));
+                }
+                L.sched_csr = std::make_shared<Schedule>();
+                CHK(build_csr_schedule(ap.data(), aj.data(), ax.data(), n, nullptr, n, *L.sched_csr, h->stream));
+                h->dev_bytes += 12L * L.A.nnz + 12L * n;
+            }
+            s.sched = L.sched_csr;
+        }
+    } else if (s.kind == AMG_SM_GAUSS_SEIDEL_INDEXED) {
+        std::vector<int> ap((size_t)n + 1), aj((size_t)L.A.nnz);
+        std::vector<double> ax((size_t)L.A.nnz);
+        AMG_HIP(hipMemcpy(ap.data(), L.A.Ap, sizeof(int) * ap.size(), hipMemcpyDeviceToHost));
+        if (L.A.nnz) {
+            AMG_HIP(hipMemcpy(aj.data(), L.A.Aj, sizeof(int) * aj.size(), hipMemcpyDeviceToHost));
+            AMG_HIP(hipMemcpy(ax.data(), L.A.Ax, sizeof(double) * ax.size(), hipMemcpyDeviceToHost));
+        }
+        s.sched = std::make_shared<Schedule>();
+        CHK(build_csr_schedule(ap.data(), aj.data(), ax.data(), n, s.indices.data(), (int)s.indices.size(), *s.sched, h->stream));
+    } else if (s.kind == AMG_SM_BLOCK_GAUSS_SEIDEL || s.kind == AMG_SM_BLOCK_JACOBI) {
+        const DevBsr *Ab = s.Ablk_owned ? &s.Ablk : &L.Ab;
+        if (!Ab->Ap || Ab->bs != s.bs) {
+            set_error("block smoother: no BSR copy of A with the smoother's blocksize (amg_hier_set_block_matrix)");
+            return AMG_ESTATE;
+        }
+        if (s.kind == AMG_SM_BLOCK_GAUSS_SEIDEL) {
+            std::vector<int> bp((size_t)Ab->nbrows + 1), bj((size_t)Ab->nblocks);
+            AMG_HIP(hipMemcpy(bp.data(), Ab->Ap, sizeof(int) * bp.size(), hipMemcpyDeviceToHost));
+            if (!bj.empty()) AMG_HIP(hipMemcpy(bj.data(), Ab->Aj, sizeof(int) * bj.size(), hipMemcpyDeviceToHost));
+            s.sched = std::make_shared<Schedule>();
+            CHK(build_block_schedule(bp.data(), bj.data(), Ab->nbrows, nullptr, Ab->nbrows, *s.sched, h->stream));
+        }
+    }
+    return 0;
+}
+
+int amg_hier_finalize(amg_hier *h)
+{
+    ENTER(h);
+    for (int l = 0; l < h->nlevels; ++l) {
+        Level &L = h->lv[l];
+        if (!L.hasA) { set_error("level " + std::to_string(l) + " has no A"); return AMG_ESTATE; }
+        if (l < h->nlevels - 1) {
+            if (!L.hasP || !L.hasR) { set_error("level " + std::to_string(l) + " lacks P or R"); return AMG_ESTATE; }
+            Level &Lc = h->lv[l + 1];
+            if (!Lc.hasA || L.P.nrows != L.A.nrows || L.P.ncols != Lc.A.nrows || L.Rm.nrows != Lc.A.nrows ||
+                L.Rm.ncols != L.A.nrows) {
+                set_error("operator shapes of level " + std::to_string(l) + " are inconsistent");
+                return AMG_EINVAL;
+            }
+        }
+        const long n = L.A.nrows;
+        double **vecs[] = {&L.x, &L.xalt, &L.b, &L.r, &L.h, &L.h2};
+        for (double **p : vecs)
+            if (!*p) CHK(dev_alloc(p, n, &h->dev_bytes));
+        if (l < h->nlevels - 1) {
+            CHK(need_schedule(h, L, L.sm[0]));
+            CHK(need_schedule(h, L, L.sm[1]));
+        }
+    }
+    if (h->coarse_kind == 2) CHK(need_schedule(h, h->lv[h->nlevels - 1], h->coarse_sm));
+    if (h->coarse_kind == 1 && h->coarse_n != h->lv[h->nlevels - 1].A.nrows) {
+        set_error("coarse dense operator has the wrong size");
+        return AMG_EINVAL;
+    }
+    if (!h->norm_scratch) CHK(dev_alloc(&h->norm_scratch, 1024 + 8, &h->dev_bytes));
+    h->finalized = true;
+    return 0;
+}
+
+static int ensure_res(amg_hier *h, int cap)
+{
+    if (cap <= h->res_cap) return 0;
+    if (h->res_dev) hipFree(h->res_dev);
+    h->res_dev = nullptr;
+    CHK(dev_alloc(&h->res_dev, cap, &h->dev_bytes));
+    h->res_cap = cap;
+    return 0;
+}
+
+static int load_vectors(amg_hier *h, const double *b, const double *x, int flags)
+{
+    Level &L0 = h->lv[0];
+    const size_t bytes = sizeof(double) * (size_t)L0.A.nrows;
+    hipMemcpyKind kind = (flags & AMG_SOLVE_DEVICE_VECTORS) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    if (b != L0.b) AMG_HIP(hipMemcpyAsync(L0.b, b, bytes, kind, h->stream));
+    if (flags & AMG_SOLVE_X0_ZERO) AMG_HIP(hipMemsetAsync(L0.x, 0, bytes, h->stream));
+    else if (x != L0.x) AMG_HIP(hipMemcpyAsync(L0.x, x, bytes, kind, h->stream));
+    return 0;
+}
+
+static int store_x(amg_hier *h, double *x, int flags)
+{
+    Level &L0 = h->lv[0];
+    const size_t bytes = sizeof(double) * (size_t)L0.A.nrows;
+    hipMemcpyKind kind = (flags & AMG_SOLVE_DEVICE_VECTORS) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    if (x != L0.x) AMG_HIP(hipMemcpyAsync(x, L0.x, bytes, kind, h->stream));
+    AMG_HIP(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int amg_hier_solve(amg_hier *h, const double *b, double *x, double tol, int maxiter, int cyc,
+                   double *residuals, int *nres, int flags)
+{
+    ENTER(h);
+    if (!h->finalized) { set_error("hierarchy not finalised"); return AMG_ESTATE; }
+    if (!b || !x || !residuals || !nres || maxiter < 0) { set_error("bad solve arguments"); return AMG_EINVAL; }
+    Level &L0 = h->lv[0];
+    hipStream_t st = h->stream;
+    CHK(ensure_res(h, maxiter + 2));
+    CHK(load_vectors(h, b, x, flags));
+
+    // tol *= norm(b)  (multilevel.py:427-429)
+    double normb = 0.0;
+    CHK(launch_norm2(L0.b, L0.A.nrows, h->norm_scratch, h->res_dev + maxiter + 1, st));
+    AMG_HIP(hipMemcpyAsync(&normb, h->res_dev + maxiter + 1, sizeof(double), hipMemcpyDeviceToHost, st));
+    CHK(residual_norm_to(h, h->res_dev));                                         // :450
+    AMG_HIP(hipMemcpyAsync(&residuals[0], h->res_dev, sizeof(double), hipMemcpyDeviceToHost, st));
+    AMG_HIP(hipStreamSynchronize(st));
+    if (normb != 0.0) tol = tol * normb;
+
+    int k = 1;
+    bool x_zero = (flags & AMG_SOLVE_X0_ZERO) != 0;
+    const bool fixed = (flags & AMG_SOLVE_NO_EARLY_STOP) != 0;
+    AMG_HIP(hipEventRecord(h->ev0, st));
+    while (k <= maxiter && (fixed || residuals[k - 1] > tol)) {                   // :454
+        CHK(one_iteration(h, cyc, x_zero));
+        x_zero = false;
+        CHK(residual_norm_to(h, h->res_dev + k));                                 // :461
+        if (!fixed) {
+            AMG_HIP(hipMemcpyAsync(&residuals[k], h->res_dev + k, sizeof(double), hipMemcpyDeviceToHost, st));
+            AMG_HIP(hipStreamSynchronize(st));
+        }
+        ++k;
+    }
+    AMG_HIP(hipEventRecord(h->ev1, st));
+    if (fixed && k > 1)
+        AMG_HIP(hipMemcpyAsync(residuals + 1, h->res_dev + 1, sizeof(double) * (size_t)(k - 1), hipMemcpyDeviceToHost, st));
+    *nres = k;
+    CHK(store_x(h, x, flags));
+    float ms = 0.f;
+    AMG_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    h->last_ms = ms;
+    return 0;
+}
+
+int amg_hier_cycle(amg_hier *h, const double *b, double *x, int cyc, int flags)
+{
+    ENTER(h);
+    if (!h->finalized) { set_error("hierarchy not finalised"); return AMG_ESTATE; }
+    CHK(load_vectors(h, b, x, flags));
+    CHK(one_iteration(h, cyc, (flags & AMG_SOLVE_X0_ZERO) != 0));
+    return store_x(h, x, flags);
+}
+
+int amg_hier_relax(amg_hier *h, int lvl, int which, const double *b, double *x)
+{
+    ENTER(h);
+    if (!h->finalized) { set_error("hierarchy not finalised"); return AMG_ESTATE; }
+    if (lvl < 0 || lvl >= h->nlevels || which < 0 || which > 2) { set_error("bad level/which"); return AMG_EINVAL; }
+    Level &L = h->lv[lvl];
+    Smoother &s = (which == 2) ? h->coarse_sm : L.sm[which];
+    const size_t bytes = sizeof(double) * (size_t)L.A.nrows;
+    AMG_HIP(hipMemcpyAsync(L.b, b, bytes, hipMemcpyHostToDevice, h->stream));
+    AMG_HIP(hipMemcpyAsync(L.x, x, bytes, hipMemcpyHostToDevice, h->stream));
+    CHK(relax(h, L, s, L.x, L.xalt, L.b, false));
+    AMG_HIP(hipMemcpyAsync(x, L.x, bytes, hipMemcpyDeviceToHost, h->stream));
+    AMG_HIP(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int amg_hier_matvec(amg_hier *h, int lvl, int which, const double *x, double *y)
+{
+    ENTER(h);
+    if (lvl < 0 || lvl >= h->nlevels || which < 0 || which > 2) { set_error("bad level/which"); return AMG_EINVAL; }
+    Level &L = h->lv[lvl];
+    const DevCsr &M = (which == AMG_MAT_A) ? L.A : (which == AMG_MAT_P ? L.P : L.Rm);
+    if (!M.Ap) { set_error("operator not set"); return AMG_ESTATE; }
+    double *dx = nullptr, *dy = nullptr;
+    CHK(dev_alloc(&dx, M.ncols, (long *)nullptr));
+    CHK(dev_alloc(&dy, M.nrows, (long *)nullptr));
+    AMG_HIP(hipMemcpy(dx, x, sizeof(double) * (size_t)M.ncols, hipMemcpyHostToDevice));
+    int rc = spmv(M, SM_MATVEC, dx, nullptr, nullptr, dy, nullptr, 0.0, h->stream);
+    if (rc == 0) {
+        hipStreamSynchronize(h->stream);
+        hipMemcpy(y, dy, sizeof(double) * (size_t)M.nrows, hipMemcpyDeviceToHost);
+    }
+    hipFree(dx); hipFree(dy);
+    return rc;
+}
+
+// algorithmic bytes, SURVEY.md 8(d): bytes_spmv(M) = 12 nnz + 4 (rows+1) + 8 cols + 8 rows
+static double bytes_spmv(const DevCsr &M)
+{
+    return 12.0 * (double)M.nnz + 4.0 * (M.nrows + 1.0) + 8.0 * M.ncols + 8.0 * M.nrows;
+}
+
+static double smoother_apps(const Smoother &s, bool x_zero)
+{
+    // number of "A-applications" (bytes_spmv(A)+8n each) of one smoother call
+    switch (s.kind) {
+    case AMG_SM_JACOBI: case AMG_SM_BLOCK_JACOBI: return s.iterations;
+    case AMG_SM_GAUSS_SEIDEL: case AMG_SM_GAUSS_SEIDEL_INDEXED: case AMG_SM_BLOCK_GAUSS_SEIDEL: case AMG_SM_SOR:
+        return s.iterations * (s.sweep == AMG_SWEEP_SYMMETRIC ? 2.0 : 1.0);
+    case AMG_SM_POLYNOMIAL: {
+        double d = (double)s.coef.size();
+        return s.iterations * d - (x_zero ? 1.0 : 0.0);
+    }
+    default: return 0.0;
+    }
+}
+
+double amg_hier_cycle_bytes(amg_hier *h, int cyc)
+{
+    if (!h) return 0.0;
+    // visits per level for V/W/F
+    std::vector<double> visits((size_t)h->nlevels, 0.0);
+    std::vector<double> first((size_t)h->nlevels, 0.0);
+    visits[0] = 1.0;
+    for (int l = 1; l < h->nlevels; ++l) {
+        if (cyc == AMG_CYCLE_W) visits[l] = 2.0 * visits[l - 1];
+        else if (cyc == AMG_CYCLE_F) visits[l] = visits[l - 1] + 1.0;
+        else visits[l] = 1.0;
+    }
+    double total = 0.0;
+    for (int l = 0; l < h->nlevels - 1; ++l) {
+        Level &L = h->lv[l];
+        double n = L.A.nrows;
+        double app = bytes_spmv(L.A) + 8.0 * n;
+        // every visit: pre + residual + post; coarse levels enter with x == 0 on first of
+        // each pair of visits -- counted as zero-start for all coarse presmooths of a V cycle
+        double k = smoother_apps(L.sm[0], l > 0) + 1.0 + smoother_apps(L.sm[1], false);
+        if (l == 0) k += 1.0;   // outer residual norm (multilevel.py:461)
+        total += visits[l] * (k * app + bytes_spmv(L.Rm) + bytes_spmv(L.P) + 8.0 * n);
+    }
+    double ncs = h->lv[h->nlevels - 1].A.nrows;
+    total += visits[h->nlevels - 1] * (8.0 * ncs * ncs + 16.0 * ncs);
+    return total;
+}
+
+double amg_hier_last_solve_ms(amg_hier *h) { return h ? h->last_ms : 0.0; }
+long amg_hier_device_bytes(amg_hier *h) { return h ? h->dev_bytes : 0; }
+void *amg_hier_stream(amg_hier *h) { return h ? (void *)h->stream : nullptr; }
+double *amg_hier_dev_x(amg_hier *h) { return h && h->finalized ? h->lv[0].x : nullptr; }
+double *amg_hier_dev_b(amg_hier *h) { return h && h->finalized ? h->lv[0].b : nullptr; }
+
+int amg_hier_time_spmv(amg_hier *h, int lvl, int which, int mode, int reps, double *ms)
+{
+    ENTER(h);
+    if (!h->finalized) { set_error("hierarchy not finalised"); return AMG_ESTATE; }
+    if (lvl < 0 || lvl >= h->nlevels || reps < 1 || !ms) { set_error("bad arguments"); return AMG_EINVAL; }
+    Level &L = h->lv[lvl];
+    const DevCsr &M = (which == AMG_MAT_A) ? L.A : (which == AMG_MAT_P ? L.P : L.Rm);
+    if (!M.Ap) { set_error("operator not set"); return AMG_ESTATE; }
+    // vectors: A: x -> r ; P: coarse x -> h ; R: r -> coarse b
+    const double *in; double *out;
+    if (which == AMG_MAT_A) { in = L.x; out = L.r; }
+    else if (which == AMG_MAT_P) { in = h->lv[lvl + 1].x; out = L.h; }
+    else { in = L.r; out = h->lv[lvl + 1].b; }
+    StreamMode sm = (mode == 1 && which == AMG_MAT_A) ? SM_RESIDUAL : SM_MATVEC;
+    CHK(spmv(M, sm, in, L.b, nullptr, out, nullptr, 0.0, h->stream));   // warm-up
+    AMG_HIP(hipEventRecord(h->ev0, h->stream));
+    for (int r = 0; r < reps; ++r) CHK(spmv(M, sm, in, L.b, nullptr, out, nullptr, 0.0, h->stream));
+    AMG_HIP(hipEventRecord(h->ev1, h->stream));
+    AMG_HIP(hipStreamSynchronize(h->stream));
+    float t = 0.f;
+    AMG_HIP(hipEventElapsedTime(&t, h->ev0, h->ev1));
+    *ms = t / reps;
+    return 0;
+}
+
+void amg_set_stream_variant(int v) { amg::set_stream_variant(v); }
+void amg_set_xcd_chunk(int c) { amg::set_xcd_chunk(c); }
+
+}  // extern "C"

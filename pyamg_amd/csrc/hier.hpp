@@ -1,0 +1,82 @@
+// Device-resident multigrid hierarchy (host-side engine).
+#pragma once
+#include "amg_dev.hpp"
+#include "../../include/amgcore_hip.h"
+
+#include <memory>
+
+namespace amg {
+
+// Dependency-level schedule of a sequential sweep (Gauss-Seidel family).
+// Tasks = the sequence of rows the reference's loop visits.  Two tasks conflict
+// when one writes an unknown the other reads or writes; level(t) = 1 + max level
+// of the earlier tasks it conflicts with.  Running levels in ascending order
+// (tasks of one level concurrently) reproduces the sequential sweep bit for
+// bit; because the conflict relation is symmetric, running the levels in
+// DESCENDING order reproduces the reversed sweep.
+struct Schedule {
+    int ntasks = 0;
+    std::vector<int> level_ptr;   // host, size nlevels+1, offsets into the task order
+    // CSR flavour: rows copied in level order (coalesced streaming per level)
+    DevCsr G;                     // permuted rows, ORIGINAL column indices
+    int *rowmap = nullptr;        // device: original row of permuted row
+    int *diagpos = nullptr;       // device: position of the diagonal entry in G (-1 if none)
+    // BSR flavour: block rows listed in level order
+    int *rows = nullptr;          // device
+    int nlevels() const { return (int)level_ptr.size() - 1; }
+    void release();
+};
+
+int build_levels(int n, const int *Ap, const int *Aj, const int *tasks, int ntasks,
+                 std::vector<int> &level_ptr, std::vector<int> &order);
+int build_csr_schedule(const int *Ap, const int *Aj, const double *Ax, int n, const int *tasks,
+                       int ntasks, Schedule &S, hipStream_t st);
+int build_block_schedule(const int *Ap, const int *Aj, int nb, const int *tasks, int ntasks,
+                         Schedule &S, hipStream_t st);
+
+struct Smoother {
+    int kind = AMG_SM_NONE;
+    int iterations = 1;
+    int sweep = AMG_SWEEP_FORWARD;
+    double omega = 1.0;
+    std::vector<double> coef;
+    int bs = 1;
+    double *Dinv = nullptr;          // device
+    std::vector<int> indices;        // gauss_seidel_indexed
+    DevBsr Ablk;                     // re-blocked A for block smoothers (owned) ...
+    bool Ablk_owned = false;
+    std::shared_ptr<Schedule> sched; // GS-type smoothers
+};
+
+struct Level {
+    int fmt = AMG_FMT_CSR, R = 1, C = 1;   // container of A in the reference hierarchy
+    DevCsr A, P, Rm;
+    DevBsr Ab;                             // A's own blocks when fmt == BSR and R == C > 1
+    bool hasA = false, hasP = false, hasR = false;
+    Smoother sm[2];
+    // work vectors (device), length n
+    double *x = nullptr, *xalt = nullptr, *b = nullptr, *r = nullptr, *h = nullptr, *h2 = nullptr;
+    std::shared_ptr<Schedule> sched_csr, sched_blk;   // natural-order schedules, shared pre/post
+};
+
+}  // namespace amg
+
+struct amg_hier {
+    int device = 0;
+    int nlevels = 0;
+    std::vector<amg::Level> lv;
+    hipStream_t stream = nullptr;
+    bool finalized = false;
+    // coarse solve
+    int coarse_kind = 0;              // 0 none (zero correction), 1 dense, 2 smoother
+    double *coarse_Mt = nullptr;
+    int coarse_n = 0;
+    amg::Smoother coarse_sm;
+    // scratch
+    double *norm_scratch = nullptr;   // 1024 partials
+    double *res_dev = nullptr;        // residual history on device
+    int res_cap = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double last_ms = 0.0;
+    long dev_bytes = 0;
+};

@@ -1,0 +1,575 @@
+// HIP kernels for gfx950 (MI355X): the solve-phase hot path of the AMG cycle.
+//
+// Everything here is HBM-bandwidth bound (~0.17 flop/byte): no MFMA.  The
+// design goals are (1) every matrix byte is read once, fully coalesced, (2) the
+// gathered vector is served from L2 / Infinity Cache, (3) per-row sums are
+// accumulated strictly left to right with no FMA contraction (this file is
+// compiled with -ffp-contract=off), so results are bit-identical to the
+// reference's sequential C++ / scipy loops.
+//
+// csr_stream: a workgroup of 256 threads owns 256 consecutive rows.  The
+// products a_ij * x_j of those rows form one contiguous slice of the CSR arrays;
+// the workgroup streams that slice through an LDS tile with coalesced loads
+// (lane k -> entry k), then thread t walks the products of row t in LDS in
+// storage order.  Short rows (7-pt stencil) and long rows (30-60 nnz on coarse
+// SA levels) go through the same path; a slice longer than the tile is
+// processed in several passes with the running sums kept in registers.
+#include "amg_dev.hpp"
+
+namespace amg {
+
+constexpr int WG = 256;      // threads = rows per workgroup
+constexpr int TILE = 2048;   // products staged in LDS per pass (16 KiB)
+
+static int g_stream_variant = 1;
+static int g_xcd_chunk = 0;
+void set_stream_variant(int v) { g_stream_variant = v; }
+int stream_variant() { return g_stream_variant; }
+void set_xcd_chunk(int c) { g_xcd_chunk = c; }
+
+// Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2).
+// With chunk > 0, each group of 8*chunk consecutive logical blocks is laid out
+// so that one XCD sweeps `chunk` consecutive row blocks: neighbouring rows (and
+// the x entries they gather) then live in one L2.  Speed only, never correctness.
+__device__ __forceinline__ int remap_block(int b, int nb, int chunk)
+{
+    if (chunk <= 0) return b;
+    int gsz = 8 * chunk;
+    int g = b / gsz;
+    int base = g * gsz;
+    int n_g = min(gsz, nb - base);
+    int l = b - base;
+    int xcd = l & 7, j = l >> 3;
+    int q = n_g >> 3, r = n_g & 7;
+    int start = xcd * q + min(xcd, r);
+    return base + start + j;
+}
+
+template <int MODE> struct ModeTraits {
+    static constexpr bool jac = (MODE == SM_JACOBI || MODE == SM_JACOBI_BSR1);
+    static constexpr bool gs = (MODE == SM_GS || MODE == SM_GS_BSR1);
+    static constexpr bool sub = (MODE == SM_JACOBI_BSR1 || MODE == SM_GS_BSR1);
+};
+
+template <int MODE, int VEC>
+__global__ __launch_bounds__(WG) void csr_stream_kernel(StreamArgs a, int xcd_chunk)
+{
+    const long nnz_total = a.nnz_total;
+    using MT = ModeTraits<MODE>;
+    __shared__ double sp[TILE];
+    __shared__ int sAp[WG + 1];
+    __shared__ double sdiag[MT::jac ? WG : 1];
+
+    const int t = threadIdx.x;
+    const int blk = remap_block(blockIdx.x, gridDim.x, xcd_chunk);
+    const int r0 = a.row_lo + blk * WG;
+    const int nr = min(WG, a.row_hi - r0);
+
+    for (int i = t; i <= nr; i += WG) sAp[i] = a.Ap[r0 + i];
+    if (MT::jac) sdiag[t] = 0.0;
+    __syncthreads();
+
+    const int kbeg = sAp[0], kend = sAp[nr];
+    const int my_s = (t < nr) ? sAp[t] : kend;
+    const int my_e = (t < nr) ? sAp[t + 1] : kend;
+
+    int row = r0 + t;            // index into b / out (original numbering)
+    int dpos = -1;
+    if (MT::gs && t < nr) {
+        if (a.rowmap) row = a.rowmap[r0 + t];
+        dpos = a.diagpos[r0 + t];
+    }
+    double acc = 0.0;
+    if (MT::sub && t < nr) acc = a.b[row];
+
+    // tile origin aligned to 4 entries so that 16-byte loads are aligned
+    const int abeg = VEC ? (kbeg & ~3) : kbeg;
+
+    for (int tile_lo = abeg; tile_lo < kend; tile_lo += TILE) {
+        const int tile_hi = min(tile_lo + TILE, kend);
+        if (VEC) {
+            // each thread: 2 quads of 4 consecutive entries
+            int e[2];
+            int4 cj[2];
+            double2 av[2][2];
+            bool full[2], any[2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                e[p] = tile_lo + p * (4 * WG) + 4 * t;
+                any[p] = e[p] < tile_hi;
+                full[p] = any[p] && ((long)e[p] + 4 <= nnz_total);
+                if (full[p]) {
+                    cj[p] = *reinterpret_cast<const int4 *>(a.Aj + e[p]);
+                    av[p][0] = *reinterpret_cast<const double2 *>(a.Ax + e[p]);
+                    av[p][1] = *reinterpret_cast<const double2 *>(a.Ax + e[p] + 2);
+                } else if (any[p]) {
+                    int c[4]; double v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        bool ok = (long)e[p] + u < nnz_total;
+                        c[u] = ok ? a.Aj[e[p] + u] : 0;
+                        v[u] = ok ? a.Ax[e[p] + u] : 0.0;
+                    }
+                    cj[p] = make_int4(c[0], c[1], c[2], c[3]);
+                    av[p][0] = make_double2(v[0], v[1]);
+                    av[p][1] = make_double2(v[2], v[3]);
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                if (!any[p]) continue;
+                int c[4] = {cj[p].x, cj[p].y, cj[p].z, cj[p].w};
+                double v[4] = {av[p][0].x, av[p][0].y, av[p][1].x, av[p][1].y};
+                double xv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) xv[u] = a.xg[c[u]];
+                double pr[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    pr[u] = v[u] * xv[u];
+                    if (MT::jac) {
+                        int k = e[p] + u;
+                        int lc = c[u] - r0;
+                        if ((unsigned)lc < (unsigned)nr && k >= sAp[lc] && k < sAp[lc + 1]) {
+                            sdiag[lc] = v[u];
+                            pr[u] = 0.0;
+                        }
+                    }
+                }
+                int q = e[p] - tile_lo;
+                *reinterpret_cast<double2 *>(&sp[q]) = make_double2(pr[0], pr[1]);
+                *reinterpret_cast<double2 *>(&sp[q + 2]) = make_double2(pr[2], pr[3]);
+            }
+        } else {
+            constexpr int U = TILE / WG;   // 8 entries per thread, lane-contiguous
+            int c[U];
+            double v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                int k = tile_lo + u * WG + t;
+                bool ok = k < tile_hi;
+                c[u] = ok ? a.Aj[k] : 0;
+                v[u] = ok ? a.Ax[k] : 0.0;
+            }
+            double xv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                int k = tile_lo + u * WG + t;
+                xv[u] = (k < tile_hi) ? a.xg[c[u]] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                int k = tile_lo + u * WG + t;
+                if (k < tile_hi) {
+                    double pr = v[u] * xv[u];
+                    if (MT::jac) {
+                        int lc = c[u] - r0;
+                        if ((unsigned)lc < (unsigned)nr && k >= sAp[lc] && k < sAp[lc + 1]) {
+                            sdiag[lc] = v[u];
+                            pr = 0.0;
+                        }
+                    }
+                    sp[u * WG + t] = pr;
+                }
+            }
+        }
+        __syncthreads();
+        {
+            const int s = max(my_s, tile_lo), e2 = min(my_e, tile_hi);
+            for (int k = s; k < e2; ++k) {
+                double p = sp[k - tile_lo];
+                if (MT::gs && k == dpos) continue;
+                acc = MT::sub ? (acc - p) : (acc + p);
+            }
+        }
+        __syncthreads();
+    }
+
+    if (t >= nr) return;
+    const int i = r0 + t;
+    if (MODE == SM_MATVEC) {
+        a.out[i] = acc;
+    } else if (MODE == SM_MATVEC_ACC) {
+        a.out[i] = a.out[i] + acc;
+    } else if (MODE == SM_RESIDUAL) {
+        a.out[i] = a.b[i] - acc;
+    } else if (MODE == SM_POLY_FIRST) {
+        double r = a.b[i] - acc;
+        a.out[i] = r;
+        a.out2[i] = a.c0 * r;
+    } else if (MODE == SM_POLY_STEP) {
+        double cr = a.c0 * a.b[i];
+        a.out[i] = cr + acc;
+    } else if (MODE == SM_POLY_LAST) {
+        double cr = a.c0 * a.b[i];
+        double h = cr + acc;
+        a.out[i] = a.v2[i] + h;
+    } else if (MODE == SM_JACOBI) {
+        double d = sdiag[t];
+        double told = a.v2[i];
+        if (d != 0.0) {
+            double q = (a.b[i] - acc) / d;
+            double t1 = (1.0 - a.c0) * told;
+            double t2 = a.c0 * q;
+            a.out[i] = t1 + t2;
+        } else {
+            a.out[i] = told;
+        }
+    } else if (MODE == SM_JACOBI_BSR1) {
+        double d = sdiag[t];
+        double told = a.v2[i];
+        if (d != 0.0) {
+            double t1 = (1.0 - a.c0) * told;
+            double t2 = (a.c0 * acc) / d;
+            a.out[i] = t1 + t2;
+        } else {
+            a.out[i] = told;
+        }
+    } else if (MODE == SM_GS) {
+        double d = (dpos >= 0) ? a.Ax[dpos] : 0.0;
+        if (d != 0.0) a.out[row] = (a.b[row] - acc) / d;
+    } else if (MODE == SM_GS_BSR1) {
+        double d = (dpos >= 0) ? a.Ax[dpos] : 0.0;
+        if (d != 0.0) a.out[row] = acc / d;
+    }
+}
+
+template <int MODE>
+static int launch_stream_mode(const StreamArgs &a, hipStream_t st)
+{
+    int rows = a.row_hi - a.row_lo;
+    if (rows <= 0) return 0;
+    int nb = (rows + WG - 1) / WG;
+    if (g_stream_variant)
+        hipLaunchKernelGGL((csr_stream_kernel<MODE, 1>), dim3(nb), dim3(WG), 0, st, a, g_xcd_chunk);
+    else
+        hipLaunchKernelGGL((csr_stream_kernel<MODE, 0>), dim3(nb), dim3(WG), 0, st, a, g_xcd_chunk);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "csr_stream launch", __FILE__, __LINE__);
+    return 0;
+}
+
+int launch_stream(StreamMode mode, const StreamArgs &a, hipStream_t st)
+{
+    switch (mode) {
+    case SM_MATVEC: return launch_stream_mode<SM_MATVEC>(a, st);
+    case SM_MATVEC_ACC: return launch_stream_mode<SM_MATVEC_ACC>(a, st);
+    case SM_RESIDUAL: return launch_stream_mode<SM_RESIDUAL>(a, st);
+    case SM_POLY_FIRST: return launch_stream_mode<SM_POLY_FIRST>(a, st);
+    case SM_POLY_STEP: return launch_stream_mode<SM_POLY_STEP>(a, st);
+    case SM_POLY_LAST: return launch_stream_mode<SM_POLY_LAST>(a, st);
+    case SM_JACOBI: return launch_stream_mode<SM_JACOBI>(a, st);
+    case SM_JACOBI_BSR1: return launch_stream_mode<SM_JACOBI_BSR1>(a, st);
+    case SM_GS: return launch_stream_mode<SM_GS>(a, st);
+    case SM_GS_BSR1: return launch_stream_mode<SM_GS_BSR1>(a, st);
+    }
+    set_error("launch_stream: bad mode");
+    return -1;
+}
+
+// ---------------------------------------------------------------------------
+// thread-per-row Jacobi for strided row ranges (amg_core.jacobi with a
+// row_step other than +-1): same arithmetic, rows are independent.
+// ---------------------------------------------------------------------------
+__global__ void jacobi_rows_kernel(const int *Ap, const int *Aj, const double *Ax,
+                                   const double *temp, const double *b, double *x, int row_start,
+                                   int count, int row_step, double omega)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    int i = row_start + t * row_step;
+    double rsum = 0.0, diag = 0.0;
+    for (int jj = Ap[i]; jj < Ap[i + 1]; ++jj) {
+        int j = Aj[jj];
+        if (i == j) diag = Ax[jj];
+        else rsum = rsum + Ax[jj] * temp[j];
+    }
+    if (diag != 0.0) {
+        double q = (b[i] - rsum) / diag;
+        double t1 = (1.0 - omega) * temp[i];
+        double t2 = omega * q;
+        x[i] = t1 + t2;
+    }
+}
+
+int launch_jacobi_rows(const DevCsr &A, const double *temp, const double *b, double *x,
+                       int row_start, int count, int row_step, double omega, hipStream_t st)
+{
+    if (count <= 0) return 0;
+    hipLaunchKernelGGL(jacobi_rows_kernel, dim3((count + 255) / 256), dim3(256), 0, st, A.Ap, A.Aj,
+                       A.Ax, temp, b, x, row_start, count, row_step, omega);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "jacobi_rows launch", __FILE__, __LINE__);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// vector kernels (grid-stride, 16-byte accesses where alignment allows)
+// ---------------------------------------------------------------------------
+static inline int vec_grid(long n)
+{
+    long nb = (n + 255) / 256;
+    if (nb > 256L * 16) nb = 256L * 16;
+    if (nb < 1) nb = 1;
+    return (int)nb;
+}
+
+__global__ void scale_kernel(double *out, const double *in, double c, long n)
+{
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        out[i] = c * in[i];
+}
+__global__ void sor_combine_kernel(double *x, const double *xold, double omega, long n)
+{
+    // relaxation.py:166-168: x *= omega; x_old *= (1-omega); x += x_old
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        double a = x[i] * omega;
+        double b = xold[i] * (1.0 - omega);
+        x[i] = a + b;
+    }
+}
+__global__ void axpy_inplace_kernel(double *x, const double *h, long n)
+{
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        x[i] = x[i] + h[i];
+}
+__global__ void sub_kernel(double *out, const double *a, const double *b, long n)
+{
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        out[i] = a[i] - b[i];
+}
+__global__ void copy_strided_kernel(double *dst, const double *src, int start, int count, int step)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < count) {
+        int i = start + t * step;
+        dst[i] = src[i];
+    }
+}
+
+#define LAUNCH_CHECK(name)                                                      \
+    do {                                                                        \
+        hipError_t e__ = hipGetLastError();                                     \
+        if (e__ != hipSuccess) return hip_fail(e__, name, __FILE__, __LINE__);  \
+        return 0;                                                               \
+    } while (0)
+
+int launch_scale(double *out, const double *in, double c, long n, hipStream_t st)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(scale_kernel, dim3(vec_grid(n)), dim3(256), 0, st, out, in, c, n);
+    LAUNCH_CHECK("scale");
+}
+int launch_sor_combine(double *x, const double *xold, double omega, long n, hipStream_t st)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(sor_combine_kernel, dim3(vec_grid(n)), dim3(256), 0, st, x, xold, omega, n);
+    LAUNCH_CHECK("sor_combine");
+}
+int launch_axpy_inplace(double *x, const double *h, long n, hipStream_t st)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(axpy_inplace_kernel, dim3(vec_grid(n)), dim3(256), 0, st, x, h, n);
+    LAUNCH_CHECK("axpy_inplace");
+}
+int launch_sub(double *out, const double *a, const double *b, long n, hipStream_t st)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(sub_kernel, dim3(vec_grid(n)), dim3(256), 0, st, out, a, b, n);
+    LAUNCH_CHECK("sub");
+}
+int launch_copy_strided(double *dst, const double *src, int start, int count, int step, hipStream_t st)
+{
+    if (count <= 0) return 0;
+    hipLaunchKernelGGL(copy_strided_kernel, dim3((count + 255) / 256), dim3(256), 0, st, dst, src,
+                       start, count, step);
+    LAUNCH_CHECK("copy_strided");
+}
+
+// ---------------------------------------------------------------------------
+// 2-norm: deterministic two-stage tree reduction (fixed grid, fixed order)
+// ---------------------------------------------------------------------------
+constexpr int NORM_BLOCKS = 1024;
+
+__device__ __forceinline__ double block_reduce_sum(double v, double *smem)
+{
+    // wave64 butterfly, then 4 waves through LDS
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) smem[w] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0) {
+        int nw = blockDim.x >> 6;
+        for (int k = 0; k < nw; ++k) r += smem[k];
+    }
+    return r;
+}
+
+__global__ __launch_bounds__(256) void sumsq_stage1(const double *x, long n, double *partial)
+{
+    __shared__ double smem[4];
+    double s0 = 0.0, s1 = 0.0;
+    long stride = (long)gridDim.x * blockDim.x;
+    long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    for (; i + stride < n; i += 2 * stride) {
+        double a = x[i], b = x[i + stride];
+        s0 += a * a;
+        s1 += b * b;
+    }
+    if (i < n) { double a = x[i]; s0 += a * a; }
+    double r = block_reduce_sum(s0 + s1, smem);
+    if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+
+__global__ __launch_bounds__(256) void sumsq_stage2(const double *partial, int np, double *result)
+{
+    __shared__ double smem[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < np; i += blockDim.x) s += partial[i];
+    double r = block_reduce_sum(s, smem);
+    if (threadIdx.x == 0) *result = sqrt(r);
+}
+
+int launch_norm2(const double *x, long n, double *scratch, double *result_dev, hipStream_t st)
+{
+    int nb = (int)((n + 255) / 256);
+    if (nb > NORM_BLOCKS) nb = NORM_BLOCKS;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(sumsq_stage1, dim3(nb), dim3(256), 0, st, x, n, scratch);
+    hipLaunchKernelGGL(sumsq_stage2, dim3(1), dim3(256), 0, st, scratch, nb, result_dev);
+    LAUNCH_CHECK("norm2");
+}
+
+// ---------------------------------------------------------------------------
+// coarse solve: x = M b, M dense n x n (n <= a few hundred), stored transposed
+// so that lane i streams Mt[k*n+i] coalesced; strict left-to-right row sums
+// ---------------------------------------------------------------------------
+__global__ void dense_apply_kernel(const double *Mt, const double *b, double *x, int n)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int k = 0; k < n; ++k) s = s + Mt[(long)k * n + i] * b[k];
+    x[i] = s;
+}
+
+int launch_dense_apply(const double *Mt, const double *b, double *x, int n, hipStream_t st)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(dense_apply_kernel, dim3((n + 63) / 64), dim3(64), 0, st, Mt, b, x, n);
+    LAUNCH_CHECK("dense_apply");
+}
+
+// ---------------------------------------------------------------------------
+// BSR relaxation kernels, one thread per block row (exact restatement of
+// relaxation.h:90-173, 268-360, 662-728, 756-810).  Independent block rows of
+// one launch are either all rows (Jacobi) or one dependency level (GS).
+// ---------------------------------------------------------------------------
+constexpr int MAXBS = 16;
+
+template <int BMODE>
+__global__ void block_kernel(BlockArgs a)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= a.count) return;
+    const int i = a.rows ? a.rows[t] : a.first + t * a.step;
+    const int bs = a.bs, B2 = bs * bs;
+    double rsum[MAXBS], v[MAXBS];
+    const long ib = (long)i * bs;
+
+    if (BMODE == BM_BSR_JACOBI || BMODE == BM_BSR_GS) {
+        long diag_ptr = -1;
+        for (int k = 0; k < bs; ++k) rsum[k] = a.b[ib + k];
+        for (int jj = a.Ap[i]; jj < a.Ap[i + 1]; ++jj) {
+            int j = a.Aj[jj];
+            if (i == j) {
+                diag_ptr = (long)jj * B2;
+            } else {
+                const double *blk = a.Ax + (long)jj * B2;
+                const double *xj = a.xin + (long)j * bs;
+                for (int r = 0; r < bs; ++r) {
+                    double s = 0.0;
+                    for (int c = 0; c < bs; ++c) s = s + blk[r * bs + c] * xj[c];
+                    v[r] = s;
+                }
+                for (int m = 0; m < bs; ++m) rsum[m] = rsum[m] - v[m];
+            }
+        }
+        if (diag_ptr != -1) {
+            int step = a.intra_reverse ? -1 : 1;
+            int k0 = a.intra_reverse ? bs - 1 : 0, k1 = a.intra_reverse ? -1 : bs;
+            for (int k = k0; k != k1; k += step) {
+                double diag = 1.0;
+                for (int kk = k0; kk != k1; kk += step) {
+                    if (k == kk) {
+                        diag = a.Ax[k * bs + kk + diag_ptr];
+                    } else {
+                        // Jacobi reads temp (xin); GS reads the live x (xout), which this
+                        // thread may already have updated for kk ahead of k in sweep order
+                        double xv = (BMODE == BM_BSR_JACOBI) ? a.xin[ib + kk] : a.xout[ib + kk];
+                        rsum[k] = rsum[k] - a.Ax[k * bs + kk + diag_ptr] * xv;
+                    }
+                }
+                if (diag != 0.0) {
+                    if (BMODE == BM_BSR_JACOBI) {
+                        double t1 = (1.0 - a.omega) * a.xin[ib + k];
+                        double t2 = (a.omega * rsum[k]) / diag;
+                        a.xout[ib + k] = t1 + t2;
+                    } else {
+                        a.xout[ib + k] = rsum[k] / diag;
+                    }
+                }
+            }
+        }
+    } else {
+        for (int k = 0; k < bs; ++k) rsum[k] = 0.0;
+        for (int jj = a.Ap[i]; jj < a.Ap[i + 1]; ++jj) {
+            int j = a.Aj[jj];
+            if (i == j) continue;
+            const double *blk = a.Ax + (long)jj * B2;
+            const double *xj = a.xin + (long)j * bs;
+            for (int r = 0; r < bs; ++r) {
+                double s = 0.0;
+                for (int c = 0; c < bs; ++c) s = s + blk[r * bs + c] * xj[c];
+                v[r] = s;
+            }
+            for (int k = 0; k < bs; ++k) rsum[k] = rsum[k] + v[k];
+        }
+        for (int k = 0; k < bs; ++k) rsum[k] = a.b[ib + k] - rsum[k];
+        const double *D = a.Dinv + (long)i * B2;
+        for (int r = 0; r < bs; ++r) {
+            double s = 0.0;
+            for (int c = 0; c < bs; ++c) s = s + D[r * bs + c] * rsum[c];
+            v[r] = s;
+        }
+        if (BMODE == BM_BLOCK_JACOBI) {
+            for (int k = 0; k < bs; ++k) {
+                double t1 = (1.0 - a.omega) * a.xin[ib + k];
+                double t2 = a.omega * v[k];
+                a.xout[ib + k] = t1 + t2;
+            }
+        } else {
+            for (int k = 0; k < bs; ++k) a.xout[ib + k] = v[k];
+        }
+    }
+}
+
+int launch_block(BlockMode m, const BlockArgs &a, hipStream_t st)
+{
+    if (a.count <= 0) return 0;
+    if (a.bs > MAXBS || a.bs < 1) {
+        set_error("block kernels support blocksize 1..16");
+        return -5;
+    }
+    dim3 g((a.count + 127) / 128), b(128);
+    switch (m) {
+    case BM_BSR_JACOBI: hipLaunchKernelGGL(block_kernel<BM_BSR_JACOBI>, g, b, 0, st, a); break;
+    case BM_BLOCK_JACOBI: hipLaunchKernelGGL(block_kernel<BM_BLOCK_JACOBI>, g, b, 0, st, a); break;
+    case BM_BSR_GS: hipLaunchKernelGGL(block_kernel<BM_BSR_GS>, g, b, 0, st, a); break;
+    case BM_BLOCK_GS: hipLaunchKernelGGL(block_kernel<BM_BLOCK_GS>, g, b, 0, st, a); break;
+    }
+    LAUNCH_CHECK("block kernel");
+}
+
+}  // namespace amg

@@ -1,0 +1,462 @@
+"""Generic AMG solver -- the ``multilevel_solver`` object API of the reference
+(/root/reference/pyamg/multilevel.py) with the solve phase running on MI355X.
+
+The object keeps the reference's attributes (``levels[i].A/P/R``,
+``presmoother``/``postsmoother`` closures, ``coarse_solver``) as host-side
+scipy matrices -- that is how setup code builds and inspects a hierarchy --
+and mirrors them ONCE into HBM (operators, smoother constants, work vectors)
+the first time ``solve`` runs.  ``solve``/``aspreconditioner`` then execute
+multilevel.py:316-548 entirely on the device through libamgcore_hip.so.
+"""
+from warnings import warn
+
+import numpy as np
+import scipy.linalg
+import scipy.sparse as sparse
+
+from . import _lib
+
+__all__ = ["multilevel_solver", "coarse_grid_solver"]
+
+_SM_KIND = {None: 0, "None": 0, "jacobi": 1, "gauss_seidel": 2, "sor": 3, "polynomial": 4,
+            "block_jacobi": 5, "block_gauss_seidel": 6, "gauss_seidel_indexed": 7}
+_SWEEP = {"forward": 0, "backward": 1, "symmetric": 2}
+_CYCLE = {"V": 0, "W": 1, "F": 2, "AMLI": 3}
+_X0_ZERO, _NO_EARLY_STOP, _DEVICE_VECTORS = 1, 2, 4
+
+
+def _desc_struct(desc, keep):
+    """descriptor dict (smoothing.py closures' .desc) -> amg_smoother_desc"""
+    d = _lib.SmootherDesc()
+    name = None if desc is None else desc.get("name")
+    if name not in _SM_KIND:
+        raise NotImplementedError("smoother %r has no device implementation" % (name,))
+    d.kind = _SM_KIND[name]
+    if d.kind == 0:
+        return d
+    d.iterations = int(desc.get("iterations", 1))
+    sweep = desc.get("sweep", "forward")
+    if sweep not in _SWEEP:
+        raise ValueError("valid sweep directions are 'forward', 'backward', and 'symmetric'")
+    d.sweep = _SWEEP[sweep]
+    d.omega = float(desc.get("omega", 1.0))
+    if desc.get("coefficients") is not None:
+        co = np.ascontiguousarray(desc["coefficients"], dtype=np.float64)
+        keep.append(co)
+        d.ncoef, d.coef = len(co), _lib.dp(co)
+    d.blocksize = int(desc.get("blocksize", 1) or 1)
+    if desc.get("Dinv") is not None:
+        Dinv = np.ascontiguousarray(np.ravel(desc["Dinv"]), dtype=np.float64)
+        keep.append(Dinv)
+        d.Dinv = _lib.dp(Dinv)
+    if desc.get("indices") is not None:
+        idx = np.ascontiguousarray(desc["indices"], dtype=np.intc)
+        keep.append(idx)
+        d.indices, d.nindices = _lib.ip(idx), len(idx)
+    return d
+
+
+class _DeviceHierarchy(object):
+    """Owns an amg_hier handle (include/amgcore_hip.h section 2)."""
+
+    def __init__(self, ml, device=0):
+        L = _lib.lib()
+        self.L = L
+        levels = ml.levels
+        self.n = levels[0].A.shape[0]
+        self._shapes = {}
+        self.h = L.amg_hier_create(len(levels), int(device))
+        if not self.h:
+            msg = L.amg_last_error().decode()
+            raise _lib.AmgDeviceError(msg)
+        try:
+            self._build(ml)
+        except Exception:
+            L.amg_hier_destroy(self.h)
+            self.h = None
+            raise
+
+    def _set_matrix(self, lvl, which, M):
+        if M.dtype != np.float64:
+            raise NotImplementedError("device hierarchy supports float64 operators only")
+        if sparse.isspmatrix_bsr(M):
+            fmt, (R, C) = 1, M.blocksize
+            data = np.ascontiguousarray(np.ravel(M.data), dtype=np.float64)
+        elif sparse.isspmatrix_csr(M):
+            fmt, R, C = 0, 1, 1
+            data = np.ascontiguousarray(M.data, dtype=np.float64)
+        else:
+            M = sparse.csr_matrix(M)
+            fmt, R, C = 0, 1, 1
+            data = np.ascontiguousarray(M.data, dtype=np.float64)
+        Ap = np.ascontiguousarray(M.indptr, dtype=np.intc)
+        Aj = np.ascontiguousarray(M.indices, dtype=np.intc)
+        self._shapes[(lvl, which)] = M.shape
+        _lib.check(self.L.amg_hier_set_matrix(self.h, lvl, which, fmt, M.shape[0], M.shape[1], R, C,
+                                              Ap.ctypes.data, Aj.ctypes.data, data.ctypes.data, 0))
+
+    def _set_smoother(self, lvl, which, fn, A):
+        desc = getattr(fn, "desc", None)
+        if fn is not None and desc is None:
+            raise NotImplementedError(
+                "level %d: smoother %r carries no device descriptor; use pyamg_amd.smoothing."
+                "change_smoothers with one of the device smoothers" % (lvl, fn))
+        keep = []
+        d = _desc_struct(desc, keep)
+        if which == 2:
+            _lib.check(self.L.amg_hier_set_coarse_smoother(self.h, d))
+        else:
+            _lib.check(self.L.amg_hier_set_smoother(self.h, lvl, which, d))
+        if d.kind in (5, 6):
+            # the shim re-blocks A (relaxation.py:471,563): A.tobsr(blocksize=(bs, bs))
+            bs = d.blocksize
+            if not (sparse.isspmatrix_bsr(A) and A.blocksize == (bs, bs)):
+                Ab = A.tobsr(blocksize=(bs, bs))
+                Ap = np.ascontiguousarray(Ab.indptr, dtype=np.intc)
+                Aj = np.ascontiguousarray(Ab.indices, dtype=np.intc)
+                Ax = np.ascontiguousarray(np.ravel(Ab.data), dtype=np.float64)
+                _lib.check(self.L.amg_hier_set_block_matrix(self.h, lvl, which, Ab.shape[0] // bs, bs,
+                                                            _lib.ip(Ap), _lib.ip(Aj), _lib.dp(Ax)))
+
+    def _build(self, ml):
+        levels = ml.levels
+        for i, lvl in enumerate(levels):
+            self._set_matrix(i, 0, lvl.A)
+            if i < len(levels) - 1:
+                self._set_matrix(i, 1, lvl.P)
+                self._set_matrix(i, 2, lvl.R)
+                self._set_smoother(i, 0, getattr(lvl, "presmoother", None), lvl.A)
+                self._set_smoother(i, 1, getattr(lvl, "postsmoother", None), lvl.A)
+        cs = ml.coarse_solver
+        Ac = levels[-1].A
+        kind, payload = cs.device_form(Ac)
+        if kind == "dense":
+            M = np.ascontiguousarray(payload, dtype=np.float64)
+            _lib.check(self.L.amg_hier_set_coarse_dense(self.h, _lib.dp(M), M.shape[0]))
+        elif kind == "smoother":
+            self._set_smoother(len(levels) - 1, 2, payload, Ac)
+        elif kind != "none":
+            raise NotImplementedError("coarse solver %s has no device implementation" % cs.name())
+        _lib.check(self.L.amg_hier_finalize(self.h))
+
+    def solve(self, b, x, tol, maxiter, cycle, x0_zero=False, fixed=False):
+        res = np.zeros(maxiter + 2, dtype=np.float64)
+        nres = _lib.C.c_int(0)
+        flags = (_X0_ZERO if x0_zero else 0) | (_NO_EARLY_STOP if fixed else 0)
+        _lib.check(self.L.amg_hier_solve(self.h, b.ctypes.data, x.ctypes.data, float(tol), int(maxiter),
+                                         _CYCLE[cycle], _lib.dp(res), _lib.C.byref(nres), flags))
+        return res[:nres.value]
+
+    def cycle(self, b, x, cycle, x0_zero=False):
+        _lib.check(self.L.amg_hier_cycle(self.h, b.ctypes.data, x.ctypes.data, _CYCLE[cycle],
+                                         _X0_ZERO if x0_zero else 0))
+
+    def relax(self, lvl, which, b, x):
+        _lib.check(self.L.amg_hier_relax(self.h, lvl, which, _lib.dp(b), _lib.dp(x)))
+
+    def matvec(self, lvl, which, x):
+        rows, cols = self._shapes[(lvl, which)]
+        x = np.ascontiguousarray(np.ravel(x), dtype=np.float64)
+        if x.size != cols:
+            raise ValueError("dimension mismatch")
+        y = np.zeros(rows, dtype=np.float64)
+        _lib.check(self.L.amg_hier_matvec(self.h, lvl, which, _lib.dp(x), _lib.dp(y)))
+        return y
+
+    def cycle_bytes(self, cycle="V"):
+        return self.L.amg_hier_cycle_bytes(self.h, _CYCLE[cycle])
+
+    def last_solve_ms(self):
+        return self.L.amg_hier_last_solve_ms(self.h)
+
+    def device_bytes(self):
+        return self.L.amg_hier_device_bytes(self.h)
+
+    def time_spmv(self, lvl, which, mode=0, reps=10):
+        ms = _lib.C.c_double(0.0)
+        _lib.check(self.L.amg_hier_time_spmv(self.h, lvl, which, mode, reps, _lib.C.byref(ms)))
+        return ms.value
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.amg_hier_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class multilevel_solver:
+    """Stores multigrid hierarchy and implements the multigrid cycle
+    (multilevel.py:14-548).  Same attributes and methods as the reference."""
+
+    class level:
+        """One level: A, and (except on the coarsest) P, R, presmoother,
+        postsmoother (multilevel.py:45-68)."""
+
+        def __init__(self):
+            pass
+
+    def __init__(self, levels, coarse_solver="pinv2", device=0):
+        self.levels = levels
+        self.coarse_solver = coarse_grid_solver(coarse_solver)
+        self.device = device
+        self._dev = None
+        for level in levels[:-1]:
+            if not hasattr(level, "R"):
+                level.R = level.P.conj().T.asformat(level.P.format)   # level.P.H (multilevel.py:154-156)
+
+    # ------------------------------------------------------------------ reporting
+    def __repr__(self):
+        output = "multilevel_solver\n"
+        output += "Number of Levels:     %d\n" % len(self.levels)
+        output += "Operator Complexity: %6.3f\n" % self.operator_complexity()
+        output += "Grid Complexity:     %6.3f\n" % self.grid_complexity()
+        output += "Coarse Solver:        %s\n" % self.coarse_solver.name()
+        total_nnz = sum([level.A.nnz for level in self.levels])
+        output += "  level   unknowns     nonzeros\n"
+        for n, level in enumerate(self.levels):
+            A = level.A
+            output += "   %2d   %10d   %10d [%5.2f%%]\n" % (n, A.shape[1], A.nnz,
+                                                          (100 * float(A.nnz) / float(total_nnz)))
+        return output
+
+    def cycle_complexity(self, cycle="V"):
+        """multilevel.py:178-248"""
+        cycle = str(cycle).upper()
+        nnz = [level.A.nnz for level in self.levels]
+
+        def V(level):
+            if len(self.levels) == 1:
+                return nnz[0]
+            elif level == len(self.levels) - 2:
+                return 2 * nnz[level] + nnz[level + 1]
+            return 2 * nnz[level] + V(level + 1)
+
+        def W(level):
+            if len(self.levels) == 1:
+                return nnz[0]
+            elif level == len(self.levels) - 2:
+                return 2 * nnz[level] + nnz[level + 1]
+            return 2 * nnz[level] + 2 * W(level + 1)
+
+        def F(level):
+            if len(self.levels) == 1:
+                return nnz[0]
+            elif level == len(self.levels) - 2:
+                return 2 * nnz[level] + nnz[level + 1]
+            return 2 * nnz[level] + F(level + 1) + V(level + 1)
+
+        if cycle == "V":
+            flops = V(0)
+        elif (cycle == "W") or (cycle == "AMLI"):
+            flops = W(0)
+        elif cycle == "F":
+            flops = F(0)
+        else:
+            raise TypeError("Unrecognized cycle type (%s)" % cycle)
+        return float(flops) / float(nnz[0])
+
+    def operator_complexity(self):
+        return sum([level.A.nnz for level in self.levels]) / float(self.levels[0].A.nnz)
+
+    def grid_complexity(self):
+        return sum([level.A.shape[0] for level in self.levels]) / float(self.levels[0].A.shape[0])
+
+    # ------------------------------------------------------------------ device mirror
+    def _invalidate_device(self):
+        if self._dev is not None:
+            self._dev.close()
+        self._dev = None
+
+    def device_hierarchy(self):
+        """The HBM-resident mirror of this hierarchy (built on first use)."""
+        if self._dev is None:
+            self._dev = _DeviceHierarchy(self, self.device)
+        return self._dev
+
+    # ------------------------------------------------------------------ solve
+    def psolve(self, b):
+        return self.solve(b, maxiter=1)
+
+    def aspreconditioner(self, cycle="V"):
+        """multilevel.py:274-314"""
+        from scipy.sparse.linalg import LinearOperator
+        shape = self.levels[0].A.shape
+        dtype = self.levels[0].A.dtype
+
+        def matvec(b):
+            return self.solve(b, maxiter=1, cycle=cycle, tol=1e-12)
+        return LinearOperator(shape, matvec, dtype=dtype)
+
+    def solve(self, b, x0=None, tol=1e-5, maxiter=100, cycle="V", accel=None, callback=None,
+              residuals=None, return_residuals=False):
+        """Main solution call to execute multigrid cycling (multilevel.py:316-471)."""
+        b = np.asarray(b)
+        if x0 is None:
+            x = np.zeros_like(b)
+        else:
+            x = np.array(x0)   # copy
+        cycle = str(cycle).upper()
+        if cycle not in _CYCLE:
+            raise TypeError("Unrecognized cycle type (%s)" % cycle)
+        if (cycle == "AMLI") and hasattr(self.levels[0].A, "symmetry"):
+            if self.levels[0].A.symmetry != "hermitian":
+                raise ValueError("AMLI cycles require symmetry to be hermitian")
+
+        if accel is not None:
+            return self._solve_accel(b, x0, tol, maxiter, cycle, accel, callback, residuals)
+
+        if return_residuals:
+            warn("return_residuals is deprecated.  Use residuals instead")
+            residuals = []
+        if residuals is None:
+            residuals = []
+        else:
+            residuals[:] = []
+
+        tp = np.result_type(b.dtype, x.dtype, self.levels[0].A.dtype)
+        if tp != np.float64:
+            if np.issubdtype(tp, np.floating) or np.issubdtype(tp, np.integer):
+                tp = np.float64
+            else:
+                raise NotImplementedError("device solve supports real float64 systems only")
+        shape = b.shape
+        n = self.levels[0].A.shape[0]
+        if b.size != n or x.size != n:
+            raise ValueError("b and x0 must have %d entries" % n)
+        b1 = np.ascontiguousarray(np.ravel(b), dtype=np.float64)
+        x1 = np.ascontiguousarray(np.ravel(x), dtype=np.float64)
+        x0_zero = not np.any(x1)
+        dev = self.device_hierarchy()
+
+        if callback is None:
+            res = dev.solve(b1, x1, tol, maxiter, cycle, x0_zero=x0_zero)
+            residuals.extend(float(r) for r in res)
+        else:
+            # one cycle per call so that callback(x) sees every iterate (multilevel.py:454-466)
+            normb = float(np.sqrt(np.inner(b1, b1)))
+            atol = tol * normb if normb != 0 else tol
+            res = dev.solve(b1, x1, 0.0, 0, cycle, x0_zero=x0_zero)
+            residuals.append(float(res[0]))
+            while len(residuals) <= maxiter and residuals[-1] > atol:
+                res = dev.solve(b1, x1, 0.0, 1, cycle, x0_zero=x0_zero, fixed=True)
+                x0_zero = False
+                residuals.append(float(res[-1]))
+                callback(x1.reshape(shape))
+        xout = x1.reshape(shape)
+        if return_residuals:
+            return xout, residuals
+        return xout
+
+    def _solve_accel(self, b, x0, tol, maxiter, cycle, accel, callback, residuals):
+        """Krylov acceleration (multilevel.py:381-422): the cycle is the preconditioner M;
+        the outer Krylov iteration is scipy's (the reference falls back to the same
+        scipy.sparse.linalg interface, :404-422)."""
+        if (accel != "fgmres") and (cycle == "AMLI"):
+            raise ValueError("AMLI cycles require acceleration (accel) to be fgmres, or no acceleration")
+        import scipy.sparse.linalg as spla
+        if isinstance(accel, str):
+            if not hasattr(spla, accel):
+                raise ValueError("unknown accel method %r" % accel)
+            accel = getattr(spla, accel)
+        A = self.levels[0].A
+        M = self.aspreconditioner(cycle=cycle)
+        cb = callback
+        if residuals is not None:
+            residuals[:] = [float(np.linalg.norm(np.ravel(b) - A * np.ravel(np.zeros_like(b) if x0 is None else x0)))]
+
+            def callback(x):
+                if np.isscalar(x):
+                    residuals.append(float(x))
+                else:
+                    residuals.append(float(np.linalg.norm(np.ravel(b) - A * np.ravel(x))))
+                if cb is not None:
+                    cb(x)
+        try:
+            return accel(A, b, x0=x0, rtol=tol, maxiter=maxiter, M=M, callback=callback)[0]
+        except TypeError:
+            return accel(A, b, x0=x0, tol=tol, maxiter=maxiter, M=M, callback=callback)[0]
+
+
+def coarse_grid_solver(solver):
+    """Return a coarse grid solver suitable for multilevel_solver
+    (multilevel.py:554-720).
+
+    Dense methods ('pinv', 'pinv2', 'lu', 'cholesky', 'splu') are turned into
+    one dense operator at setup and applied on the device; relaxation names run
+    the corresponding device smoother from a zero guess (default 10
+    iterations); None gives a zero correction.  ('dense', {'M': array}) supplies
+    the operator directly.  Krylov names / arbitrary callables are host code
+    outside the device path and raise NotImplementedError when a solve needs them.
+    """
+    if isinstance(solver, _CoarseSolver):
+        return solver
+    return _CoarseSolver(solver)
+
+
+class _CoarseSolver(object):
+    _DENSE = ("pinv", "pinv2", "lu", "cholesky", "splu", "dense")
+    _RELAX = ("gauss_seidel", "jacobi", "block_gauss_seidel", "block_jacobi", "richardson", "sor",
+              "chebyshev")
+
+    def __init__(self, solver):
+        self.spec = solver
+        if isinstance(solver, tuple):
+            self.solver, self.kwargs = solver[0], dict(solver[1])
+        else:
+            self.solver, self.kwargs = solver, {}
+        ok = self.solver is None or callable(self.solver) or self.solver in self._DENSE + self._RELAX + (
+            "schwarz", "jacobi_ne", "gauss_seidel_ne", "gauss_seidel_nr", "bicg", "bicgstab", "cg", "cgs",
+            "gmres", "qmr", "minres")
+        if not ok:
+            raise ValueError("unknown solver: %s" % self.solver)
+
+    def device_form(self, A):
+        """-> ('dense', M) | ('smoother', closure) | ('none', None)"""
+        s = self.solver
+        if s is None:
+            return "none", None
+        if s in self._DENSE:
+            if not hasattr(self, "P"):
+                if s == "dense":
+                    self.P = np.asarray(self.kwargs["M"], dtype=np.float64)
+                elif A.nnz == 0:
+                    self.P = np.zeros(A.shape)
+                elif s in ("pinv", "pinv2"):
+                    self.P = scipy.linalg.pinv(A.toarray(), **self.kwargs)      # multilevel.py:608-612
+                else:
+                    # lu / cholesky / splu: exact inverse of the (nonsingular part of the) operator
+                    self.P = scipy.linalg.pinv(A.toarray())
+            return "dense", self.P
+        if s in self._RELAX:
+            from . import smoothing
+            kw = dict(self.kwargs)
+            if "iterations" not in kw:
+                kw["iterations"] = 10                                           # multilevel.py:665-666
+            lvl = multilevel_solver.level()
+            lvl.A = A
+            return "smoother", getattr(smoothing, "setup_" + str(s))(lvl, **kw)
+        raise NotImplementedError("coarse solver %r runs on the host and is outside the device path" % (s,))
+
+    def __call__(self, A, b):
+        """generic_solver.__call__ (multilevel.py:694-712): solve on the device."""
+        b = np.asanyarray(b)
+        if A.nnz == 0:
+            return np.zeros(b.shape)
+        lvl = multilevel_solver.level()
+        lvl.A = sparse.csr_matrix(A) if not (sparse.isspmatrix_csr(A) or sparse.isspmatrix_bsr(A)) else A
+        ml = multilevel_solver([lvl], coarse_solver=self)
+        x = np.zeros(A.shape[0])
+        ml.device_hierarchy().cycle(np.ascontiguousarray(np.ravel(b), dtype=np.float64), x, "V", x0_zero=True)
+        ml._invalidate_device()
+        return x.reshape(b.shape)
+
+    def __repr__(self):
+        return "coarse_grid_solver(" + repr(self.solver) + ")"
+
+    def name(self):
+        return repr(self.solver)

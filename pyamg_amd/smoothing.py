@@ -1,0 +1,223 @@
+"""Method to create pre- and post-smoothers on the levels of a multilevel_solver
+-- mirror of /root/reference/pyamg/relaxation/smoothing.py.
+
+``change_smoothers(ml, presmoother, postsmoother)`` accepts the reference's
+descriptors: ``'name'``, ``('name', {opts})``, ``None`` or a per-level list.
+Each ``setup_<name>(lvl, **opts)`` returns a closure ``smoother(A, x, b)`` like
+the reference's; the closure additionally carries ``.desc``, the constants
+(omega after rho scaling, Chebyshev coefficients, Dinv ...) that the
+device-resident cycle uploads once.
+"""
+import numpy as np
+import scipy.sparse as sparse
+
+from . import relaxation
+from .chebyshev import chebyshev_polynomial_coefficients
+from .util import approximate_spectral_radius, get_block_diag, get_diagonal, scale_rows
+
+__all__ = ["change_smoothers", "rho_D_inv_A", "rho_block_D_inv_A"]
+
+# names the device cycle implements; the rest of the reference's list
+# (schwarz, cg, gmres, cgne, cgnr, *_ne, *_nr) is outside the hot path
+DEVICE_SMOOTHERS = ("gauss_seidel", "jacobi", "block_jacobi", "block_gauss_seidel", "richardson",
+                    "sor", "chebyshev", "polynomial", "gauss_seidel_indexed", "None")
+
+
+def unpack_arg(v):
+    if isinstance(v, tuple):
+        return v[0], v[1]
+    return v, {}
+
+
+def _lookup(fn, which):
+    try:
+        return globals()["setup_" + str(fn)]
+    except KeyError:
+        raise NameError("invalid %s method: " % which, fn)
+
+
+def change_smoothers(ml, presmoother, postsmoother):
+    """smoothing.py:24-169"""
+    if isinstance(presmoother, str) or isinstance(presmoother, tuple) or (presmoother is None):
+        presmoother = [presmoother]
+    elif not isinstance(presmoother, list):
+        raise ValueError("Unrecognized presmoother")
+    if isinstance(postsmoother, str) or isinstance(postsmoother, tuple) or (postsmoother is None):
+        postsmoother = [postsmoother]
+    elif not isinstance(postsmoother, list):
+        raise ValueError("Unrecognized postsmoother")
+
+    for side, spec in (("presmoother", presmoother), ("postsmoother", postsmoother)):
+        i = 0
+        setup, kwargs = None, {}
+        for i in range(min(len(spec), len(ml.levels[:-1]))):
+            fn, kwargs = unpack_arg(spec[i])
+            setup = _lookup(fn, side)
+            setattr(ml.levels[i], side, setup(ml.levels[i], **kwargs))
+        for j in range(i + 1, len(ml.levels[:-1])):
+            setattr(ml.levels[j], side, setup(ml.levels[j], **kwargs))
+    if hasattr(ml, "_invalidate_device"):
+        ml._invalidate_device()
+
+
+def rho_D_inv_A(A):
+    """smoothing.py:172-200"""
+    if not hasattr(A, "rho_D_inv"):
+        D_inv = get_diagonal(A, inv=True)
+        D_inv_A = scale_rows(A, D_inv, copy=True)
+        A.rho_D_inv = approximate_spectral_radius(D_inv_A)
+    return A.rho_D_inv
+
+
+def rho_block_D_inv_A(A, Dinv):
+    """smoothing.py:203-250"""
+    if not hasattr(A, "rho_block_D_inv"):
+        from scipy.sparse.linalg import LinearOperator
+        blocksize = Dinv.shape[1]
+        if Dinv.shape[1] != Dinv.shape[2]:
+            raise ValueError("Dinv has incorrect dimensions")
+        elif Dinv.shape[0] != int(A.shape[0] / blocksize):
+            raise ValueError("Dinv and A have incompatible dimensions")
+        Dm = sparse.bsr_matrix((Dinv, np.arange(Dinv.shape[0]), np.arange(Dinv.shape[0] + 1)), shape=A.shape)
+
+        def matvec(x):
+            return Dm * (A * x)
+        D_inv_A = LinearOperator(A.shape, matvec, dtype=A.dtype)
+        A.rho_block_D_inv = approximate_spectral_radius(D_inv_A)
+    return A.rho_block_D_inv
+
+
+def _with_desc(fn, **desc):
+    fn.desc = desc
+    return fn
+
+
+def setup_gauss_seidel(lvl, iterations=1, sweep="forward"):
+    def smoother(A, x, b):
+        relaxation.gauss_seidel(A, x, b, iterations=iterations, sweep=sweep)
+    return _with_desc(smoother, name="gauss_seidel", iterations=iterations, sweep=sweep)
+
+
+def setup_jacobi(lvl, iterations=1, omega=1.0, withrho=True):
+    if withrho:
+        omega = omega / rho_D_inv_A(lvl.A)
+
+    def smoother(A, x, b):
+        relaxation.jacobi(A, x, b, iterations=iterations, omega=omega)
+    return _with_desc(smoother, name="jacobi", iterations=iterations, omega=float(omega))
+
+
+def _blocksize_of(lvl, blocksize, Dinv):
+    if blocksize is None and Dinv is None:
+        if sparse.isspmatrix_csr(lvl.A):
+            blocksize = 1
+        elif sparse.isspmatrix_bsr(lvl.A):
+            blocksize = lvl.A.blocksize[0]
+    elif blocksize is None:
+        blocksize = Dinv.shape[1]
+    return blocksize
+
+
+def setup_block_jacobi(lvl, iterations=1, omega=1.0, Dinv=None, blocksize=None, withrho=True):
+    blocksize = _blocksize_of(lvl, blocksize, Dinv)
+    if blocksize == 1:
+        return setup_jacobi(lvl, iterations=iterations, omega=omega, withrho=withrho)
+    if Dinv is None:
+        Dinv = get_block_diag(lvl.A, blocksize=blocksize, inv_flag=True)
+    if withrho:
+        omega = omega / rho_block_D_inv_A(lvl.A, Dinv)
+
+    def smoother(A, x, b):
+        relaxation.block_jacobi(A, x, b, iterations=iterations, omega=omega, Dinv=Dinv, blocksize=blocksize)
+    return _with_desc(smoother, name="block_jacobi", iterations=iterations, omega=float(omega),
+                      Dinv=Dinv, blocksize=blocksize)
+
+
+def setup_block_gauss_seidel(lvl, iterations=1, sweep="forward", Dinv=None, blocksize=None):
+    blocksize = _blocksize_of(lvl, blocksize, Dinv)
+    if blocksize == 1:
+        return setup_gauss_seidel(lvl, iterations=iterations, sweep=sweep)
+    if Dinv is None:
+        Dinv = get_block_diag(lvl.A, blocksize=blocksize, inv_flag=True)
+
+    def smoother(A, x, b):
+        relaxation.block_gauss_seidel(A, x, b, iterations=iterations, Dinv=Dinv, blocksize=blocksize,
+                                      sweep=sweep)
+    return _with_desc(smoother, name="block_gauss_seidel", iterations=iterations, sweep=sweep,
+                      Dinv=Dinv, blocksize=blocksize)
+
+
+def setup_richardson(lvl, iterations=1, omega=1.0):
+    omega = omega / approximate_spectral_radius(lvl.A)
+
+    def smoother(A, x, b):
+        relaxation.polynomial(A, x, b, coefficients=[omega], iterations=iterations)
+    return _with_desc(smoother, name="polynomial", iterations=iterations, coefficients=[float(omega)])
+
+
+def setup_sor(lvl, omega=0.5, iterations=1, sweep="forward"):
+    def smoother(A, x, b):
+        relaxation.sor(A, x, b, omega=omega, iterations=iterations, sweep=sweep)
+    return _with_desc(smoother, name="sor", iterations=iterations, sweep=sweep, omega=float(omega))
+
+
+def setup_chebyshev(lvl, lower_bound=1.0 / 30.0, upper_bound=1.1, degree=3, iterations=1):
+    rho = approximate_spectral_radius(lvl.A)
+    a = rho * lower_bound
+    b = rho * upper_bound
+    coefficients = -chebyshev_polynomial_coefficients(a, b, degree)[:-1]
+    return setup_polynomial(lvl, coefficients=coefficients, iterations=iterations)
+
+
+def setup_polynomial(lvl, coefficients=None, iterations=1):
+    """Extension: polynomial smoother with explicit Horner coefficients (what
+    setup_chebyshev / setup_richardson reduce to, smoothing.py:422-449)."""
+    coefficients = np.array(coefficients, dtype=float)
+
+    def smoother(A, x, b):
+        relaxation.polynomial(A, x, b, coefficients=coefficients, iterations=iterations)
+    return _with_desc(smoother, name="polynomial", iterations=iterations,
+                      coefficients=[float(c) for c in coefficients])
+
+
+def setup_gauss_seidel_indexed(lvl, indices=None, iterations=1, sweep="forward"):
+    """Extension: relaxation.gauss_seidel_indexed (relaxation.py:671-741) as a level smoother
+    (e.g. multicolour or F/C-ordered Gauss-Seidel)."""
+    indices = np.asarray(indices, dtype=np.intc)
+
+    def smoother(A, x, b):
+        relaxation.gauss_seidel_indexed(A, x, b, indices, iterations=iterations, sweep=sweep)
+    return _with_desc(smoother, name="gauss_seidel_indexed", iterations=iterations, sweep=sweep,
+                      indices=indices)
+
+
+def setup_jacobi_ne(lvl, iterations=1, omega=1.0, withrho=True):
+    Acsr = lvl.A.tocsr()
+    if withrho:
+        omega = omega / rho_D_inv_A(Acsr) ** 2
+
+    def smoother(A, x, b):
+        relaxation.jacobi_ne(Acsr, x, b, iterations=iterations, omega=omega)
+    return smoother
+
+
+def setup_gauss_seidel_ne(lvl, iterations=1, sweep="forward", omega=1.0):
+    Acsr = lvl.A.tocsr()
+
+    def smoother(A, x, b):
+        relaxation.gauss_seidel_ne(Acsr, x, b, iterations=iterations, sweep=sweep, omega=omega)
+    return smoother
+
+
+def setup_gauss_seidel_nr(lvl, iterations=1, sweep="forward", omega=1.0):
+    Acsc = lvl.A.tocsc()
+
+    def smoother(A, x, b):
+        relaxation.gauss_seidel_nr(Acsc, x, b, iterations=iterations, sweep=sweep, omega=omega)
+    return smoother
+
+
+def setup_None(lvl):
+    def smoother(A, x, b):
+        pass
+    return _with_desc(smoother, name=None)

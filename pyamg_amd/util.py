@@ -1,0 +1,178 @@
+"""Host-side helpers the relaxation shims and smoother setup need
+(restated from /root/reference/pyamg/util/utils.py and util/linalg.py).
+
+These produce per-level CONSTANTS (omega scaling, Chebyshev bounds, inverse
+diagonal blocks) once at setup; nothing here runs inside the cycle.
+"""
+import numpy as np
+import scipy.linalg
+from scipy.sparse import bsr_matrix, csr_matrix, isspmatrix, isspmatrix_bsr, isspmatrix_csc, isspmatrix_csr
+
+__all__ = ["type_prep", "to_type", "get_diagonal", "get_block_diag", "scale_rows", "norm",
+           "approximate_spectral_radius", "upcast"]
+
+
+def upcast(*args):
+    return np.result_type(*args)
+
+
+def to_type(upcast_type, varlist):
+    """util/utils.py:475-523"""
+    out = list(varlist)
+    for i, v in enumerate(out):
+        if np.isscalar(v):
+            out[i] = np.array([v], upcast_type)[0]
+        else:
+            try:
+                if v.dtype != upcast_type:
+                    out[i] = v.astype(upcast_type)
+            except AttributeError:
+                out[i] = np.asarray(v).astype(upcast_type)
+    return out
+
+
+def type_prep(upcast_type, varlist):
+    """util/utils.py:431-472: scalars become length-1 arrays."""
+    out = to_type(upcast_type, varlist)
+    for i, v in enumerate(out):
+        if np.isscalar(v):
+            out[i] = np.array([v])
+    return out
+
+
+def norm(x, pnorm="2"):
+    """util/linalg.py:17-58 (host vectors; device vectors use amgcore_norm2)."""
+    x = np.ravel(x)
+    if pnorm == "2":
+        return np.sqrt(np.inner(x.conj(), x).real)
+    if pnorm == "inf":
+        return np.max(np.abs(x))
+    raise ValueError("Only the 2-norm and infinity-norm are supported")
+
+
+def get_diagonal(A, norm_eq=False, inv=False):
+    """util/utils.py:526-588"""
+    if not (isspmatrix_csr(A) or isspmatrix_csc(A) or isspmatrix_bsr(A)):
+        A = csr_matrix(A)
+    A.sort_indices()
+    if norm_eq == 1:
+        At = A.T
+        D = (At.multiply(At.conjugate())) * np.ones((At.shape[0],))
+    elif norm_eq == 2:
+        D = (A.multiply(A.conjugate())) * np.ones((A.shape[0],))
+    else:
+        D = A.diagonal()
+    D = np.asarray(D).ravel()
+    if inv:
+        Dinv = np.zeros_like(D)
+        mask = (D != 0.0)
+        Dinv[mask] = 1.0 / D[mask]
+        return Dinv
+    return D
+
+
+def get_block_diag(A, blocksize, inv_flag=True):
+    """util/utils.py:591-683.  The reference inverts the blocks with its own
+    SVD routine (amg_core.pinv_array); LAPACK's pinv is used here -- the result
+    is a setup constant handed to the smoother as Dinv."""
+    if not isspmatrix(A):
+        raise TypeError("Expected sparse matrix")
+    if A.shape[0] != A.shape[1]:
+        raise ValueError("Expected square matrix")
+    if A.shape[0] % blocksize != 0:
+        raise ValueError("blocksize and A.shape must be compatible")
+    if not isspmatrix_bsr(A):
+        A = bsr_matrix(A, blocksize=(blocksize, blocksize))
+    if A.blocksize != (blocksize, blocksize):
+        A = A.tobsr(blocksize=(blocksize, blocksize))
+    A = A.asfptype() if hasattr(A, "asfptype") else A.astype(np.float64)
+    nb = A.shape[0] // blocksize
+    block_diag = np.zeros((nb, blocksize, blocksize), dtype=A.dtype)
+    for i in range(nb):
+        for jj in range(A.indptr[i], A.indptr[i + 1]):
+            if A.indices[jj] == i:
+                block_diag[i] = A.data[jj]
+    if inv_flag:
+        for i in range(nb):
+            block_diag[i] = scipy.linalg.pinv(block_diag[i])
+    return block_diag
+
+
+def scale_rows(A, v, copy=True):
+    """util/utils.py:133-200 (CSR/BSR(1,1))"""
+    v = np.ravel(v)
+    if isspmatrix_bsr(A) and A.blocksize != (1, 1):
+        A = A.tocsr()
+    A = csr_matrix(A, copy=copy)
+    A.data = A.data * np.repeat(v, np.diff(A.indptr))
+    return A
+
+
+def _approximate_eigenvalues(A, tol, maxiter, symmetric=None, initial_guess=None):
+    """util/linalg.py:173-279 (non-symmetric Arnoldi branch, the only one the
+    spectral-radius estimate uses, :353-355)."""
+    from scipy.sparse.linalg import aslinearoperator
+    A = aslinearoperator(A)
+    eps = np.finfo(float).eps
+    breakdown = eps * 1e6
+    breakdown_flag = False
+    if A.shape[0] != A.shape[1]:
+        raise ValueError("expected square matrix")
+    maxiter = min(A.shape[0], maxiter)
+    if initial_guess is None:
+        v0 = np.random.rand(A.shape[1], 1)
+    else:
+        v0 = initial_guess
+    v0 = v0 / norm(v0)
+    H = np.zeros((maxiter + 1, maxiter), dtype=np.result_type(v0.dtype, A.dtype))
+    V = [v0]
+    j = 0
+    for j in range(maxiter):
+        w = A * V[-1]
+        for i, v in enumerate(V):
+            H[i, j] = np.dot(np.conjugate(v.ravel()), w.ravel())
+            w = w - H[i, j] * v
+        H[j + 1, j] = norm(w)
+        if H[j + 1, j] < breakdown:
+            breakdown_flag = True
+            if H[j + 1, j] != 0.0:
+                w = w / H[j + 1, j]
+            V.append(w)
+            break
+        w = w / H[j + 1, j]
+        V.append(w)
+    Eigs, Vects = scipy.linalg.eig(H[:j + 1, :j + 1], left=False, right=True)
+    return (Vects, Eigs, H, V, breakdown_flag)
+
+
+def approximate_spectral_radius(A, tol=0.01, maxiter=15, restart=5, symmetric=None,
+                                initial_guess=None, return_vector=False):
+    """util/linalg.py:282-416.  Consumes the global numpy RNG exactly like the
+    reference (one rand(n,1) per call), so seeded runs give the same rho."""
+    if not hasattr(A, "rho") or return_vector:
+        if maxiter < 1:
+            raise ValueError("expected maxiter > 0")
+        if restart < 0:
+            raise ValueError("expected restart >= 0")
+        if A.shape[0] != A.shape[1]:
+            raise ValueError("expected square A")
+        if initial_guess is None:
+            v0 = np.random.rand(A.shape[1], 1)
+        else:
+            v0 = np.array(initial_guess.reshape(-1, 1), dtype=A.dtype)
+        for j in range(restart + 1):
+            evect, ev, H, V, breakdown_flag = _approximate_eigenvalues(A, tol, maxiter, False,
+                                                                        initial_guess=v0)
+            nvecs = ev.shape[0]
+            max_index = np.abs(ev).argmax()
+            error = H[nvecs, nvecs - 1] * evect[-1, max_index]
+            v0 = np.dot(np.hstack(V[:-1]), evect[:, max_index].reshape(-1, 1))
+            if (np.abs(error) / np.abs(ev[max_index]) < tol) or breakdown_flag:
+                break
+        rho = np.abs(ev[max_index])
+        if isspmatrix(A):
+            A.rho = rho
+        if return_vector:
+            return (rho, v0)
+        return rho
+    return A.rho

@@ -85,3 +85,45 @@ def history_tolerance(A, x, b, ref):
     Ainf = abs(sps.csr_matrix(A)).sum(axis=1).max()
     floor = 100 * eps * (np.linalg.norm(b) + Ainf * np.linalg.norm(x))
     return 1e-12 * np.asarray(ref) + floor
+
+
+def smoother_spec(d):
+    """canonical recorded descriptor -> the ('name', {opts}) tuple change_smoothers takes,
+    with the reference's constants passed explicitly (never re-estimated)."""
+    name = d.get("name")
+    if name is None:
+        return None
+    it = int(d.get("iterations", 1))
+    if name == "jacobi":
+        return ("jacobi", {"iterations": it, "omega": d["omega"], "withrho": False})
+    if name == "gauss_seidel":
+        return ("gauss_seidel", {"iterations": it, "sweep": d.get("sweep", "forward")})
+    if name == "sor":
+        return ("sor", {"iterations": it, "omega": d["omega"], "sweep": d.get("sweep", "forward")})
+    if name == "polynomial":
+        return ("polynomial", {"iterations": it, "coefficients": d["coefficients"]})
+    bs = int(d.get("blocksize", 1))
+    if name == "block_jacobi":
+        return ("block_jacobi", {"iterations": it, "omega": d["omega"], "withrho": False, "blocksize": bs,
+                                 "Dinv": np.asarray(d["Dinv"]).reshape(-1, bs, bs)})
+    if name == "block_gauss_seidel":
+        return ("block_gauss_seidel", {"iterations": it, "sweep": d.get("sweep", "forward"), "blocksize": bs,
+                                       "Dinv": np.asarray(d["Dinv"]).reshape(-1, bs, bs)})
+    raise KeyError(name)
+
+
+def build_ml(g):
+    """pyamg_amd.multilevel_solver from a golden hierarchy (reference operators + constants)."""
+    import pyamg_amd
+    levels = []
+    for L in g["levels"]:
+        lvl = pyamg_amd.multilevel_solver.level()
+        lvl.A = L["A"]
+        if "P" in L:
+            lvl.P, lvl.R = L["P"], L["R"]
+        levels.append(lvl)
+    ml = pyamg_amd.multilevel_solver(levels, coarse_solver=("dense", {"M": g["coarse_pinv"]}))
+    pre = [smoother_spec(L["pre"]) for L in g["levels"][:-1]]
+    post = [smoother_spec(L["post"]) for L in g["levels"][:-1]]
+    pyamg_amd.change_smoothers(ml, pre, post)
+    return ml

@@ -1,0 +1,264 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through
+the C ABI, against (a) the golden fixtures captured from the reference and
+(b) the CPU oracle on the same inputs.
+
+Bars: amg_core kernels and SpMV BIT-EXACT vs the reference's own outputs;
+whole-solve iterates BIT-EXACT vs the oracle (same summation order by
+construction); residual histories vs the reference within 1e-12 relative
+(+ fp64 evaluation floor, golden_io.history_tolerance).
+"""
+import numpy as np
+import pytest
+import scipy.sparse as sps
+
+import golden_io
+import oracle_lib
+import pyamg_amd
+from pyamg_amd import amg_core, relaxation
+
+pytestmark = pytest.mark.gpu
+
+KERNELS = golden_io.load_kernels()
+
+
+def _c(a, dt=np.float64):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+def run_gpu_kernel(name, c):
+    Ap, Aj, Ax = _c(c["Ap"], np.intc), _c(c["Aj"], np.intc), _c(c["Ax"])
+    if name.startswith("csr_matvec"):
+        y = np.zeros(int(c["shape"][0]))
+        amg_core.csr_matvec(int(c["shape"][0]), int(c["shape"][1]), Ap, Aj, Ax, _c(c["x"]), y)
+        return {"y": y}
+    if name.startswith("bsr_matvec"):
+        R, C = (int(v) for v in c["blocksize"])
+        y = np.zeros(int(c["shape"][0]))
+        amg_core.bsr_matvec(int(c["shape"][0]) // R, int(c["shape"][1]) // C, R, C, Ap, Aj, Ax, _c(c["x"]), y)
+        return {"y": y}
+    x = c["x0"].copy()
+    rs, re, rt = (int(v) for v in c["sweep"])
+    n = len(x)
+    if name.startswith("gauss_seidel_indexed"):
+        amg_core.gauss_seidel_indexed(Ap, Aj, Ax, x, _c(c["b"]), _c(c["Id"], np.intc), rs, re, rt)
+    elif name.startswith("gauss_seidel_ne"):
+        amg_core.gauss_seidel_ne(Ap, Aj, Ax, x, _c(c["b"]), rs, re, rt, _c(c["Tx"]), float(c["omega"][0]))
+    elif name.startswith("gauss_seidel_nr"):
+        z = c["z0"].copy()
+        amg_core.gauss_seidel_nr(Ap, Aj, Ax, x, z, rs, re, rt, _c(c["Tx"]), float(c["omega"][0]))
+        return {"x": x, "z": z}
+    elif name.startswith("gauss_seidel"):
+        amg_core.gauss_seidel(Ap, Aj, Ax, x, _c(c["b"]), rs, re, rt)
+    elif name.startswith("jacobi_ne"):
+        amg_core.jacobi_ne(Ap, Aj, Ax, x, _c(c["b"]), _c(c["Tx"]), np.zeros(n), rs, re, rt, _c(c["omega"]))
+    elif name.startswith("jacobi"):
+        amg_core.jacobi(Ap, Aj, Ax, x, _c(c["b"]), np.zeros(n), rs, re, rt, _c(c["omega"]))
+    elif name.startswith("bsr_gauss_seidel"):
+        amg_core.bsr_gauss_seidel(Ap, Aj, Ax, x, _c(c["b"]), rs, re, rt, int(c["blocksize"][0]))
+    elif name.startswith("bsr_jacobi"):
+        amg_core.bsr_jacobi(Ap, Aj, Ax, x, _c(c["b"]), np.zeros(n), rs, re, rt, int(c["blocksize"][0]),
+                            _c(c["omega"]))
+    elif name.startswith("block_jacobi"):
+        amg_core.block_jacobi(Ap, Aj, Ax, x, _c(c["b"]), _c(c["Dinv"]), np.zeros(n), rs, re, rt,
+                              _c(c["omega"]), int(c["blocksize"][0]))
+    elif name.startswith("block_gauss_seidel"):
+        amg_core.block_gauss_seidel(Ap, Aj, Ax, x, _c(c["b"]), _c(c["Dinv"]), rs, re, rt, int(c["blocksize"][0]))
+    else:
+        raise KeyError(name)
+    return {"x": x}
+
+
+@pytest.mark.parametrize("name", sorted(KERNELS))
+def test_amg_core_kernel_bit_exact_vs_reference(name):
+    c = KERNELS[name]
+    out = run_gpu_kernel(name, c)
+    for k, v in out.items():
+        assert np.array_equal(v, c[k]), "%s: %s differs from the reference, max |d| = %g" % (
+            name, k, np.abs(v - c[k]).max())
+
+
+DEVICE_CASES = [c for c in golden_io.hier_cases() if c != "sa_amli_2d"]
+
+
+@pytest.mark.parametrize("case", DEVICE_CASES)
+def test_solve_history_vs_reference_and_oracle(case):
+    g = golden_io.load_hier(case)
+    m = g["meta"]
+    ml = golden_io.build_ml(g)
+    res = []
+    x0 = g["x0"] if np.any(g["x0"]) else None
+    x = ml.solve(g["b"], x0=x0, tol=m["tol"], maxiter=m["maxiter"], cycle=m["cycle"], residuals=res)
+    res = np.array(res)
+    ref = g["residuals"]
+    assert len(res) == len(ref)
+    tol = golden_io.history_tolerance(g["levels"][0]["A"], g["x"], g["b"], ref)
+    assert np.all(np.abs(res - ref) <= tol), np.max(np.abs(res - ref) / tol)
+    assert np.linalg.norm(x - g["x"]) <= 1e-12 * np.linalg.norm(g["x"])
+    # against the oracle: identical arithmetic order -> identical iterates
+    H = oracle_lib.Hierarchy(g["levels"], g["coarse_pinv"])
+    xo, reso = H.solve(g["b"], x0=g["x0"], tol=m["tol"], maxiter=m["maxiter"], cycle=m["cycle"])
+    assert len(reso) == len(res)
+    assert np.array_equal(x, xo), "iterates differ from the oracle: max |d| = %g" % np.abs(x - xo).max()
+    assert np.allclose(res, reso, rtol=1e-12, atol=tol.min())
+
+
+def test_amli_is_refused_not_faked():
+    g = golden_io.load_hier("sa_amli_2d")
+    ml = golden_io.build_ml(g)
+    with pytest.raises(NotImplementedError):
+        ml.solve(g["b"], cycle="AMLI", maxiter=2)
+
+
+def test_callback_and_residual_semantics():
+    # multilevel.py:454-466: callback(x) after every cycle; residuals list cleared in place
+    g = golden_io.load_hier("sa_jacobi_2d")
+    ml = golden_io.build_ml(g)
+    res = [123.0]
+    seen = []
+    x = ml.solve(g["b"], tol=1e-10, residuals=res, callback=lambda xk: seen.append(xk.copy()))
+    assert len(seen) == len(res) - 1
+    assert np.array_equal(seen[0], g["x_iter1"]) or np.linalg.norm(seen[0] - g["x_iter1"]) <= 1e-13 * np.linalg.norm(seen[0])
+    assert np.array_equal(seen[-1], x)
+    res2 = []
+    x2 = ml.solve(g["b"], tol=1e-10, residuals=res2)
+    assert np.array_equal(x, x2) and np.allclose(res, res2, rtol=1e-13)
+    # maxiter stops the loop: len(residuals) == maxiter + 1
+    res3 = []
+    ml.solve(g["b"], tol=1e-30, maxiter=3, residuals=res3)
+    assert len(res3) == 4
+
+
+def test_aspreconditioner_is_one_cycle_from_zero():
+    g = golden_io.load_hier("sa_cheb2_3d")
+    ml = golden_io.build_ml(g)
+    M = ml.aspreconditioner(cycle="V")
+    y = M.matvec(g["b"])
+    assert np.linalg.norm(y - g["x_iter1"]) <= 1e-13 * np.linalg.norm(g["x_iter1"])
+    # CG accelerated solve converges and beats the stand-alone cycle count
+    res = []
+    x = ml.solve(g["b"], tol=1e-8, accel="cg", residuals=res)
+    A = g["levels"][0]["A"]
+    assert np.linalg.norm(g["b"] - A * x) <= 1e-7 * np.linalg.norm(g["b"])
+    assert len(res) < len(g["residuals"])
+
+
+def poisson(grid):
+    A = None
+    for n in grid:
+        T = sps.diags([-np.ones(n - 1), 2 * np.ones(n), -np.ones(n - 1)], [-1, 0, 1], format="csr")
+        A = T if A is None else sps.kron(A, sps.identity(n), format="csr") + sps.kron(sps.identity(A.shape[0]), T, format="csr")
+    A = sps.csr_matrix(A); A.sort_indices()
+    return A
+
+
+def test_relaxation_shims_match_oracle_at_scale(oracle):
+    """Larger systems than the fixtures: every shim of relaxation.py vs the oracle, bit-exact."""
+    import ctypes as C
+    A = poisson((40, 40, 40))          # 64000 rows, 7-pt
+    n = A.shape[0]
+    rng = np.random.RandomState(3)
+    b = rng.rand(n)
+
+    def oracle_relax(desc, x):
+        keep = []
+        m = oracle_lib.make_mat(A, keep)
+        s = oracle_lib.make_smoother(desc, A, keep)
+        oracle.oracle_relax(C.byref(m), C.byref(s), oracle_lib.dp(x), oracle_lib.dp(b))
+
+    x = rng.rand(n); xo = x.copy()
+    relaxation.gauss_seidel(A, x, b, iterations=2, sweep="symmetric")
+    oracle_relax({"name": "gauss_seidel", "iterations": 2, "sweep": "symmetric"}, xo)
+    assert np.array_equal(x, xo)
+
+    x = rng.rand(n); xo = x.copy()
+    relaxation.jacobi(A, x, b, iterations=3, omega=0.7)
+    oracle_relax({"name": "jacobi", "iterations": 3, "omega": 0.7}, xo)
+    assert np.array_equal(x, xo)
+
+    x = rng.rand(n); xo = x.copy()
+    relaxation.sor(A, x, b, omega=1.3, iterations=2, sweep="backward")
+    oracle_relax({"name": "sor", "iterations": 2, "omega": 1.3, "sweep": "backward"}, xo)
+    assert np.array_equal(x, xo)
+
+    x = rng.rand(n); xo = x.copy()
+    co = [0.05, -0.3, 0.4]
+    relaxation.polynomial(A, x, b, co, iterations=2)
+    oracle_relax({"name": "polynomial", "iterations": 2, "coefficients": co}, xo)
+    assert np.array_equal(x, xo)
+
+    idx = rng.permutation(n)[: n // 3].astype(np.intc)
+    x = rng.rand(n); xo = x.copy()
+    relaxation.gauss_seidel_indexed(A, x, b, idx, iterations=1, sweep="symmetric")
+    oracle_relax({"name": "gauss_seidel_indexed", "iterations": 1, "sweep": "symmetric", "indices": idx}, xo)
+    assert np.array_equal(x, xo)
+
+    # BSR(3,3) view of the same matrix: point-BSR and block smoothers
+    n3 = (n // 3) * 3
+    A3 = sps.csr_matrix(A[:n3, :n3]).tobsr((3, 3))
+    b3 = b[:n3].copy()
+    from pyamg_amd.util import get_block_diag
+    Dinv = get_block_diag(A3, 3, inv_flag=True)
+
+    def oracle_relax3(desc, x):
+        keep = []
+        m = oracle_lib.make_mat(A3, keep)
+        s = oracle_lib.make_smoother(desc, A3, keep)
+        oracle.oracle_relax(C.byref(m), C.byref(s), oracle_lib.dp(x), oracle_lib.dp(b3))
+
+    for desc, call in (
+        ({"name": "gauss_seidel", "sweep": "symmetric"}, lambda x: relaxation.gauss_seidel(A3, x, b3, sweep="symmetric")),
+        ({"name": "jacobi", "omega": 0.6}, lambda x: relaxation.jacobi(A3, x, b3, omega=0.6)),
+        ({"name": "block_gauss_seidel", "sweep": "symmetric", "blocksize": 3, "Dinv": Dinv},
+         lambda x: relaxation.block_gauss_seidel(A3, x, b3, sweep="symmetric", blocksize=3, Dinv=Dinv)),
+        ({"name": "block_jacobi", "omega": 0.8, "blocksize": 3, "Dinv": Dinv},
+         lambda x: relaxation.block_jacobi(A3, x, b3, omega=0.8, blocksize=3, Dinv=Dinv)),
+    ):
+        x = rng.rand(n3); xo = x.copy()
+        call(x)
+        oracle_relax3(desc, xo)
+        assert np.array_equal(x, xo), desc["name"]
+
+
+def test_edge_cases():
+    # empty matrix / empty rows / single row / rows longer than the LDS tile
+    A = sps.csr_matrix((5, 5)); x = np.ones(5); b = np.ones(5)
+    relaxation.gauss_seidel(A, x, b)          # all diagonals zero: untouched (relaxation.h:58-60)
+    assert np.array_equal(x, np.ones(5))
+    relaxation.jacobi(A, x, b)
+    assert np.array_equal(x, np.ones(5))
+    y = np.zeros(5)
+    amg_core.csr_matvec(5, 5, A.indptr.astype(np.intc), A.indices.astype(np.intc), A.data, x, y)
+    assert np.array_equal(y, np.zeros(5))
+    # one dense row of 5000 entries (> LDS tile) among sparse rows
+    n = 6000
+    rng = np.random.RandomState(5)
+    M = sps.lil_matrix((n, n))
+    M[17, :5000] = rng.randn(5000)
+    M.setdiag(rng.rand(n) + 10.0)
+    M = sps.csr_matrix(M); M.sort_indices()
+    xv = rng.randn(n)
+    y = np.zeros(n)
+    amg_core.csr_matvec(n, n, M.indptr.astype(np.intc), M.indices.astype(np.intc), M.data, xv, y)
+    assert np.array_equal(y, M * xv)          # scipy's sequential row sums, bit for bit
+    x = rng.randn(n); xo = x.copy(); bb = rng.randn(n)
+    relaxation.gauss_seidel(M, x, bb, sweep="symmetric")
+    lib = oracle_lib.load()
+    Ap, Aj = M.indptr.astype(np.intc), M.indices.astype(np.intc)
+    lib.oracle_gauss_seidel(oracle_lib.ip(Ap), oracle_lib.ip(Aj), oracle_lib.dp(M.data), oracle_lib.dp(xo), oracle_lib.dp(bb), 0, n, 1)
+    lib.oracle_gauss_seidel(oracle_lib.ip(Ap), oracle_lib.ip(Aj), oracle_lib.dp(M.data), oracle_lib.dp(xo), oracle_lib.dp(bb), n - 1, -1, -1)
+    assert np.array_equal(x, xo)
+    # 1x1 system
+    A1 = sps.csr_matrix(np.array([[4.0]])); x = np.array([0.0]); b = np.array([2.0])
+    relaxation.gauss_seidel(A1, x, b)
+    assert x[0] == 0.5
+
+
+def test_norm_matches_numpy():
+    rng = np.random.RandomState(0)
+    import ctypes as C
+    from pyamg_amd import _lib
+    for n in (1, 7, 1000, 1 << 20):
+        v = rng.randn(n)
+        out = C.c_double()
+        _lib.check(_lib.lib().amgcore_norm2_f64(_lib.dp(v), n, C.byref(out)))
+        assert abs(out.value - np.linalg.norm(v)) <= 4e-16 * np.linalg.norm(v) * max(1, np.log2(n))
