@@ -1,0 +1,427 @@
+"""Smoothed-aggregation setup on the CPU -- the part of
+/root/reference/pyamg/aggregation/aggregation.py the BASELINE configurations
+use, restated so that a hierarchy can be built where the reference cannot
+travel (the GPU box).  The hierarchy is built ONCE on the host and shipped to
+HBM by ``multilevel_solver``; nothing here runs inside the cycle.
+
+Supported subset (anything else raises NotImplementedError):
+  strength   'symmetric' (any theta) | None | ('predefined', {'C': csr})
+  aggregate  'standard' | ('predefined', {'AggOp': csr})
+  smooth     ('jacobi', {'omega', 'degree'}) | None
+  symmetry   'hermitian' | 'symmetric'
+  improve_candidates  relaxation descriptors (run on the device) | None
+
+Arithmetic follows the reference step by step (same scipy sparse products,
+same RNG consumption in the spectral-radius estimates), so for a seeded run the
+operators match the reference's to rounding -- tests/test_setup_golden.py pins
+that against the captured hierarchies.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import scipy.sparse as sparse
+from scipy.sparse import bsr_matrix, csr_matrix, isspmatrix_bsr, isspmatrix_csr
+
+from .multilevel import multilevel_solver
+from .smoothing import change_smoothers
+from .util import approximate_spectral_radius, get_diagonal, scale_rows
+
+__all__ = ["smoothed_aggregation_solver", "standard_aggregation", "fit_candidates",
+           "symmetric_strength_of_connection", "jacobi_prolongation_smoother"]
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_host = None
+
+
+def host_lib():
+    global _host
+    if _host is None:
+        path = os.path.join(_HERE, "lib", "libamgsetup_host.so")
+        if not os.path.exists(path):
+            raise ImportError("%s missing: run `make -C pyamg_amd/csrc`" % path)
+        L = C.CDLL(path)
+        ip, lp, dp = C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_double)
+        L.amgsetup_standard_aggregation.argtypes = [C.c_int, ip, ip, ip, ip]
+        L.amgsetup_standard_aggregation.restype = C.c_int
+        L.amgsetup_gauss_seidel.argtypes = [ip, ip, dp, dp, dp, C.c_int, C.c_int, C.c_int]
+        L.amgsetup_gauss_seidel.restype = None
+        L.amgsetup_csr_matmat_count.argtypes = [C.c_int, C.c_int, lp, ip, lp, ip, lp]
+        L.amgsetup_csr_matmat_count.restype = C.c_int64
+        L.amgsetup_csr_matmat_fill.argtypes = [C.c_int, C.c_int, lp, ip, dp, lp, ip, dp, lp, ip, dp]
+        L.amgsetup_csr_matmat_fill.restype = C.c_int64
+        L.amgsetup_csr_sort_indices.argtypes = [C.c_int, lp, ip, dp]
+        L.amgsetup_csr_sort_indices.restype = None
+        L.amgsetup_csr_transpose.argtypes = [C.c_int, C.c_int, lp, ip, dp, lp, ip, dp]
+        L.amgsetup_csr_transpose.restype = None
+        L.amgsetup_fit_candidates_scalar.argtypes = [C.c_int, ip, ip, dp, dp, dp, C.c_double]
+        L.amgsetup_fit_candidates_scalar.restype = None
+        L.amgsetup_num_threads.restype = C.c_int
+        _host = L
+    return _host
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+def _lp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int64))
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def unpack_arg(v):
+    if isinstance(v, tuple):
+        return v[0], v[1]
+    return v, {}
+
+
+def blocksize(A):
+    return A.blocksize[0] if isspmatrix_bsr(A) else 1
+
+
+# --------------------------------------------------------------------------- strength
+def symmetric_strength_of_connection(A, theta=0):
+    """pyamg/strength.py:213-318, amg_core/smoothed_aggregation.h:49-99:
+    keep a_ij with |a_ij| >= theta*sqrt(|a_ii a_jj|) (the diagonal always), take
+    magnitudes and scale each row by its largest entry."""
+    if theta < 0:
+        raise ValueError("expected a positive theta")
+    if isspmatrix_csr(A):
+        A = csr_matrix(A)
+        n = A.shape[0]
+        rows = np.repeat(np.arange(n), np.diff(A.indptr))
+        isdiag = rows == A.indices
+        d = np.zeros(n)
+        np.add.at(d, rows[isdiag], A.data[isdiag])
+        diags = np.abs(d)
+        eps = (theta * theta) * diags
+        keep = isdiag | (A.data * A.data >= eps[rows] * diags[A.indices])
+        Sp = np.concatenate(([0], np.cumsum(np.bincount(rows[keep], minlength=n)))).astype(A.indptr.dtype)
+        S = csr_matrix((A.data[keep], A.indices[keep], Sp), shape=A.shape)
+    elif isspmatrix_bsr(A):
+        M, N = A.shape
+        R, Cb = A.blocksize
+        if R != Cb:
+            raise ValueError("matrix must have square blocks")
+        if theta == 0:
+            data = np.ones(len(A.indices), dtype=A.dtype)
+            S = csr_matrix((data, A.indices.copy(), A.indptr.copy()), shape=(int(M / R), int(N / Cb)))
+        else:
+            data = (np.conjugate(A.data) * A.data).reshape(-1, R * Cb).sum(axis=1)
+            Ab = csr_matrix((data, A.indices, A.indptr), shape=(int(M / R), int(N / Cb)))
+            return symmetric_strength_of_connection(Ab, theta)
+    else:
+        raise TypeError("expected csr_matrix or bsr_matrix")
+    S.data = np.abs(S.data)
+    # scale_rows_by_largest_entry (util/utils.py)
+    largest = np.maximum.reduceat(S.data, S.indptr[:-1][np.diff(S.indptr) > 0]) if S.nnz else np.array([])
+    scale = np.ones(S.shape[0])
+    scale[np.diff(S.indptr) > 0] = largest
+    scale[scale == 0] = 1.0
+    S.data = S.data / np.repeat(scale, np.diff(S.indptr))
+    return S
+
+
+# --------------------------------------------------------------------------- aggregation
+def standard_aggregation(Cm):
+    """pyamg/aggregation/aggregate.py:20-105 -> (AggOp, Cpts)"""
+    if not isspmatrix_csr(Cm):
+        raise TypeError("expected csr_matrix")
+    if Cm.shape[0] != Cm.shape[1]:
+        raise ValueError("expected square matrix")
+    num_rows = Cm.shape[0]
+    Ap = np.ascontiguousarray(Cm.indptr, dtype=np.intc)
+    Aj = np.ascontiguousarray(Cm.indices, dtype=np.intc)
+    Tj = np.empty(num_rows, dtype=np.intc)
+    Cpts = np.empty(num_rows, dtype=np.intc)
+    num_aggregates = host_lib().amgsetup_standard_aggregation(num_rows, _ip(Ap), _ip(Aj), _ip(Tj), _ip(Cpts))
+    Cpts = Cpts[:num_aggregates]
+    if num_aggregates == 0:
+        return csr_matrix((num_rows, 1), dtype="int8"), np.array([], dtype=np.intc)
+    shape = (num_rows, num_aggregates)
+    if Tj.min() == -1:
+        mask = Tj != -1
+        row = np.arange(num_rows, dtype=np.intc)[mask]
+        col = Tj[mask]
+        data = np.ones(len(col), dtype="int8")
+        return sparse.coo_matrix((data, (row, col)), shape=shape).tocsr(), Cpts
+    Tp = np.arange(num_rows + 1, dtype=np.intc)
+    Tx = np.ones(len(Tj), dtype="int8")
+    return csr_matrix((Tx, Tj, Tp), shape=shape), Cpts
+
+
+# --------------------------------------------------------------------------- tentative prolongator
+def fit_candidates(AggOp, B, tol=1e-10):
+    """pyamg/aggregation/tentative.py:19-166 / amg_core/smoothed_aggregation.h:323-500:
+    per aggregate, modified Gram-Schmidt QR of the candidates restricted to it."""
+    if not isspmatrix_csr(AggOp):
+        raise TypeError("expected csr_matrix for argument AggOp")
+    B = np.asarray(B)
+    if B.dtype not in ["float32", "float64"]:
+        B = np.asarray(B, dtype="float64")
+    if len(B.shape) != 2:
+        raise ValueError("expected 2d array for argument B")
+    if B.shape[0] % AggOp.shape[0] != 0:
+        raise ValueError("dimensions of AggOp %s and B %s are incompatible" % (AggOp.shape, B.shape))
+    N_fine, N_coarse = AggOp.shape
+    K1 = int(B.shape[0] / N_fine)
+    K2 = B.shape[1]
+    AggOp_csc = AggOp.tocsc()
+    Ap, Ai = AggOp_csc.indptr, AggOp_csc.indices
+    nnz = AggOp.nnz
+    BS = K1 * K2
+    Bb = B.reshape(-1, K1, K2)
+    # copy blocks: Qx[ii] = B block of fine node Ai[ii]   (smoothed_aggregation.h:341-351)
+    Qx = Bb[Ai].copy()
+    R = np.zeros((N_coarse, K2, K2), dtype=B.dtype)
+    if K1 == 1 and K2 == 1:
+        # scalar fast path (one candidate, scalar unknowns)
+        q = np.empty(nnz, dtype=np.float64)
+        Rv = np.zeros(N_coarse, dtype=np.float64)
+        Bv = np.ascontiguousarray(B.ravel(), dtype=np.float64)
+        Ap32 = np.ascontiguousarray(Ap, dtype=np.intc)
+        Ai32 = np.ascontiguousarray(Ai, dtype=np.intc)
+        host_lib().amgsetup_fit_candidates_scalar(N_coarse, _ip(Ap32), _ip(Ai32), _dp(Bv), _dp(q), _dp(Rv),
+                                                  float(tol))
+        R[:, 0, 0] = Rv
+        Qx = q.reshape(-1, 1, 1)
+    else:
+        for j in range(N_coarse):
+            s, e = Ap[j], Ap[j + 1]
+            blk = Qx[s:e].reshape(-1, K2)            # ((e-s)*K1, K2) rows in storage order
+            for bj in range(K2):
+                norm_j = 0.0
+                for v in blk[:, bj]:
+                    norm_j += v * v
+                norm_j = np.sqrt(norm_j)
+                threshold_j = tol * norm_j
+                for bi in range(bj):
+                    dot_prod = 0.0
+                    for a, c in zip(blk[:, bj], blk[:, bi]):
+                        dot_prod += c * a
+                    blk[:, bj] -= dot_prod * blk[:, bi]
+                    R[j, bi, bj] = dot_prod
+                norm_j = 0.0
+                for v in blk[:, bj]:
+                    norm_j += v * v
+                norm_j = np.sqrt(norm_j)
+                if norm_j > threshold_j:
+                    scale = 1.0 / norm_j
+                    R[j, bj, bj] = norm_j
+                else:
+                    scale = 0.0
+                    R[j, bj, bj] = 0.0
+                blk[:, bj] *= scale
+            Qx[s:e] = blk.reshape(-1, K1, K2)
+    Q = bsr_matrix((Qx.swapaxes(1, 2).copy(), Ai, Ap), shape=(K2 * N_coarse, K1 * N_fine))
+    Q = Q.T.tobsr()
+    R = R.reshape(-1, K2)
+    return Q, R
+
+
+# --------------------------------------------------------------------------- prolongation smoothing
+def jacobi_prolongation_smoother(S, T, Cm, B, omega=4.0 / 3.0, degree=1, filter=False,
+                                 weighting="diagonal"):
+    """pyamg/aggregation/smooth.py:67-210 (weighting 'diagonal' / 'local', no filtering)."""
+    if filter:
+        raise NotImplementedError("filtered prolongation smoothing is outside the restated setup")
+    if weighting == "block":
+        if isspmatrix_csr(S) or (isspmatrix_bsr(S) and S.blocksize[0] == 1):
+            weighting = "diagonal"
+    if weighting == "diagonal":
+        D_inv = get_diagonal(S, inv=True)
+        D_inv_S = scale_rows(S, D_inv, copy=True)
+        D_inv_S = (omega / approximate_spectral_radius(D_inv_S)) * D_inv_S
+    elif weighting == "local":
+        D = np.abs(S) * np.ones((S.shape[0], 1), dtype=S.dtype)
+        D_inv = np.zeros_like(D)
+        D_inv[D != 0] = 1.0 / np.abs(D[D != 0])
+        D_inv_S = scale_rows(S, D_inv, copy=True)
+        D_inv_S = omega * D_inv_S
+    else:
+        raise NotImplementedError("weighting=%r" % weighting)
+    P = T
+    for i in range(degree):
+        P = P - (D_inv_S * P)
+    return P
+
+
+# --------------------------------------------------------------------------- driver
+def _levelize_sa(to_levelize, max_levels, max_coarse):
+    """util/utils.py:1872-1953"""
+    if isinstance(to_levelize, tuple):
+        if to_levelize[0] == "predefined":
+            to_levelize = [to_levelize]
+            max_levels = 2
+            max_coarse = 0
+        else:
+            to_levelize = [to_levelize for i in range(max_levels - 1)]
+    elif isinstance(to_levelize, str):
+        if to_levelize == "predefined":
+            raise ValueError("predefined to_levelize requires a user-provided CSR matrix")
+        to_levelize = [to_levelize for i in range(max_levels - 1)]
+    elif isinstance(to_levelize, list):
+        if isinstance(to_levelize[-1], tuple) and (to_levelize[-1][0] == "predefined"):
+            max_levels = len(to_levelize) + 1
+            max_coarse = 0
+        elif len(to_levelize) < max_levels - 1:
+            to_levelize = to_levelize + [to_levelize[-1]] * (max_levels - 1 - len(to_levelize))
+    elif to_levelize is None:
+        to_levelize = [(None, {}) for i in range(max_levels - 1)]
+    else:
+        raise ValueError("invalid to_levelize")
+    return max_levels, max_coarse, to_levelize
+
+
+def _levelize_smooth(to_levelize, max_levels):
+    """util/utils.py:1956-2006"""
+    if isinstance(to_levelize, tuple) or isinstance(to_levelize, str):
+        return [to_levelize for i in range(max_levels)]
+    if isinstance(to_levelize, list):
+        if len(to_levelize) < max_levels:
+            return to_levelize + [to_levelize[-1]] * (max_levels - len(to_levelize))
+        return list(to_levelize)
+    if to_levelize is None:
+        return [(None, {}) for i in range(max_levels)]
+    return to_levelize
+
+
+def _improve(method, A, B):
+    """relaxation_as_linear_operator(method, A, 0) * B  (util/utils.py:1129-1204,
+    aggregation.py:313-320): relax A x = 0 from each candidate column.  Setup runs on
+    the CPU: Gauss-Seidel sweeps use the host restatement of relaxation.h:34-62."""
+    from . import smoothing
+    fn, kwargs = unpack_arg(method)
+    lvl = multilevel_solver.level()
+    lvl.A = A
+    desc = getattr(smoothing, "setup_" + str(fn))(lvl, **kwargs).desc
+    if desc["name"] != "gauss_seidel" or (isspmatrix_bsr(A) and A.blocksize != (1, 1)):
+        raise NotImplementedError("improve_candidates=%r on this matrix is outside the restated setup" % (fn,))
+    Ac = A if isspmatrix_csr(A) else A.tocsr()
+    Ap = np.ascontiguousarray(Ac.indptr, dtype=np.intc)
+    Aj = np.ascontiguousarray(Ac.indices, dtype=np.intc)
+    Ax = np.ascontiguousarray(Ac.data, dtype=np.float64)
+    n = A.shape[0]
+    b = np.zeros(n)
+    out = np.empty_like(B)
+    bsr1 = isspmatrix_bsr(A)
+    if bsr1:
+        raise NotImplementedError("candidate improvement on BSR(1,1) levels")
+    L = host_lib()
+    for j in range(B.shape[1]):
+        x = np.ascontiguousarray(B[:, j], dtype=np.float64).copy()
+        for it in range(int(desc.get("iterations", 1))):
+            sw = desc.get("sweep", "forward")
+            if sw in ("forward", "symmetric"):
+                L.amgsetup_gauss_seidel(_ip(Ap), _ip(Aj), _dp(Ax), _dp(x), _dp(b), 0, n, 1)
+            if sw in ("backward", "symmetric"):
+                L.amgsetup_gauss_seidel(_ip(Ap), _ip(Aj), _dp(Ax), _dp(x), _dp(b), n - 1, -1, -1)
+        out[:, j] = x
+    return out
+
+
+def smoothed_aggregation_solver(A, B=None, BH=None, symmetry="hermitian", strength="symmetric",
+                                aggregate="standard", smooth=("jacobi", {"omega": 4.0 / 3.0}),
+                                presmoother=("block_gauss_seidel", {"sweep": "symmetric"}),
+                                postsmoother=("block_gauss_seidel", {"sweep": "symmetric"}),
+                                improve_candidates=[("block_gauss_seidel", {"sweep": "symmetric",
+                                                                            "iterations": 4}), None],
+                                max_levels=10, max_coarse=500, diagonal_dominance=False, keep=False,
+                                **kwargs):
+    """Create a multilevel solver using Smoothed Aggregation (SA)
+    (pyamg/aggregation/aggregation.py:30-290); returns a pyamg_amd.multilevel_solver."""
+    if not (isspmatrix_csr(A) or isspmatrix_bsr(A)):
+        try:
+            A = csr_matrix(A)
+        except Exception:
+            raise TypeError("Argument A must have type csr_matrix or bsr_matrix, or be convertible to csr_matrix")
+    A = A.astype(np.float64) if A.dtype != np.float64 else A
+    if symmetry not in ("symmetric", "hermitian"):
+        raise NotImplementedError("symmetry=%r is outside the restated setup" % (symmetry,))
+    if diagonal_dominance:
+        raise NotImplementedError("diagonal_dominance is outside the restated setup")
+    A.symmetry = symmetry
+    if A.shape[0] != A.shape[1]:
+        raise ValueError("expected square matrix")
+    if B is None:
+        B = np.kron(np.ones((int(A.shape[0] / blocksize(A)), 1), dtype=A.dtype), np.eye(blocksize(A)))
+    else:
+        B = np.asarray(B, dtype=A.dtype)
+        if len(B.shape) == 1:
+            B = B.reshape(-1, 1)
+        if B.shape[0] != A.shape[0]:
+            raise ValueError("The near null-space modes B have incorrect dimensions for matrix A")
+
+    max_levels, max_coarse, strength = _levelize_sa(strength, max_levels, max_coarse)
+    max_levels, max_coarse, aggregate = _levelize_sa(aggregate, max_levels, max_coarse)
+    improve_candidates = _levelize_smooth(list(improve_candidates) if isinstance(improve_candidates, list)
+                                          else improve_candidates, max_levels)
+    smooth = _levelize_smooth(smooth, max_levels)
+
+    levels = [multilevel_solver.level()]
+    levels[-1].A = A
+    levels[-1].B = B
+    while len(levels) < max_levels and int(levels[-1].A.shape[0] / blocksize(levels[-1].A)) > max_coarse:
+        extend_hierarchy(levels, strength, aggregate, smooth, improve_candidates, keep)
+    ml = multilevel_solver(levels, **kwargs)
+    change_smoothers(ml, presmoother, postsmoother)
+    return ml
+
+
+def extend_hierarchy(levels, strength, aggregate, smooth, improve_candidates, keep=True):
+    """aggregation.py:293-435"""
+    A = levels[-1].A
+    B = levels[-1].B
+
+    fn, kwargs = unpack_arg(improve_candidates[len(levels) - 1])
+    if fn is not None:
+        B = _improve((fn, kwargs), A, B)
+        levels[-1].B = B
+
+    fn, kwargs = unpack_arg(strength[len(levels) - 1])
+    if fn == "symmetric":
+        Cm = symmetric_strength_of_connection(A, **kwargs)
+    elif fn == "predefined":
+        Cm = kwargs["C"].tocsr()
+    elif fn is None:
+        Cm = A.tocsr()
+    else:
+        raise NotImplementedError("strength=%r is outside the restated setup" % (fn,))
+
+    fn, kwargs = unpack_arg(aggregate[len(levels) - 1])
+    if fn == "standard":
+        AggOp = standard_aggregation(Cm, **kwargs)[0]
+    elif fn == "predefined":
+        AggOp = kwargs["AggOp"].tocsr()
+    else:
+        raise NotImplementedError("aggregate=%r is outside the restated setup" % (fn,))
+
+    T, B = fit_candidates(AggOp, B)
+
+    fn, kwargs = unpack_arg(smooth[len(levels) - 1])
+    if fn == "jacobi":
+        P = jacobi_prolongation_smoother(A, T, Cm, B, **kwargs)
+    elif fn is None:
+        P = T
+    else:
+        raise NotImplementedError("smooth=%r is outside the restated setup" % (fn,))
+
+    symmetry = A.symmetry
+    R = P.conj().T.asformat(P.format) if symmetry == "hermitian" else P.T.asformat(P.format)
+
+    if keep:
+        levels[-1].C = Cm
+        levels[-1].AggOp = AggOp
+        levels[-1].T = T
+    levels[-1].P = P
+    levels[-1].R = R
+
+    levels.append(multilevel_solver.level())
+    A = R * A * P
+    A.symmetry = symmetry
+    levels[-1].A = A
+    levels[-1].B = B

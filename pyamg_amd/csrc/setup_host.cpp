@@ -1,0 +1,238 @@
+// Host-side (CPU) setup helpers for the smoothed-aggregation hierarchy.
+// The hierarchy is built ONCE on the CPU (north_star) and then shipped to HBM;
+// these routines exist so that the build travels to the GPU box without the
+// reference: they restate the setup kernels the BASELINE configurations need.
+// All reference paths relative to /root/reference.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+extern "C" {
+
+// pyamg/amg_core/smoothed_aggregation.h:122-222 (greedy three-pass aggregation).
+// x[i] = aggregate of node i (-1: isolated), y = root nodes; returns #aggregates.
+int amgsetup_standard_aggregation(int n_row, const int *Ap, const int *Aj, int *x, int *y)
+{
+    std::fill(x, x + n_row, 0);
+    int next_aggregate = 1;
+    for (int i = 0; i < n_row; i++) {                     // pass 1
+        if (x[i]) continue;
+        const int row_start = Ap[i], row_end = Ap[i + 1];
+        bool has_aggregated_neighbors = false, has_neighbors = false;
+        for (int jj = row_start; jj < row_end; jj++) {
+            const int j = Aj[jj];
+            if (i != j) {
+                has_neighbors = true;
+                if (x[j]) { has_aggregated_neighbors = true; break; }
+            }
+        }
+        if (!has_neighbors) {
+            x[i] = -n_row;
+        } else if (!has_aggregated_neighbors) {
+            x[i] = next_aggregate;
+            y[next_aggregate - 1] = i;
+            for (int jj = row_start; jj < row_end; jj++) x[Aj[jj]] = next_aggregate;
+            next_aggregate++;
+        }
+    }
+    for (int i = 0; i < n_row; i++) {                     // pass 2
+        if (x[i]) continue;
+        for (int jj = Ap[i]; jj < Ap[i + 1]; jj++) {
+            const int xj = x[Aj[jj]];
+            if (xj > 0) { x[i] = -xj; break; }
+        }
+    }
+    next_aggregate--;
+    for (int i = 0; i < n_row; i++) {                     // pass 3
+        const int xi = x[i];
+        if (xi != 0) {
+            if (xi > 0) x[i] = xi - 1;
+            else if (xi == -n_row) x[i] = -1;
+            else x[i] = -xi - 1;
+            continue;
+        }
+        x[i] = next_aggregate;
+        y[next_aggregate] = i;
+        for (int jj = Ap[i]; jj < Ap[i + 1]; jj++) {
+            const int j = Aj[jj];
+            if (x[j] == 0) x[j] = next_aggregate;
+        }
+        next_aggregate++;
+    }
+    return next_aggregate;
+}
+
+// pyamg/amg_core/relaxation.h:34-62 on the host: used only at SETUP time for the
+// candidate improvement sweeps when no device is wanted for it.
+void amgsetup_gauss_seidel(const int *Ap, const int *Aj, const double *Ax, double *x, const double *b,
+                           int row_start, int row_stop, int row_step)
+{
+    for (int i = row_start; i != row_stop; i += row_step) {
+        double rsum = 0, diag = 0;
+        for (int jj = Ap[i]; jj < Ap[i + 1]; jj++) {
+            int j = Aj[jj];
+            if (i == j) diag = Ax[jj];
+            else rsum += Ax[jj] * x[j];
+        }
+        if (diag != 0.0) x[i] = (b[i] - rsum) / diag;
+    }
+}
+
+// C = A * B for CSR operands, row-parallel restatement of scipy's SMMP
+// (scipy.sparse._sparsetools csr_matmat): per output row the products are
+// accumulated in the order of A's row entries, the output columns come out in
+// reverse first-touch order and exact zeros are dropped -- so a chain of
+// products rounds exactly like scipy's (and hence the reference's R*A*P).
+// Pass 1: returns per-row upper bounds in Cp64 (as counts, length n_row+1 after
+// prefix sum).  Pass 2 fills Cj/Cx and rewrites Cp64 with the compacted offsets.
+int64_t amgsetup_csr_matmat_count(int n_row, int n_col, const int64_t *Ap, const int *Aj,
+                                  const int64_t *Bp, const int *Bj, int64_t *Cp)
+{
+    Cp[0] = 0;
+#pragma omp parallel
+    {
+        std::vector<int> mask((size_t)n_col, -1);
+#pragma omp for schedule(dynamic, 4096)
+        for (int i = 0; i < n_row; i++) {
+            int64_t row_nnz = 0;
+            for (int64_t jj = Ap[i]; jj < Ap[i + 1]; jj++) {
+                int j = Aj[jj];
+                for (int64_t kk = Bp[j]; kk < Bp[j + 1]; kk++) {
+                    int k = Bj[kk];
+                    if (mask[k] != i) { mask[k] = i; row_nnz++; }
+                }
+            }
+            Cp[i + 1] = row_nnz;
+        }
+    }
+    for (int i = 0; i < n_row; i++) Cp[i + 1] += Cp[i];
+    return Cp[n_row];
+}
+
+int64_t amgsetup_csr_matmat_fill(int n_row, int n_col, const int64_t *Ap, const int *Aj, const double *Ax,
+                                 const int64_t *Bp, const int *Bj, const double *Bx, int64_t *Cp, int *Cj,
+                                 double *Cx)
+{
+    std::vector<int64_t> actual((size_t)n_row, 0);
+#pragma omp parallel
+    {
+        std::vector<int> next((size_t)n_col, -1);
+        std::vector<double> sums((size_t)n_col, 0.0);
+#pragma omp for schedule(dynamic, 4096)
+        for (int i = 0; i < n_row; i++) {
+            int head = -2, length = 0;
+            for (int64_t jj = Ap[i]; jj < Ap[i + 1]; jj++) {
+                int j = Aj[jj];
+                double v = Ax[jj];
+                for (int64_t kk = Bp[j]; kk < Bp[j + 1]; kk++) {
+                    int k = Bj[kk];
+                    sums[k] += v * Bx[kk];
+                    if (next[k] == -1) { next[k] = head; head = k; length++; }
+                }
+            }
+            int64_t nnz = Cp[i];
+            for (int jj = 0; jj < length; jj++) {
+                if (sums[head] != 0) { Cj[nnz] = head; Cx[nnz] = sums[head]; nnz++; }
+                int temp = head;
+                head = next[head];
+                next[temp] = -1;
+                sums[temp] = 0;
+            }
+            actual[i] = nnz - Cp[i];
+        }
+    }
+    // compact rows whose exact-zero results were dropped
+    int64_t pos = 0;
+    bool moved = false;
+    for (int i = 0; i < n_row; i++) {
+        int64_t start = Cp[i], cnt = actual[i];
+        if (start != pos) {
+            moved = true;
+            std::memmove(Cj + pos, Cj + start, sizeof(int) * (size_t)cnt);
+            std::memmove(Cx + pos, Cx + start, sizeof(double) * (size_t)cnt);
+        }
+        Cp[i] = pos;
+        pos += cnt;
+    }
+    (void)moved;
+    Cp[n_row] = pos;
+    return pos;
+}
+
+// in-place stable sort of the column indices of every row (scipy sort_indices)
+void amgsetup_csr_sort_indices(int n_row, const int64_t *Ap, int *Aj, double *Ax)
+{
+#pragma omp parallel
+    {
+        std::vector<std::pair<int, double>> tmp;
+#pragma omp for schedule(dynamic, 4096)
+        for (int i = 0; i < n_row; i++) {
+            int64_t s = Ap[i], e = Ap[i + 1];
+            bool sorted = true;
+            for (int64_t k = s + 1; k < e; k++)
+                if (Aj[k] < Aj[k - 1]) { sorted = false; break; }
+            if (sorted) continue;
+            tmp.resize((size_t)(e - s));
+            for (int64_t k = s; k < e; k++) tmp[(size_t)(k - s)] = {Aj[k], Ax[k]};
+            std::stable_sort(tmp.begin(), tmp.end(), [](const std::pair<int, double> &a, const std::pair<int, double> &b) { return a.first < b.first; });
+            for (int64_t k = s; k < e; k++) { Aj[k] = tmp[(size_t)(k - s)].first; Ax[k] = tmp[(size_t)(k - s)].second; }
+        }
+    }
+}
+
+// B = A^T for CSR (scipy csr_tocsc order: entries of each output row in ascending source row)
+void amgsetup_csr_transpose(int n_row, int n_col, const int64_t *Ap, const int *Aj, const double *Ax,
+                            int64_t *Bp, int *Bi, double *Bx)
+{
+    std::fill(Bp, Bp + n_col + 1, (int64_t)0);
+    int64_t nnz = Ap[n_row];
+    for (int64_t k = 0; k < nnz; k++) Bp[Aj[k] + 1]++;
+    for (int c = 0; c < n_col; c++) Bp[c + 1] += Bp[c];
+    std::vector<int64_t> cur(Bp, Bp + n_col);
+    for (int i = 0; i < n_row; i++)
+        for (int64_t k = Ap[i]; k < Ap[i + 1]; k++) {
+            int64_t d = cur[Aj[k]]++;
+            Bi[d] = i;
+            Bx[d] = Ax[k];
+        }
+}
+
+// pyamg/amg_core/smoothed_aggregation.h:323-500 for one candidate and scalar
+// unknowns (K1 = K2 = 1): normalise the candidate over every aggregate.
+// Ap/Ai: CSC of AggOp (members of aggregate j in ascending order).
+void amgsetup_fit_candidates_scalar(int n_col, const int *Ap, const int *Ai, const double *B,
+                                    double *Qx, double *R, double tol)
+{
+#pragma omp parallel for schedule(static)
+    for (int j = 0; j < n_col; j++) {
+        double norm_j = 0.0;
+        for (int ii = Ap[j]; ii < Ap[j + 1]; ii++) {
+            double v = B[Ai[ii]];
+            Qx[ii] = v;
+            norm_j += v * v;
+        }
+        norm_j = std::sqrt(norm_j);
+        const double threshold_j = tol * norm_j;
+        // (second norm evaluation of the reference gives the same value: nothing to orthogonalise)
+        double scale;
+        if (norm_j > threshold_j) { scale = 1.0 / norm_j; R[j] = norm_j; }
+        else { scale = 0.0; R[j] = 0.0; }
+        for (int ii = Ap[j]; ii < Ap[j + 1]; ii++) Qx[ii] *= scale;
+    }
+}
+
+int amgsetup_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+}  // extern "C"

@@ -1,0 +1,89 @@
+"""CPU: our smoothed-aggregation setup (pyamg_amd.aggregation) against the
+hierarchies the reference built (tests/golden/hier_sa_*.npz, generated with
+np.random.seed(0) before the setup): same level sizes and sparsity, operators and
+smoother constants equal to rounding."""
+import numpy as np
+import pytest
+import scipy.sparse as sps
+
+import golden_io
+from pyamg_amd.aggregation import (fit_candidates, smoothed_aggregation_solver, standard_aggregation,
+                                   symmetric_strength_of_connection)
+
+
+def poisson(grid):
+    A = None
+    for n in grid:
+        T = sps.diags([-np.ones(n - 1), 2 * np.ones(n), -np.ones(n - 1)], [-1, 0, 1], format="csr")
+        A = T if A is None else sps.kron(A, sps.identity(n), format="csr") + sps.kron(sps.identity(A.shape[0]), T, format="csr")
+    A = sps.csr_matrix(A); A.sort_indices()
+    A.indices = A.indices.astype(np.intc); A.indptr = A.indptr.astype(np.intc)
+    return A
+
+
+CASES = {
+    "sa_jacobi_2d": ((48, 48), ("jacobi", {"omega": 4.0 / 3.0}), dict(max_coarse=30)),
+    "sa_cheb2_3d": ((16, 16, 16), ("chebyshev", {"degree": 2}), dict(max_coarse=30)),
+    "sa_gs_3d": ((12, 12, 12), ("block_gauss_seidel", {"sweep": "symmetric"}), dict(max_coarse=30)),
+}
+
+
+def same(M, G, rtol):
+    M = sps.csr_matrix(M); G = sps.csr_matrix(G)
+    M.sort_indices(); G.sort_indices()
+    assert M.shape == G.shape
+    assert np.array_equal(M.indptr, G.indptr) and np.array_equal(M.indices, G.indices), "sparsity differs"
+    scale = np.abs(G.data).max()
+    assert np.abs(M.data - G.data).max() <= rtol * scale, np.abs(M.data - G.data).max() / scale
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_sa_setup_reproduces_reference_hierarchy(case):
+    grid, sm, kw = CASES[case]
+    g = golden_io.load_hier(case)
+    A = poisson(grid)
+    np.random.seed(0)
+    ml = smoothed_aggregation_solver(A, presmoother=sm, postsmoother=sm, **kw)
+    assert len(ml.levels) == g["meta"]["nlevels"]
+    for i, (lvl, G) in enumerate(zip(ml.levels, g["levels"])):
+        assert type(lvl.A).__name__ == type(G["A"]).__name__        # csr on level 0, bsr(1,1) below
+        same(lvl.A, G["A"], 1e-13)
+        if "P" in G:
+            same(lvl.P, G["P"], 1e-13)
+            same(lvl.R, G["R"], 1e-13)
+            d, gd = lvl.presmoother.desc, G["pre"]
+            assert d["name"] == gd["name"]
+            if "omega" in gd:
+                assert abs(d["omega"] - gd["omega"]) <= 1e-12 * abs(gd["omega"])
+            if "coefficients" in gd:
+                assert np.allclose(d["coefficients"], gd["coefficients"], rtol=1e-11, atol=0)
+
+
+def test_standard_aggregation_kat():
+    # hand-run of smoothed_aggregation.h:122-222 on a 6-node chain: pass 1 roots 0 ({0,1}) and
+    # 3 ({2,3,4}); pass 2 attaches node 5 to the aggregate of node 4
+    A = poisson((6,))
+    AggOp, Cpts = standard_aggregation(symmetric_strength_of_connection(A))
+    assert AggOp.shape == (6, 2)
+    assert np.array_equal(AggOp.indices, [0, 0, 1, 1, 1, 1])
+    assert np.array_equal(Cpts, [0, 3])
+    # isolated node is left out
+    M = sps.csr_matrix(np.array([[1.0, 0, 0], [0, 2.0, -1.0], [0, -1.0, 2.0]]))
+    AggOp, Cpts = standard_aggregation(M)
+    assert AggOp.shape == (3, 1) and AggOp.nnz == 2
+
+
+def test_fit_candidates_kat():
+    # pyamg/aggregation/tentative.py docstring examples
+    AggOp = sps.csr_matrix(np.array([[1, 0], [1, 0], [0, 1], [0, 1]]))
+    Q, R = fit_candidates(AggOp, [[1], [1], [1], [1]])
+    assert np.allclose(Q.toarray(), [[0.70710678, 0], [0.70710678, 0], [0, 0.70710678], [0, 0.70710678]])
+    assert np.allclose(R, [[1.41421356], [1.41421356]])
+    Q, R = fit_candidates(AggOp, [[1, 0], [1, 1], [1, 2], [1, 3]])
+    assert np.allclose(Q.toarray(), [[0.70710678, -0.70710678, 0, 0], [0.70710678, 0.70710678, 0, 0],
+                                     [0, 0, 0.70710678, -0.70710678], [0, 0, 0.70710678, 0.70710678]])
+    assert np.allclose(R, [[1.41421356, 0.70710678], [0, 0.70710678], [1.41421356, 3.53553391], [0, 0.70710678]])
+    AggOp = sps.csr_matrix(np.array([[1, 0], [1, 0], [0, 0], [0, 1]]))
+    Q, R = fit_candidates(AggOp, [[1], [1], [1], [1]])
+    assert np.allclose(Q.toarray(), [[0.70710678, 0], [0.70710678, 0], [0, 0], [0, 1]])
+    assert np.allclose(R, [[1.41421356], [1.0]])
