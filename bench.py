@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""V-cycle throughput of the MI355X AMG solve path on BASELINE.json's metric
+configuration: 3D Poisson 500^3 (125 M dof, 7-pt stencil) CSR fp64,
+smoothed-aggregation hierarchy, Chebyshev(2) pre/post smoother, V(1,1) cycles.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--grid 500] [--smoother chebyshev]
+
+One "step" = one multilevel_solver.solve() iteration: a V-cycle + the residual
+norm (pyamg/multilevel.py:454-461).  The hierarchy is resident in HBM before the
+timed region (b and x are device vectors).  Prints ONE JSON line (rank 0).
+
+N > 1: one process per GPU (torch.distributed / RCCL); round 1 runs N
+independent replicas of the whole problem ("replicas": no data-path exchange) --
+the row-partitioned fine level with halo exchange is not built yet.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def build_hierarchy(grid, smoother):
+    import pyamg_amd
+    from pyamg_amd.aggregation import poisson, smoothed_aggregation_solver
+    t0 = time.time()
+    A = poisson((grid, grid, grid))
+    t1 = time.time()
+    np.random.seed(0)
+    if smoother == "chebyshev":
+        sm = ("chebyshev", {"degree": 2})
+    elif smoother == "jacobi":
+        sm = ("jacobi", {"omega": 4.0 / 3.0})
+    elif smoother == "gauss_seidel":
+        sm = ("gauss_seidel", {"sweep": "symmetric"})
+    else:
+        raise ValueError(smoother)
+    ml = smoothed_aggregation_solver(A, presmoother=sm, postsmoother=sm)
+    t2 = time.time()
+    log("[bench] poisson %.1fs, SA setup %.1fs" % (t1 - t0, t2 - t1))
+    log(repr(ml))
+    return ml, (t1 - t0, t2 - t1)
+
+
+def oracle_hierarchy(ml):
+    """The CPU oracle (oracle/amg_oracle.c) on the same host arrays -- the timed CPU baseline."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    levels = []
+    for lvl in ml.levels:
+        L = {"A": lvl.A}
+        if hasattr(lvl, "P"):
+            L["P"], L["R"] = lvl.P, lvl.R
+            L["pre"] = dict(lvl.presmoother.desc)
+            L["post"] = dict(lvl.postsmoother.desc)
+        levels.append(L)
+    kind, M = ml.coarse_solver.device_form(ml.levels[-1].A)
+    return oracle_lib.Hierarchy(levels, M if kind == "dense" else None, dup_prolong=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--grid", type=int, default=500)
+    ap.add_argument("--smoother", default="chebyshev")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--variant", type=int, default=None, help="CSR stream kernel load variant (0/1)")
+    ap.add_argument("--xcd-chunk", type=int, default=None)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import pyamg_amd
+    from pyamg_amd import _lib
+    L = _lib.lib()
+    if pyamg_amd.device_count() <= local_rank:
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    if args.variant is not None:
+        L.amg_set_stream_variant(args.variant)
+    if args.xcd_chunk is not None:
+        L.amg_set_xcd_chunk(args.xcd_chunk)
+
+    ml, (t_gen, t_setup) = build_hierarchy(args.grid, args.smoother)
+    ml.device = local_rank
+    n = ml.levels[0].A.shape[0]
+    t0 = time.time()
+    dev = ml.device_hierarchy()
+    log("[bench] upload %.1fs, %.1f GB in HBM" % (time.time() - t0, dev.device_bytes() / 1e9))
+    h = dev.h
+
+    np.random.seed(0)
+    b = np.random.rand(n)
+    x = np.zeros(n)
+    res = np.zeros(max(args.steps, args.warmup) + 2)
+    nres = C.c_int(0)
+    NO_EARLY_STOP, DEVICE_VECTORS, X0_ZERO = 2, 4, 1
+
+    # warm-up from x0 = 0 with host vectors (leaves b and the iterate resident in HBM)
+    _lib.check(L.amg_hier_solve(h, b.ctypes.data, x.ctypes.data, 0.0, args.warmup, 0, _lib.dp(res),
+                                C.byref(nres), NO_EARLY_STOP | X0_ZERO))
+    warm_res = res[:nres.value].copy()
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # timed: EXACTLY K steps, inputs resident (device pointers), continuing from the warm iterate
+    db, dx = L.amg_hier_dev_b(h), L.amg_hier_dev_x(h)
+    sync_all()
+    t0 = time.perf_counter()
+    _lib.check(L.amg_hier_solve(h, db, dx, 0.0, args.steps, 0, _lib.dp(res), C.byref(nres),
+                                NO_EARLY_STOP | DEVICE_VECTORS))
+    sync_all()
+    wall = time.perf_counter() - t0
+    ev_ms = L.amg_hier_last_solve_ms(h)
+    timed_res = res[:nres.value].copy()
+    if dist is not None:
+        tw = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        wall = float(tw.item())
+
+    cycle_bytes = dev.cycle_bytes("V")
+    cycles_per_s = world * args.steps / wall
+
+    out = None
+    if rank == 0:
+        A0 = ml.levels[0].A
+        spmv_bytes = 12.0 * A0.nnz + 4.0 * (n + 1) + 8.0 * n + 8.0 * n + 8.0 * n   # bytes_spmv(A0) + 8 n
+        reps = 20
+        ms_resid = dev.time_spmv(0, 0, mode=1, reps=reps)     # r = b - A x  (csr_stream_kernel<SM_RESIDUAL>)
+        ms_matvec = dev.time_spmv(0, 0, mode=0, reps=reps)
+        ms_P = dev.time_spmv(0, 1, mode=0, reps=reps)
+        ms_R = dev.time_spmv(0, 2, mode=0, reps=reps)
+        ach = spmv_bytes / (ms_resid * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": "csr_stream_kernel (level-0 A-application, r = b - A x)",
+                    "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                    "bytes_per_launch": spmv_bytes, "ms_per_launch": round(ms_resid, 4),
+                    "cycle_bytes": cycle_bytes,
+                    "cycle_achieved_GBs": round(cycle_bytes * (args.steps / (ev_ms * 1e-3)) / 1e9, 1),
+                    "other_kernels_ms": {"A0_matvec": round(ms_matvec, 4), "P0_matvec": round(ms_P, 4),
+                                         "R0_matvec": round(ms_R, 4)}}
+        cpu = None
+        if not args.no_cpu_baseline:
+            H = oracle_hierarchy(ml)
+            xo = np.zeros(n)
+            t0 = time.perf_counter()
+            H.cycle(xo, b, "V")
+            # + the residual norm that closes the step (multilevel.py:461)
+            Ah = np.zeros(n)
+            A0c = ml.levels[0].A
+            ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
+            dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+            H.lib.oracle_csr_matvec(n, ip(A0c.indptr), ip(A0c.indices), dp(A0c.data), dp(xo), dp(Ah))
+            rn = H.lib.oracle_norm2(dp(b - Ah), n)
+            t_cpu = time.perf_counter() - t0
+            log("[bench] CPU oracle: 1 step in %.2fs, residual %.6e (GPU first step: %.6e)" % (t_cpu, rn, warm_res[1]))
+            cpu = {"value": round(1.0 / t_cpu, 5), "unit": "V-cycle iterations/s", "cores": 1, "kind": "port",
+                   "sample": "1 V-cycle of the same hierarchy and RHS from x0=0 with the C oracle "
+                             "(oracle/amg_oracle.c, -O3, 1 thread; includes the reference's discarded "
+                             "second P*coarse_x per level, multilevel.py:548)",
+                   "seconds": round(t_cpu, 3)}
+        out = {
+            "metric": "V-cycle iterations/sec (3D Poisson %d^3 fp64, SA-AMG, %s smoother)" % (args.grid, args.smoother),
+            "value": round(cycles_per_s, 4), "unit": "V-cycle iterations/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * wall / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "3D Poisson %dx%dx%d (%.1fM dof, nnz %.1fM) CSR fp64, smoothed aggregation "
+                                   "(%d levels), %s pre/post smoother, V(1,1), b=rand seed 0" %
+                                   (args.grid, args.grid, args.grid, n / 1e6, A0.nnz / 1e6, len(ml.levels),
+                                    "Chebyshev degree 2" if args.smoother == "chebyshev" else args.smoother),
+                       "parallelism": "single GPU" if world == 1 else "%d replicas (no exchange)" % world,
+                       "levels": [[int(l.A.shape[0]), int(l.A.nnz)] for l in ml.levels],
+                       "setup_seconds": {"matrix": round(t_gen, 1), "hierarchy": round(t_setup, 1)},
+                       "device_event_ms_per_step": round(ev_ms / args.steps, 4),
+                       "residuals": [float(warm_res[0]), float(warm_res[-1]), float(timed_res[-1])]},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -203,6 +203,16 @@ double *amg_hier_dev_b(amg_hier *h);
  * returns average ms per launch in *ms. */
 int amg_hier_time_spmv(amg_hier *h, int lvl, int which, int mode, int reps, double *ms);
 
+/* Setup-time helper (hierarchy construction, not the cycle): Arnoldi iteration on
+ * M = diag(dinv) * A_lvl (dinv NULL: M = A_lvl) as in pyamg/util/linalg.py:173-279, used for
+ * the spectral-radius estimates behind omega and the Chebyshev bounds.  H is
+ * (maxiter+1) x maxiter row-major on the host; the basis stays on the device. */
+int amg_arnoldi(amg_hier *h, int lvl, const double *dinv, const double *v0, int maxiter,
+                double breakdown_tol, double *H, int *steps, int *breakdown);
+/* v = V[:, :m] @ coef (restart vector); v is a host buffer of length n */
+int amg_arnoldi_combine(amg_hier *h, const double *coef, int m, double *v);
+void amg_arnoldi_free(amg_hier *h);
+
 /* tuning knobs (speed only): 0 = scalar loads, 1 = 16-byte loads in the CSR stream kernel;
  * XCD chunk: consecutive row blocks given to one XCD (0 = round-robin dispatch order) */
 void amg_set_stream_variant(int v);

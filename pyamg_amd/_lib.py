@@ -79,6 +79,8 @@ def lib():
         "amg_hier_relax": [V, I, I, c_dbl_p, c_dbl_p],
         "amg_hier_matvec": [V, I, I, c_dbl_p, c_dbl_p],
         "amg_hier_time_spmv": [V, I, I, I, I, c_dbl_p],
+        "amg_arnoldi": [V, I, c_dbl_p, c_dbl_p, I, D, c_dbl_p, c_int_p, c_int_p],
+        "amg_arnoldi_combine": [V, c_dbl_p, I, c_dbl_p],
     }
     for name, args in sig.items():
         f = getattr(L, name)
@@ -104,6 +106,8 @@ def lib():
     L.amg_hier_dev_x.restype = V
     L.amg_hier_dev_b.argtypes = [V]
     L.amg_hier_dev_b.restype = V
+    L.amg_arnoldi_free.argtypes = [V]
+    L.amg_arnoldi_free.restype = None
     L.amg_set_stream_variant.argtypes = [I]
     L.amg_set_stream_variant.restype = None
     L.amg_set_xcd_chunk.argtypes = [I]

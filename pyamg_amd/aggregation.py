@@ -25,7 +25,8 @@ from scipy.sparse import bsr_matrix, csr_matrix, isspmatrix_bsr, isspmatrix_csr
 
 from .multilevel import multilevel_solver
 from .smoothing import change_smoothers
-from .util import approximate_spectral_radius, get_diagonal, scale_rows
+from .util import (approximate_spectral_radius, approximate_spectral_radius_device, get_diagonal,
+                   release_device_operator, scale_rows, use_device_for)
 
 __all__ = ["smoothed_aggregation_solver", "standard_aggregation", "fit_candidates",
            "symmetric_strength_of_connection", "jacobi_prolongation_smoother"]
@@ -56,6 +57,15 @@ def host_lib():
         L.amgsetup_csr_transpose.restype = None
         L.amgsetup_fit_candidates_scalar.argtypes = [C.c_int, ip, ip, dp, dp, dp, C.c_double]
         L.amgsetup_fit_candidates_scalar.restype = None
+        L.amgsetup_poisson_nnz.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.amgsetup_poisson_nnz.restype = C.c_int64
+        L.amgsetup_poisson.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, lp, ip, dp]
+        L.amgsetup_poisson.restype = None
+        L.amgsetup_tentative_scalar.argtypes = [C.c_int, C.c_int, ip, dp, C.c_double, lp, ip, dp, dp]
+        L.amgsetup_tentative_scalar.restype = C.c_int64
+        L.amgsetup_smooth_prolongator.argtypes = [C.c_int, C.c_int, lp, ip, dp, dp, C.c_double, lp, ip, dp,
+                                                  lp, ip, dp]
+        L.amgsetup_smooth_prolongator.restype = C.c_int64
         L.amgsetup_num_threads.restype = C.c_int
         _host = L
     return _host
@@ -331,7 +341,7 @@ def smoothed_aggregation_solver(A, B=None, BH=None, symmetry="hermitian", streng
                                 improve_candidates=[("block_gauss_seidel", {"sweep": "symmetric",
                                                                             "iterations": 4}), None],
                                 max_levels=10, max_coarse=500, diagonal_dominance=False, keep=False,
-                                **kwargs):
+                                fast=True, **kwargs):
     """Create a multilevel solver using Smoothed Aggregation (SA)
     (pyamg/aggregation/aggregation.py:30-290); returns a pyamg_amd.multilevel_solver."""
     if not (isspmatrix_csr(A) or isspmatrix_bsr(A)):
@@ -366,13 +376,154 @@ def smoothed_aggregation_solver(A, B=None, BH=None, symmetry="hermitian", streng
     levels[-1].A = A
     levels[-1].B = B
     while len(levels) < max_levels and int(levels[-1].A.shape[0] / blocksize(levels[-1].A)) > max_coarse:
-        extend_hierarchy(levels, strength, aggregate, smooth, improve_candidates, keep)
+        extend_hierarchy(levels, strength, aggregate, smooth, improve_candidates, keep or not fast)
     ml = multilevel_solver(levels, **kwargs)
     change_smoothers(ml, presmoother, postsmoother)
     return ml
 
 
-def extend_hierarchy(levels, strength, aggregate, smooth, improve_candidates, keep=True):
+def poisson(grid, format="csr"):
+    """gallery.poisson(grid) (pyamg/gallery/laplacian.py:14-69) for 1-3 dimensions, generated
+    natively: 2d on the diagonal, -1 off it, last axis fastest, sorted int32 indices."""
+    grid = tuple(int(g) for g in grid)
+    if not 1 <= len(grid) <= 3 or min(grid) < 1:
+        raise ValueError("invalid grid shape: %s" % str(grid))
+    g3 = (1,) * (3 - len(grid)) + grid
+    L = host_lib()
+    n = g3[0] * g3[1] * g3[2]
+    nnz = L.amgsetup_poisson_nnz(*g3)
+    if nnz >= 2 ** 31:
+        raise ValueError("matrix exceeds int32 indices")
+    Ap = np.empty(n + 1, dtype=np.int64)
+    Aj = np.empty(nnz, dtype=np.intc)
+    Ax = np.empty(nnz, dtype=np.float64)
+    L.amgsetup_poisson(g3[0], g3[1], g3[2], 2.0 * len(grid), _lp(Ap), _ip(Aj), _dp(Ax))
+    A = csr_matrix((Ax, Aj, Ap.astype(np.intc)), shape=(n, n))
+    A.has_sorted_indices = True
+    return A.asformat(format)
+
+
+def _csr_arrays64(M):
+    """(indptr int64, indices int32, data f64) of a CSR / BSR(1,1) matrix, without copies when possible"""
+    data = M.data.reshape(-1) if isspmatrix_bsr(M) else M.data
+    return (np.ascontiguousarray(M.indptr, dtype=np.int64), np.ascontiguousarray(M.indices, dtype=np.intc),
+            np.ascontiguousarray(data, dtype=np.float64))
+
+
+def _matmat(Aa, Ba, shape):
+    """C = A*B with scipy's csr_matmat arithmetic and output order, row-parallel on the host."""
+    (Ap, Aj, Ax), (Bp, Bj, Bx) = Aa, Ba
+    L = host_lib()
+    n_row, n_col = shape
+    Cp = np.empty(n_row + 1, dtype=np.int64)
+    nnz = L.amgsetup_csr_matmat_count(n_row, n_col, _lp(Ap), _ip(Aj), _lp(Bp), _ip(Bj), _lp(Cp))
+    Cj = np.empty(nnz, dtype=np.intc)
+    Cx = np.empty(nnz, dtype=np.float64)
+    nnz2 = L.amgsetup_csr_matmat_fill(n_row, n_col, _lp(Ap), _ip(Aj), _dp(Ax), _lp(Bp), _ip(Bj), _dp(Bx),
+                                      _lp(Cp), _ip(Cj), _dp(Cx))
+    if nnz2 != nnz:
+        Cj = Cj[:nnz2].copy()
+        Cx = Cx[:nnz2].copy()
+    return Cp, Cj, Cx
+
+
+def _as_bsr11(arrs, shape):
+    Cp, Cj, Cx = arrs
+    if Cp[-1] >= 2 ** 31:
+        raise ValueError("operator exceeds int32 indices")
+    M = bsr_matrix((Cx.reshape(-1, 1, 1), Cj, Cp.astype(np.intc)), shape=shape, copy=False)
+    return M
+
+
+def _scalar_fast_path_ok(A, B, strength_l, aggregate_l, smooth_l):
+    if not (isspmatrix_csr(A) or (isspmatrix_bsr(A) and A.blocksize == (1, 1))):
+        return False
+    if B.shape[1] != 1:
+        return False
+    fn, kw = unpack_arg(strength_l)
+    if fn != "symmetric" or kw.get("theta", 0) != 0:
+        return False
+    fn, kw = unpack_arg(aggregate_l)
+    if fn != "standard" or kw:
+        return False
+    fn, kw = unpack_arg(smooth_l)
+    if fn != "jacobi" or kw.get("degree", 1) != 1 or kw.get("filter", False) or \
+            kw.get("weighting", "diagonal") not in ("diagonal", "block"):
+        return False
+    return True
+
+
+def _extend_scalar(levels, smooth_l, keep, rho_fn):
+    """extend_hierarchy for scalar problems with one candidate (the BASELINE Poisson
+    configurations), on flat arrays with the host helpers: same arithmetic as the generic
+    path below, sized for 10^8 unknowns."""
+    A = levels[-1].A
+    B = levels[-1].B
+    L = host_lib()
+    n = A.shape[0]
+    Ap, Aj, Ax = _csr_arrays64(A)
+    Ap32 = np.ascontiguousarray(A.indptr, dtype=np.intc)
+    # strength with theta = 0 keeps every entry: the aggregation only reads the pattern
+    agg = np.empty(n, dtype=np.intc)
+    cpts = np.empty(n, dtype=np.intc)
+    n_agg = L.amgsetup_standard_aggregation(n, _ip(Ap32), _ip(Aj), _ip(agg), _ip(cpts))
+    del cpts
+    if n_agg == 0:
+        raise ValueError("aggregation produced no aggregates")
+    # tentative prolongator
+    Bv = np.ascontiguousarray(B.ravel(), dtype=np.float64)
+    Tp = np.empty(n + 1, dtype=np.int64)
+    Tj = np.empty(n, dtype=np.intc)
+    Tx = np.empty(n, dtype=np.float64)
+    Bc = np.empty(n_agg, dtype=np.float64)
+    tnnz = L.amgsetup_tentative_scalar(n, n_agg, _ip(agg), _dp(Bv), 1e-10, _lp(Tp), _ip(Tj), _dp(Tx), _dp(Bc))
+    Tj, Tx = Tj[:tnnz], Tx[:tnnz]
+    # Jacobi prolongation smoothing: rho(D^-1 A), then P = T - (omega/rho) D^-1 A T
+    fn, kw = unpack_arg(smooth_l)
+    omega = kw.get("omega", 4.0 / 3.0)
+    D_inv = get_diagonal(A, inv=True)
+    rho = rho_fn(A, D_inv)
+    w = omega / rho
+    Pp = np.empty(n + 1, dtype=np.int64)
+    dnull = C.POINTER(C.c_double)()
+    inull = C.POINTER(C.c_int)()
+    pnnz = L.amgsetup_smooth_prolongator(n, n_agg, _lp(Ap), _ip(Aj), _dp(Ax), _dp(D_inv), float(w), _lp(Tp),
+                                         _ip(Tj), _dp(Tx), _lp(Pp), inull, dnull)
+    Pj = np.empty(pnnz, dtype=np.intc)
+    Px = np.empty(pnnz, dtype=np.float64)
+    L.amgsetup_smooth_prolongator(n, n_agg, _lp(Ap), _ip(Aj), _dp(Ax), _dp(D_inv), float(w), _lp(Tp),
+                                  _ip(Tj), _dp(Tx), _lp(Pp), _ip(Pj), _dp(Px))
+    # R = P^H (real: transpose)
+    Rp = np.empty(n_agg + 1, dtype=np.int64)
+    Rj = np.empty(pnnz, dtype=np.intc)
+    Rx = np.empty(pnnz, dtype=np.float64)
+    L.amgsetup_csr_transpose(n, n_agg, _lp(Pp), _ip(Pj), _dp(Px), _lp(Rp), _ip(Rj), _dp(Rx))
+    # Galerkin product (R*A)*P
+    RA = _matmat((Rp, Rj, Rx), (Ap, Aj, Ax), (n_agg, n))
+    Ac = _matmat(RA, (Pp, Pj, Px), (n_agg, n_agg))
+    del RA
+    P = _as_bsr11((Pp, Pj, Px), (n, n_agg))
+    R = _as_bsr11((Rp, Rj, Rx), (n_agg, n))
+    Anew = _as_bsr11(Ac, (n_agg, n_agg))
+    if keep:
+        levels[-1].AggOp = agg
+    levels[-1].P = P
+    levels[-1].R = R
+    levels.append(multilevel_solver.level())
+    Anew.symmetry = A.symmetry
+    levels[-1].A = Anew
+    levels[-1].B = Bc.reshape(-1, 1)
+
+
+def _rho_D_inv_A_host(A, D_inv):
+    """approximate_spectral_radius(scale_rows(A, D_inv)) as the reference does it (smooth.py:169-171);
+    operators beyond util.DEVICE_RHO_MIN_ROWS run the Arnoldi iterations on the GPU."""
+    if use_device_for(A):
+        return approximate_spectral_radius_device(A, D_inv)
+    return approximate_spectral_radius(scale_rows(A, D_inv, copy=True))
+
+
+def extend_hierarchy(levels, strength, aggregate, smooth, improve_candidates, keep=True, rho_fn=None):
     """aggregation.py:293-435"""
     A = levels[-1].A
     B = levels[-1].B
@@ -381,6 +532,10 @@ def extend_hierarchy(levels, strength, aggregate, smooth, improve_candidates, ke
     if fn is not None:
         B = _improve((fn, kwargs), A, B)
         levels[-1].B = B
+
+    li = len(levels) - 1
+    if not keep and _scalar_fast_path_ok(A, B, strength[li], aggregate[li], smooth[li]):
+        return _extend_scalar(levels, smooth[li], keep, rho_fn or _rho_D_inv_A_host)
 
     fn, kwargs = unpack_arg(strength[len(levels) - 1])
     if fn == "symmetric":

@@ -90,6 +90,11 @@ int launch_sub(double *out, const double *a, const double *b, long n, hipStream_
 int launch_copy_strided(double *dst, const double *src, int start, int count, int step, hipStream_t st);
 // ||x||_2 into *result_dev (deterministic two-stage reduction); scratch >= 1024 doubles
 int launch_norm2(const double *x, long n, double *scratch, double *result_dev, hipStream_t st);
+int launch_dot(const double *x, const double *y, long n, double *scratch, double *result_dev, hipStream_t st);
+int launch_axmy(double *w, const double *v, double a, long n, hipStream_t st);      // w -= a*v
+int launch_divide(double *w, double a, long n, hipStream_t st);                     // w /= a
+int launch_mul_elem(double *w, const double *d, long n, hipStream_t st);            // w *= d (elementwise)
+int launch_combine(double *out, const double *V, const double *coef_dev, int m, long n, long ld, hipStream_t st);
 // x = M b with M given transposed (Mt[k*n+i] = M[i][k]); sequential sum per row
 int launch_dense_apply(const double *Mt, const double *b, double *x, int n, hipStream_t st);
 

@@ -508,6 +508,9 @@ void amg_hier_destroy(amg_hier *h)
     }
     free_smoother(h->coarse_sm);
     if (h->coarse_Mt) hipFree(h->coarse_Mt);
+    if (h->arn_V) hipFree(h->arn_V);
+    if (h->arn_dinv) hipFree(h->arn_dinv);
+    if (h->arn_coef) hipFree(h->arn_coef);
     if (h->norm_scratch) hipFree(h->norm_scratch);
     if (h->res_dev) hipFree(h->res_dev);
     if (h->ev0) hipEventDestroy(h->ev0);
@@ -927,6 +930,106 @@ int amg_hier_time_spmv(amg_hier *h, int lvl, int which, int mode, int reps, doub
     AMG_HIP(hipEventElapsedTime(&t, h->ev0, h->ev1));
     *ms = t / reps;
     return 0;
+}
+
+// ---- setup-time helper: Arnoldi on a stored operator (pyamg/util/linalg.py:173-279) ----------
+// Krylov basis of M = diag(dinv) * A_lvl (dinv == NULL: M = A_lvl) from the start vector v0,
+// modified Gram-Schmidt exactly in the reference's order; H is (maxiter+1) x maxiter row-major on
+// the host.  The basis stays on the device for amg_arnoldi_combine.  *steps = columns computed;
+// *breakdown = 1 if H[j+1][j] fell below `breakdown_tol`.
+int amg_arnoldi(amg_hier *h, int lvl, const double *dinv, const double *v0, int maxiter,
+                double breakdown_tol, double *H, int *steps, int *breakdown)
+{
+    ENTER(h);
+    if (lvl < 0 || lvl >= h->nlevels || maxiter < 1 || !v0 || !H || !steps || !breakdown) { set_error("bad arnoldi arguments"); return AMG_EINVAL; }
+    Level &L = h->lv[lvl];
+    if (!L.hasA) { set_error("level has no A"); return AMG_ESTATE; }
+    const long n = L.A.nrows;
+    hipStream_t st = h->stream;
+    if (maxiter > n) maxiter = (int)n;
+    if (h->arn_m < maxiter || h->arn_n != n) {
+        if (h->arn_V) hipFree(h->arn_V);
+        if (h->arn_dinv) hipFree(h->arn_dinv);
+        if (h->arn_coef) hipFree(h->arn_coef);
+        h->arn_V = h->arn_dinv = h->arn_coef = nullptr;
+        CHK(dev_alloc(&h->arn_V, (long)(maxiter + 1) * n, (long *)nullptr));
+        CHK(dev_alloc(&h->arn_dinv, n, (long *)nullptr));
+        CHK(dev_alloc(&h->arn_coef, maxiter + 8, (long *)nullptr));
+        h->arn_m = maxiter; h->arn_n = n;
+    }
+    if (!h->norm_scratch) CHK(dev_alloc(&h->norm_scratch, 1024 + 8, &h->dev_bytes));
+    double *V = h->arn_V;
+    double *slot = h->norm_scratch + 1026;
+    if (dinv) AMG_HIP(hipMemcpyAsync(h->arn_dinv, dinv, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st));
+    AMG_HIP(hipMemcpyAsync(V, v0, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st));
+    auto fetch = [&](double *dst) -> int {
+        AMG_HIP(hipMemcpyAsync(dst, slot, sizeof(double), hipMemcpyDeviceToHost, st));
+        AMG_HIP(hipStreamSynchronize(st));
+        return 0;
+    };
+    double nv = 0.0;
+    CHK(launch_norm2(V, n, h->norm_scratch, slot, st));
+    CHK(fetch(&nv));
+    CHK(launch_divide(V, nv, n, st));                               // v0 /= norm(v0)
+    for (long q = 0; q < (long)(maxiter + 1) * maxiter; ++q) H[q] = 0.0;
+    *breakdown = 0;
+    int j = 0;
+    for (j = 0; j < maxiter; ++j) {
+        double *w = V + (long)(j + 1) * n;
+        CHK(spmv(L.A, SM_MATVEC, V + (long)j * n, nullptr, nullptr, w, nullptr, 0.0, st));
+        if (dinv) CHK(launch_mul_elem(w, h->arn_dinv, n, st));
+        for (int i = 0; i <= j; ++i) {
+            double hij = 0.0;
+            CHK(launch_dot(V + (long)i * n, w, n, h->norm_scratch, slot, st));
+            CHK(fetch(&hij));
+            H[(long)i * maxiter + j] = hij;
+            CHK(launch_axmy(w, V + (long)i * n, hij, n, st));
+        }
+        double beta = 0.0;
+        CHK(launch_norm2(w, n, h->norm_scratch, slot, st));
+        CHK(fetch(&beta));
+        H[(long)(j + 1) * maxiter + j] = beta;
+        if (beta < breakdown_tol) {
+            *breakdown = 1;
+            if (beta != 0.0) CHK(launch_divide(w, beta, n, st));
+            ++j;
+            break;
+        }
+        CHK(launch_divide(w, beta, n, st));
+    }
+    *steps = j;
+    AMG_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+// v = V[:, :m] @ coef  (the restart vector, util/linalg.py:397-404); v may be NULL to keep it
+// on the device only.  The result also becomes the next amg_arnoldi start if v0_from_device.
+int amg_arnoldi_combine(amg_hier *h, const double *coef, int m, double *v)
+{
+    ENTER(h);
+    if (!h->arn_V || m < 1 || m > h->arn_m || !coef) { set_error("bad combine arguments"); return AMG_EINVAL; }
+    const long n = h->arn_n;
+    double *tmp = nullptr;
+    CHK(dev_alloc(&tmp, n, (long *)nullptr));
+    AMG_HIP(hipMemcpyAsync(h->arn_coef, coef, sizeof(double) * (size_t)m, hipMemcpyHostToDevice, h->stream));
+    int rc = launch_combine(tmp, h->arn_V, h->arn_coef, m, n, n, h->stream);
+    if (rc == 0 && v) {
+        hipMemcpyAsync(v, tmp, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, h->stream);
+    }
+    hipStreamSynchronize(h->stream);
+    hipFree(tmp);
+    return rc;
+}
+
+void amg_arnoldi_free(amg_hier *h)
+{
+    if (!h) return;
+    hipSetDevice(h->device);
+    if (h->arn_V) hipFree(h->arn_V);
+    if (h->arn_dinv) hipFree(h->arn_dinv);
+    if (h->arn_coef) hipFree(h->arn_coef);
+    h->arn_V = h->arn_dinv = h->arn_coef = nullptr;
+    h->arn_m = 0; h->arn_n = 0;
 }
 
 void amg_set_stream_variant(int v) { amg::set_stream_variant(v); }

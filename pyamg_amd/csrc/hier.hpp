@@ -76,6 +76,12 @@ struct amg_hier {
     double *norm_scratch = nullptr;   // 1024 partials
     double *res_dev = nullptr;        // residual history on device
     int res_cap = 0;
+    // Arnoldi workspace for setup-time spectral-radius estimates
+    double *arn_V = nullptr;          // (arn_m + 1) vectors of length arn_n
+    double *arn_dinv = nullptr;
+    double *arn_coef = nullptr;
+    int arn_m = 0;
+    long arn_n = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double last_ms = 0.0;
     long dev_bytes = 0;

@@ -441,6 +441,81 @@ int launch_norm2(const double *x, long n, double *scratch, double *result_dev, h
     LAUNCH_CHECK("norm2");
 }
 
+// dot product, same deterministic two-stage scheme
+__global__ __launch_bounds__(256) void dot_stage1(const double *x, const double *y, long n, double *partial)
+{
+    __shared__ double smem[4];
+    double s0 = 0.0;
+    long stride = (long)gridDim.x * blockDim.x;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += stride) s0 += x[i] * y[i];
+    double r = block_reduce_sum(s0, smem);
+    if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+__global__ __launch_bounds__(256) void sum_stage2(const double *partial, int np, double *result)
+{
+    __shared__ double smem[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < np; i += blockDim.x) s += partial[i];
+    double r = block_reduce_sum(s, smem);
+    if (threadIdx.x == 0) *result = r;
+}
+int launch_dot(const double *x, const double *y, long n, double *scratch, double *result_dev, hipStream_t st)
+{
+    int nb = (int)((n + 255) / 256);
+    if (nb > NORM_BLOCKS) nb = NORM_BLOCKS;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(dot_stage1, dim3(nb), dim3(256), 0, st, x, y, n, scratch);
+    hipLaunchKernelGGL(sum_stage2, dim3(1), dim3(256), 0, st, scratch, nb, result_dev);
+    LAUNCH_CHECK("dot");
+}
+__global__ void axpy_kernel(double *w, const double *v, double a, long n)   // w = w - a*v
+{
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        w[i] = w[i] - a * v[i];
+}
+int launch_axmy(double *w, const double *v, double a, long n, hipStream_t st)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(axpy_kernel, dim3(vec_grid(n)), dim3(256), 0, st, w, v, a, n);
+    LAUNCH_CHECK("axmy");
+}
+__global__ void divide_kernel(double *w, double a, long n)
+{
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        w[i] = w[i] / a;
+}
+int launch_divide(double *w, double a, long n, hipStream_t st)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(divide_kernel, dim3(vec_grid(n)), dim3(256), 0, st, w, a, n);
+    LAUNCH_CHECK("divide");
+}
+__global__ void mul_elem_kernel(double *w, const double *d, long n)
+{
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        w[i] = w[i] * d[i];
+}
+int launch_mul_elem(double *w, const double *d, long n, hipStream_t st)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(mul_elem_kernel, dim3(vec_grid(n)), dim3(256), 0, st, w, d, n);
+    LAUNCH_CHECK("mul_elem");
+}
+__global__ void combine_kernel(double *out, const double *V, const double *coef, int m, long n, long ld)
+{
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        double s = 0.0;
+        for (int k = 0; k < m; ++k) s += V[(long)k * ld + i] * coef[k];
+        out[i] = s;
+    }
+}
+int launch_combine(double *out, const double *V, const double *coef_dev, int m, long n, long ld, hipStream_t st)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(combine_kernel, dim3(vec_grid(n)), dim3(256), 0, st, out, V, coef_dev, m, n, ld);
+    LAUNCH_CHECK("combine");
+}
+
 // ---------------------------------------------------------------------------
 // coarse solve: x = M b, M dense n x n (n <= a few hundred), stored transposed
 // so that lane i streams Mt[k*n+i] coalesced; strict left-to-right row sums

@@ -226,6 +226,136 @@ void amgsetup_fit_candidates_scalar(int n_col, const int *Ap, const int *Ai, con
     }
 }
 
+// d-D Poisson (d = 1..3) on an nx x ny x nz grid, 2d on the diagonal and -1 off it,
+// lexicographic ordering with the LAST axis fastest and sorted column indices: the CSR the
+// reference's gallery.poisson produces (pyamg/gallery/laplacian.py:14-69, stencil.py:12-138).
+// Ap has n+1 entries (int64), Aj/Ax have nnz = sum over axes of 2*(n - n/len_axis) + n entries.
+int64_t amgsetup_poisson_nnz(int nx, int ny, int nz)
+{
+    int64_t n = (int64_t)nx * ny * nz, nnz = n;
+    if (nx > 1) nnz += 2 * (n - n / nx);
+    if (ny > 1) nnz += 2 * (n - n / ny);
+    if (nz > 1) nnz += 2 * (n - n / nz);
+    return nnz;
+}
+
+void amgsetup_poisson(int nx, int ny, int nz, double diag, int64_t *Ap, int *Aj, double *Ax)
+{
+    const int64_t n = (int64_t)nx * ny * nz;
+    const int64_t sy = nz, sx = (int64_t)ny * nz;
+    // row lengths
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < n; r++) {
+        int k = (int)(r % nz), j = (int)((r / nz) % ny), i = (int)(r / sx);
+        int c = 1;
+        if (nx > 1) c += (i > 0) + (i < nx - 1);
+        if (ny > 1) c += (j > 0) + (j < ny - 1);
+        if (nz > 1) c += (k > 0) + (k < nz - 1);
+        Ap[r + 1] = c;
+    }
+    Ap[0] = 0;
+    for (int64_t r = 0; r < n; r++) Ap[r + 1] += Ap[r];
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < n; r++) {
+        int k = (int)(r % nz), j = (int)((r / nz) % ny), i = (int)(r / sx);
+        int64_t p = Ap[r];
+        if (nx > 1 && i > 0)      { Aj[p] = (int)(r - sx); Ax[p++] = -1.0; }
+        if (ny > 1 && j > 0)      { Aj[p] = (int)(r - sy); Ax[p++] = -1.0; }
+        if (nz > 1 && k > 0)      { Aj[p] = (int)(r - 1);  Ax[p++] = -1.0; }
+        Aj[p] = (int)r; Ax[p++] = diag;
+        if (nz > 1 && k < nz - 1) { Aj[p] = (int)(r + 1);  Ax[p++] = -1.0; }
+        if (ny > 1 && j < ny - 1) { Aj[p] = (int)(r + sy); Ax[p++] = -1.0; }
+        if (nx > 1 && i < nx - 1) { Aj[p] = (int)(r + sx); Ax[p++] = -1.0; }
+    }
+}
+
+// Tentative prolongator for one candidate and scalar unknowns, built directly in the layout
+// fit_candidates returns (Q.T.tobsr(): one stored entry per aggregated fine node, row i ->
+// column agg[i]); agg[i] = -1 leaves row i empty.  The per-aggregate sums run over the members
+// in ascending fine index, exactly the CSC order the reference walks
+// (pyamg/aggregation/tentative.py:146-160, amg_core/smoothed_aggregation.h:323-500).
+// Tp has n+1 entries.  Returns the number of stored entries.
+int64_t amgsetup_tentative_scalar(int n, int n_agg, const int *agg, const double *B, double tol,
+                                  int64_t *Tp, int *Tj, double *Tx, double *Bc)
+{
+    std::vector<double> norm2((size_t)n_agg, 0.0);
+    for (int i = 0; i < n; i++)
+        if (agg[i] >= 0) norm2[agg[i]] += B[i] * B[i];
+    std::vector<double> scale((size_t)n_agg);
+    for (int j = 0; j < n_agg; j++) {
+        double nj = std::sqrt(norm2[j]);
+        if (nj > tol * nj) { scale[j] = 1.0 / nj; Bc[j] = nj; }
+        else { scale[j] = 0.0; Bc[j] = 0.0; }
+    }
+    int64_t nnz = 0;
+    Tp[0] = 0;
+    for (int i = 0; i < n; i++) {
+        if (agg[i] >= 0) { Tj[nnz] = agg[i]; Tx[nnz] = B[i] * scale[agg[i]]; nnz++; }
+        Tp[i + 1] = nnz;
+    }
+    return nnz;
+}
+
+// Jacobi-smoothed prolongator P = T - (w * D^-1 S) * T for a tentative T with at most one
+// entry per row (pyamg/aggregation/smooth.py:163-205 with degree 1):
+//   X = (D_inv_S * T) by SMMP in the order of S's row entries, with
+//   D_inv_S_ik = (S_ik * dinv_i) * w   (scale_rows, then the scalar multiply), and
+//   P = T - X entry by entry on the sorted union of the two patterns, zeros dropped
+// (scipy's csr_matmat + csr_minus_csr).  Two calls: count (Pj == nullptr) then fill.
+int64_t amgsetup_smooth_prolongator(int n, int n_agg, const int64_t *Sp, const int *Sj, const double *Sx,
+                                    const double *dinv, double w, const int64_t *Tp, const int *Tj,
+                                    const double *Tx, int64_t *Pp, int *Pj, double *Px)
+{
+    const bool fill = (Pj != nullptr);
+    if (!fill) Pp[0] = 0;
+#pragma omp parallel
+    {
+        std::vector<std::pair<int, double>> acc;
+#pragma omp for schedule(dynamic, 8192)
+        for (int i = 0; i < n; i++) {
+            acc.clear();
+            const double di = dinv[i];
+            for (int64_t jj = Sp[i]; jj < Sp[i + 1]; jj++) {
+                int k = Sj[jj];
+                if (Tp[k + 1] == Tp[k]) continue;
+                double v = (Sx[jj] * di) * w;
+                int c = Tj[Tp[k]];
+                double prod = v * Tx[Tp[k]];
+                size_t q = 0;
+                for (; q < acc.size(); q++)
+                    if (acc[q].first == c) { acc[q].second += prod; break; }
+                if (q == acc.size()) acc.push_back({c, prod});   // sums start from 0: 0 + prod == prod
+            }
+            // X drops exact zeros (csr_matmat) and is stored in reverse first-touch order; T - X then
+            // runs through scipy's csr_binop_csr_general (X is not in canonical order), whose linked
+            // list is touched by T's entry first, then X's entries as stored, and is emitted in
+            // reverse touch order: X's columns in first-touch order (T's column excluded), then T's
+            // column.  The stored order matters: it is the summation order of every later SpMV.
+            const bool hasT = Tp[i + 1] > Tp[i];
+            const int tc = hasT ? Tj[Tp[i]] : -1;
+            const double tv = hasT ? Tx[Tp[i]] : 0.0;
+            int64_t cnt = 0, base = fill ? Pp[i] : 0;
+            auto emit = [&](int c, double v) {
+                if (v != 0.0) {
+                    if (fill) { Pj[base + cnt] = c; Px[base + cnt] = v; }
+                    cnt++;
+                }
+            };
+            double xt = 0.0;
+            for (auto &e : acc) {
+                if (e.second == 0.0) continue;
+                if (hasT && e.first == tc) { xt = e.second; continue; }
+                emit(e.first, 0.0 - e.second);
+            }
+            if (hasT) emit(tc, tv - xt);
+            if (!fill) Pp[i + 1] = cnt;
+        }
+    }
+    if (!fill)
+        for (int i = 0; i < n; i++) Pp[i + 1] += Pp[i];
+    return Pp[n];
+}
+
 int amgsetup_num_threads(void)
 {
 #ifdef _OPENMP

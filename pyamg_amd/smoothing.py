@@ -13,7 +13,8 @@ import scipy.sparse as sparse
 
 from . import relaxation
 from .chebyshev import chebyshev_polynomial_coefficients
-from .util import approximate_spectral_radius, get_block_diag, get_diagonal, scale_rows
+from .util import (approximate_spectral_radius, approximate_spectral_radius_device, get_block_diag,
+                   get_diagonal, scale_rows, use_device_for)
 
 __all__ = ["change_smoothers", "rho_D_inv_A", "rho_block_D_inv_A"]
 
@@ -64,8 +65,11 @@ def rho_D_inv_A(A):
     """smoothing.py:172-200"""
     if not hasattr(A, "rho_D_inv"):
         D_inv = get_diagonal(A, inv=True)
-        D_inv_A = scale_rows(A, D_inv, copy=True)
-        A.rho_D_inv = approximate_spectral_radius(D_inv_A)
+        if use_device_for(A):
+            A.rho_D_inv = approximate_spectral_radius_device(A, D_inv)
+        else:
+            D_inv_A = scale_rows(A, D_inv, copy=True)
+            A.rho_D_inv = approximate_spectral_radius(D_inv_A)
     return A.rho_D_inv
 
 

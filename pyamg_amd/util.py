@@ -8,6 +8,8 @@ import numpy as np
 import scipy.linalg
 from scipy.sparse import bsr_matrix, csr_matrix, isspmatrix, isspmatrix_bsr, isspmatrix_csc, isspmatrix_csr
 
+DEVICE_RHO_MIN_ROWS = 200000   # spectral-radius estimates of larger operators run on the GPU
+
 __all__ = ["type_prep", "to_type", "get_diagonal", "get_block_diag", "scale_rows", "norm",
            "approximate_spectral_radius", "upcast"]
 
@@ -149,6 +151,10 @@ def approximate_spectral_radius(A, tol=0.01, maxiter=15, restart=5, symmetric=No
                                 initial_guess=None, return_vector=False):
     """util/linalg.py:282-416.  Consumes the global numpy RNG exactly like the
     reference (one rand(n,1) per call), so seeded runs give the same rho."""
+    if (not hasattr(A, "rho")) and (not return_vector) and initial_guess is None and isspmatrix(A) \
+            and use_device_for(A):
+        A.rho = approximate_spectral_radius_device(A, None, tol, maxiter, restart)
+        return A.rho
     if not hasattr(A, "rho") or return_vector:
         if maxiter < 1:
             raise ValueError("expected maxiter > 0")
@@ -176,3 +182,116 @@ def approximate_spectral_radius(A, tol=0.01, maxiter=15, restart=5, symmetric=No
             return (rho, v0)
         return rho
     return A.rho
+
+
+# --------------------------------------------------------------------------- device-assisted setup
+class _DeviceOperator(object):
+    """A single stored operator in HBM (a one-level amg_hier) for setup-time Krylov work."""
+
+    def __init__(self, A, device=0):
+        from . import _lib
+        from scipy.sparse import isspmatrix_bsr as _isbsr
+        self._lib = _lib
+        L = _lib.lib()
+        self.L = L
+        self.n = A.shape[0]
+        self.h = L.amg_hier_create(1, int(device))
+        if not self.h:
+            raise _lib.AmgDeviceError(L.amg_last_error().decode())
+        if _isbsr(A):
+            fmt, (R, C) = 1, A.blocksize
+            data = np.ascontiguousarray(np.ravel(A.data), dtype=np.float64)
+        else:
+            A = csr_matrix(A)
+            fmt, R, C = 0, 1, 1
+            data = np.ascontiguousarray(A.data, dtype=np.float64)
+        Ap = np.ascontiguousarray(A.indptr, dtype=np.intc)
+        Aj = np.ascontiguousarray(A.indices, dtype=np.intc)
+        try:
+            _lib.check(L.amg_hier_set_matrix(self.h, 0, 0, fmt, A.shape[0], A.shape[1], R, C, Ap.ctypes.data,
+                                             Aj.ctypes.data, data.ctypes.data, 0))
+        except Exception:
+            self.close()
+            raise
+
+    def arnoldi(self, dinv, v0, maxiter, breakdown_tol):
+        import ctypes as C
+        _lib = self._lib
+        maxiter = min(self.n, maxiter)
+        H = np.zeros((maxiter + 1, maxiter), dtype=np.float64)
+        steps, brk = C.c_int(0), C.c_int(0)
+        v0 = np.ascontiguousarray(np.ravel(v0), dtype=np.float64)
+        dptr = _lib.dp(np.ascontiguousarray(dinv, dtype=np.float64)) if dinv is not None else None
+        _lib.check(self.L.amg_arnoldi(self.h, 0, dptr, _lib.dp(v0), int(maxiter), float(breakdown_tol),
+                                      _lib.dp(H), C.byref(steps), C.byref(brk)))
+        return H, steps.value, bool(brk.value)
+
+    def combine(self, coef):
+        _lib = self._lib
+        coef = np.ascontiguousarray(coef, dtype=np.float64)
+        v = np.empty(self.n, dtype=np.float64)
+        _lib.check(self.L.amg_arnoldi_combine(self.h, _lib.dp(coef), len(coef), _lib.dp(v)))
+        return v
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.amg_hier_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def device_operator(A):
+    """Cached HBM copy of A for setup-time estimates (released by release_device_operator)."""
+    op = getattr(A, "_amg_devop", None)
+    if op is None or op.h is None:
+        op = _DeviceOperator(A)
+        A._amg_devop = op
+    return op
+
+
+def release_device_operator(A):
+    op = getattr(A, "_amg_devop", None)
+    if op is not None:
+        op.close()
+        try:
+            del A._amg_devop
+        except AttributeError:
+            pass
+
+
+def use_device_for(A):
+    if A.shape[0] < DEVICE_RHO_MIN_ROWS:
+        return False
+    from . import _lib
+    return _lib.device_count() > 0
+
+
+def approximate_spectral_radius_device(A, dinv=None, tol=0.01, maxiter=15, restart=5):
+    """approximate_spectral_radius (util/linalg.py:282-416) of diag(dinv)*A (dinv None: A) with the
+    Arnoldi iterations on the GPU.  Same restart logic and the same single np.random.rand(n, 1)
+    draw as the reference; dots/norms are device reductions, so rho agrees to rounding, not bitwise."""
+    op = device_operator(A)
+    n = A.shape[0]
+    v0 = np.random.rand(n, 1).ravel()
+    breakdown_tol = np.finfo(float).eps * 1e6
+    ev = None
+    max_index = 0
+    for j in range(restart + 1):
+        H, m, breakdown = op.arnoldi(dinv, v0, maxiter, breakdown_tol)
+        ev, evect = scipy.linalg.eig(H[:m, :m], left=False, right=True)
+        max_index = np.abs(ev).argmax()
+        error = H[m, m - 1] * evect[-1, max_index]
+        if (np.abs(error) / np.abs(ev[max_index]) < tol) or breakdown:
+            break
+        coef = evect[:, max_index]
+        if np.iscomplexobj(coef):
+            if np.abs(coef.imag).max() > 1e-14 * np.abs(coef).max():
+                raise NotImplementedError("complex Ritz vector in the device spectral-radius estimate")
+            coef = coef.real
+        v0 = op.combine(coef)
+    return float(np.abs(ev[max_index]))
