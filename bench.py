@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--variant", type=int, default=None, help="CSR stream kernel load variant (0/1)")
     ap.add_argument("--xcd-chunk", type=int, default=None)
+    ap.add_argument("--tile-target", type=int, default=None)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -102,6 +103,8 @@ def main():
         L.amg_set_stream_variant(args.variant)
     if args.xcd_chunk is not None:
         L.amg_set_xcd_chunk(args.xcd_chunk)
+    if args.tile_target is not None:
+        L.amg_set_tile_target(args.tile_target)
 
     ml, (t_gen, t_setup) = build_hierarchy(args.grid, args.smoother)
     ml.device = local_rank

@@ -217,6 +217,8 @@ void amg_arnoldi_free(amg_hier *h);
  * XCD chunk: consecutive row blocks given to one XCD (0 = round-robin dispatch order) */
 void amg_set_stream_variant(int v);
 void amg_set_xcd_chunk(int c);
+/* products per workgroup aimed at when choosing rows per workgroup (default 2048 = one LDS tile) */
+void amg_set_tile_target(int t);
 
 #ifdef __cplusplus
 }

@@ -110,6 +110,8 @@ def lib():
     L.amg_arnoldi_free.restype = None
     L.amg_set_stream_variant.argtypes = [I]
     L.amg_set_stream_variant.restype = None
+    L.amg_set_tile_target.argtypes = [I]
+    L.amg_set_tile_target.restype = None
     L.amg_set_xcd_chunk.argtypes = [I]
     L.amg_set_xcd_chunk.restype = None
     _lib = L

@@ -70,6 +70,7 @@ struct StreamArgs {
     const int *rowmap;       // GS levels: original row of permuted row i (rhs/out index), else null
     const int *diagpos;      // GS levels: position of the diagonal entry of permuted row i (-1: none)
     long nnz_total;          // entries in Aj/Ax (bound for 16-byte loads)
+    int rows_per_wg;         // rows handled by one workgroup (1..256; 0 -> 256)
 };
 
 // variant: 0 = scalar (8 B / 4 B per lane) loads, 1 = 16-byte vector loads
@@ -77,6 +78,8 @@ int launch_stream(StreamMode mode, const StreamArgs &a, hipStream_t st);
 void set_stream_variant(int v);
 int stream_variant();
 void set_xcd_chunk(int c);
+void set_tile_target(int t);
+int rows_per_wg_for(long nnz, long rows);
 
 // thread-per-row fallbacks for non-unit strides / index lists (exact same arithmetic)
 int launch_jacobi_rows(const DevCsr &A, const double *temp, const double *b, double *x,

@@ -120,6 +120,7 @@ int run_csr_levels(const Schedule &S, bool bsr1, double *x, const double *b)
     StreamArgs a;
     std::memset(&a, 0, sizeof(a));
     a.Ap = S.G.Ap; a.Aj = S.G.Aj; a.Ax = S.G.Ax; a.nnz_total = S.G.nnz;
+    a.rows_per_wg = rows_per_wg_for(S.G.nnz, S.G.nrows);
     a.xg = x; a.b = b; a.out = x; a.rowmap = S.rowmap; a.diagpos = S.diagpos;
     for (int l = 0; l < S.nlevels(); ++l) {
         a.row_lo = S.level_ptr[l];
@@ -241,6 +242,7 @@ int amgcore_jacobi_f64(const int Ap[], int Ap_size, const int Aj[], int Aj_size,
         StreamArgs a;
         std::memset(&a, 0, sizeof(a));
         a.Ap = ch.M.Ap; a.Aj = ch.M.Aj; a.Ax = ch.M.Ax; a.nnz_total = ch.M.nnz;
+        a.rows_per_wg = rows_per_wg_for(ch.M.nnz, ch.M.nrows);
         a.row_lo = (row_step == 1) ? row_start : row_stop + 1;
         a.row_hi = (row_step == 1) ? row_stop : row_start + 1;
         a.xg = dt.d(); a.v2 = dt.d(); a.b = db.d(); a.out = dx.d(); a.c0 = omega[0];

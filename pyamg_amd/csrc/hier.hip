@@ -217,6 +217,7 @@ static StreamArgs base_args(const DevCsr &M)
     a.Ap = M.Ap; a.Aj = M.Aj; a.Ax = M.Ax;
     a.row_lo = 0; a.row_hi = M.nrows;
     a.nnz_total = M.nnz;
+    a.rows_per_wg = rows_per_wg_for(M.nnz, M.nrows);
     return a;
 }
 
@@ -1034,5 +1035,6 @@ void amg_arnoldi_free(amg_hier *h)
 
 void amg_set_stream_variant(int v) { amg::set_stream_variant(v); }
 void amg_set_xcd_chunk(int c) { amg::set_xcd_chunk(c); }
+void amg_set_tile_target(int t) { amg::set_tile_target(t); }
 
 }  // extern "C"

@@ -23,6 +23,21 @@ constexpr int TILE = 2048;   // products staged in LDS per pass (16 KiB)
 
 static int g_stream_variant = 1;
 static int g_xcd_chunk = 0;
+static int g_tile_target = 2048;   // products per workgroup aimed at when choosing rows per workgroup
+void set_tile_target(int t) { g_tile_target = t > 0 ? t : 2048; }
+
+// Rows per workgroup for a matrix with `nnz` entries in `rows` rows: enough rows to fill about
+// one LDS tile, so that long-row operators (restriction, coarse levels) still spread over many
+// workgroups and need one staging pass per workgroup.
+int rows_per_wg_for(long nnz, long rows)
+{
+    if (rows <= 0 || nnz <= 0) return WG;
+    double avg = (double)nnz / (double)rows;
+    int r = (int)(g_tile_target / (avg > 1.0 ? avg : 1.0));
+    int p = 1;
+    while (p * 2 <= r && p < WG) p *= 2;
+    return p;
+}
 void set_stream_variant(int v) { g_stream_variant = v; }
 int stream_variant() { return g_stream_variant; }
 void set_xcd_chunk(int c) { g_xcd_chunk = c; }
@@ -52,7 +67,7 @@ template <int MODE> struct ModeTraits {
 };
 
 template <int MODE, int VEC>
-__global__ __launch_bounds__(WG) void csr_stream_kernel(StreamArgs a, int xcd_chunk)
+__global__ __launch_bounds__(WG) void csr_stream_kernel(StreamArgs a, int xcd_chunk, int rpb)
 {
     const long nnz_total = a.nnz_total;
     using MT = ModeTraits<MODE>;
@@ -62,8 +77,8 @@ __global__ __launch_bounds__(WG) void csr_stream_kernel(StreamArgs a, int xcd_ch
 
     const int t = threadIdx.x;
     const int blk = remap_block(blockIdx.x, gridDim.x, xcd_chunk);
-    const int r0 = a.row_lo + blk * WG;
-    const int nr = min(WG, a.row_hi - r0);
+    const int r0 = a.row_lo + blk * rpb;          // rpb rows per workgroup (<= WG)
+    const int nr = min(rpb, a.row_hi - r0);
 
     for (int i = t; i <= nr; i += WG) sAp[i] = a.Ap[r0 + i];
     if (MT::jac) sdiag[t] = 0.0;
@@ -239,11 +254,13 @@ static int launch_stream_mode(const StreamArgs &a, hipStream_t st)
 {
     int rows = a.row_hi - a.row_lo;
     if (rows <= 0) return 0;
-    int nb = (rows + WG - 1) / WG;
+    int rpb = a.rows_per_wg;
+    if (rpb < 1 || rpb > WG) rpb = WG;
+    int nb = (rows + rpb - 1) / rpb;
     if (g_stream_variant)
-        hipLaunchKernelGGL((csr_stream_kernel<MODE, 1>), dim3(nb), dim3(WG), 0, st, a, g_xcd_chunk);
+        hipLaunchKernelGGL((csr_stream_kernel<MODE, 1>), dim3(nb), dim3(WG), 0, st, a, g_xcd_chunk, rpb);
     else
-        hipLaunchKernelGGL((csr_stream_kernel<MODE, 0>), dim3(nb), dim3(WG), 0, st, a, g_xcd_chunk);
+        hipLaunchKernelGGL((csr_stream_kernel<MODE, 0>), dim3(nb), dim3(WG), 0, st, a, g_xcd_chunk, rpb);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "csr_stream launch", __FILE__, __LINE__);
     return 0;
@@ -525,7 +542,15 @@ __global__ void dense_apply_kernel(const double *Mt, const double *b, double *x,
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     double s = 0.0;
-    for (int k = 0; k < n; ++k) s = s + Mt[(long)k * n + i] * b[k];
+    int k = 0;
+    for (; k + 8 <= n; k += 8) {           // 8 independent loads in flight, sums stay in order
+        double m[8], v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { m[u] = Mt[(long)(k + u) * n + i]; v[u] = b[k + u]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s = s + m[u] * v[u];
+    }
+    for (; k < n; ++k) s = s + Mt[(long)k * n + i] * b[k];
     x[i] = s;
 }
 
