@@ -9,9 +9,11 @@ One "step" = one multilevel_solver.solve() iteration: a V-cycle + the residual
 norm (pyamg/multilevel.py:454-461).  The hierarchy is resident in HBM before the
 timed region (b and x are device vectors).  Prints ONE JSON line (rank 0).
 
-N > 1: one process per GPU (torch.distributed / RCCL); round 1 runs N
-independent replicas of the whole problem ("replicas": no data-path exchange) --
-the row-partitioned fine level with halo exchange is not built yet.
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL over xGMI).  The SAME
+500^3 problem is row-partitioned over the N ranks on every level (pyamg_amd/distributed.py):
+halo exchange before each operator application, one all-reduce per step for the residual
+norm -> "scaling": "strong".  Rank 0 builds the hierarchy once and ships it to the other
+ranks through /dev/shm.  `--replicas` runs N independent copies instead (no exchange).
 """
 import argparse
 import ctypes as C
@@ -70,6 +72,88 @@ def oracle_hierarchy(ml):
     return oracle_lib.Hierarchy(levels, M if kind == "dense" else None, dup_prolong=True)
 
 
+def partitioned_main(args, rank, local_rank, world, torch, dist):
+    """strong scaling: one problem, rows of every level split over the ranks"""
+    import shutil
+    from pyamg_amd.distributed import (DistributedSolver, HipBackend, levels_from_ml, load_levels, save_levels,
+                                       split_rows)
+    host_group = dist.new_group(backend="gloo")
+    shared = "/dev/shm/amg_bench_%s" % os.environ.get("MASTER_PORT", "0")
+    n = args.grid ** 3
+    t_gen = t_setup = 0.0
+    if rank == 0:
+        shutil.rmtree(shared, ignore_errors=True)
+        ml, (t_gen, t_setup) = build_hierarchy(args.grid, args.smoother)
+        levels, coarse = levels_from_ml(ml)
+        t0 = time.time()
+        save_levels(shared, levels, coarse)
+        np.random.seed(0)
+        np.save(os.path.join(shared, "b.npy"), np.random.rand(n))
+        log("[bench] hierarchy shipped to %s in %.1fs" % (shared, time.time() - t0))
+        shape_info = [[int(L["A"].shape[0]), int(L["A"].nnz)] for L in levels]
+        del ml, levels
+    dist.barrier(group=host_group)
+    levels, coarse = load_levels(shared)
+    t0 = time.time()
+    S = DistributedSolver(levels, coarse, HipBackend(local_rank), rank, world, group=None, host_group=host_group)
+    bnd = split_rows(n, world)
+    lo, hi = int(bnd[rank]), int(bnd[rank + 1])
+    b = np.load(os.path.join(shared, "b.npy"), mmap_mode="r")[lo:hi]
+    S.set_problem(np.asarray(b), None)
+    log("[bench] rank %d: rows %d..%d, halos per level %s, partition+upload %.1fs" %
+        (rank, lo, hi, [lv.n_halo for lv in S.lv], time.time() - t0))
+    dist.barrier(group=host_group)
+    if rank == 0:
+        shutil.rmtree(shared, ignore_errors=True)
+
+    r0 = S.residual_norm()
+    warm = S.run_fixed(args.warmup, "V", x_zero=True)
+    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    timed = S.run_fixed(args.steps, "V", x_zero=False)
+    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    tw = torch.tensor([wall], dtype=torch.float64, device="cuda")
+    dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+    wall = float(tw.item())
+    # level-0 A-application on this rank's slab, hipEvents on the launch stream
+    lv = S.lv[0]
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 20
+    S.be.apply(lv.A, 2, lv.x, lv.b, None, lv.r, None, 0.0)
+    e0.record()
+    for _ in range(reps):
+        S.be.apply(lv.A, 2, lv.x, lv.b, None, lv.r, None, 0.0)
+    e1.record(); torch.cuda.synchronize()
+    ms_resid = e0.elapsed_time(e1) / reps
+    if rank == 0:
+        n_own = lv.n_own
+        spmv_bytes = 12.0 * lv.nnzA + 4.0 * (n_own + 1) + 24.0 * n_own
+        ach = spmv_bytes / (ms_resid * 1e-3) / 1e9
+        out = {
+            "metric": "V-cycle iterations/sec (3D Poisson %d^3 fp64, SA-AMG, %s smoother)" % (args.grid, args.smoother),
+            "value": round(args.steps / wall, 4), "unit": "V-cycle iterations/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * wall / args.steps, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "3D Poisson %dx%dx%d (%.1fM dof) CSR fp64, smoothed aggregation (%d levels), "
+                                   "%s pre/post smoother, V(1,1), b=rand seed 0" %
+                                   (args.grid, args.grid, args.grid, n / 1e6, len(S.lv), args.smoother),
+                       "parallelism": "rows of every level partitioned over %d GPUs, halo exchange + residual "
+                                      "all-reduce over RCCL" % world,
+                       "levels": shape_info, "halo_per_level_rank0": [lv_.n_halo for lv_ in S.lv],
+                       "setup_seconds": {"matrix": round(t_gen, 1), "hierarchy": round(t_setup, 1)},
+                       "residuals": [r0, warm[-1] if warm else r0, timed[-1]]},
+            "roofline": {"bound": "hbm", "kernel": "csr_stream_kernel (level-0 A-application on rank 0's row block)",
+                         "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                         "bytes_per_launch": spmv_bytes, "ms_per_launch": round(ms_resid, 4)},
+            "cpu_baseline": None,
+        }
+        print(json.dumps(out), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -81,6 +165,7 @@ def main():
     ap.add_argument("--variant", type=int, default=None, help="CSR stream kernel load variant (0/1)")
     ap.add_argument("--xcd-chunk", type=int, default=None)
     ap.add_argument("--tile-target", type=int, default=None)
+    ap.add_argument("--replicas", action="store_true", help="N>1: independent replicas instead of partitioning")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -105,6 +190,9 @@ def main():
         L.amg_set_xcd_chunk(args.xcd_chunk)
     if args.tile_target is not None:
         L.amg_set_tile_target(args.tile_target)
+
+    if world > 1 and not args.replicas:
+        return partitioned_main(args, rank, local_rank, world, torch, dist)
 
     ml, (t_gen, t_setup) = build_hierarchy(args.grid, args.smoother)
     ml.device = local_rank
@@ -168,6 +256,14 @@ def main():
                     "cycle_achieved_GBs": round(cycle_bytes * (args.steps / (ev_ms * 1e-3)) / 1e9, 1),
                     "other_kernels_ms": {"A0_matvec": round(ms_matvec, 4), "P0_matvec": round(ms_P, 4),
                                          "R0_matvec": round(ms_R, 4)}}
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+        if os.path.exists(pmc):
+            pj = json.load(open(pmc))
+            if pj.get("grid") == args.grid:
+                # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel (profiles/README.md);
+                # FETCH_SIZE doubled per MI355X_MICROARCH.md (calibrated on a known 1e9-byte read)
+                roofline["traffic"] = pj["traffic_bytes"]
+                roofline["traffic_source"] = pj["source"]
         cpu = None
         if not args.no_cpu_baseline:
             H = oracle_hierarchy(ml)

@@ -203,6 +203,29 @@ double *amg_hier_dev_b(amg_hier *h);
  * returns average ms per launch in *ms. */
 int amg_hier_time_spmv(amg_hier *h, int lvl, int which, int mode, int reps, double *ms);
 
+/* ------------------------------------------------------------------------ */
+/* 3. Device-pointer API: one operator in HBM + the vector kernels on        */
+/*    caller-owned DEVICE vectors and stream (hipStream_t as void*).  The    */
+/*    row-partitioned multi-GPU cycle (pyamg_amd/distributed.py) is built    */
+/*    from these; halos move through torch.distributed (RCCL).               */
+/* ------------------------------------------------------------------------ */
+typedef struct amg_mat amg_mat;
+/* copies a host CSR into HBM (local rows of a partitioned operator; column indices local) */
+amg_mat *amg_mat_create(int device, int nrows, int ncols, const int *Ap, const int *Aj, const double *Ax);
+void amg_mat_destroy(amg_mat *m);
+long amg_mat_nnz(amg_mat *m);
+/* one csr_stream launch.  mode: 0 out=Mx  1 out+=Mx  2 out=b-Mx  3 out=b-Mx,out2=c0*out
+ * 4 out=c0*b+Mx  5 out=v2+(c0*b+Mx)  6 Jacobi (CSR rounding)  7 Jacobi (BSR(1,1) rounding);
+ * xg is the gathered vector (owned entries followed by the halo) */
+int amg_mat_apply(amg_mat *m, int mode, const double *xg, const double *b, const double *v2, double *out,
+                  double *out2, double c0, void *stream);
+int amg_dev_scale(double *out, const double *in, double c, long n, void *stream);
+int amg_dev_axpy(double *x, const double *h, long n, void *stream);
+int amg_dev_norm2(const double *x, long n, double *scratch, double *result_dev, void *stream);
+int amg_dev_dot(const double *x, const double *y, long n, double *scratch, double *result_dev, void *stream);
+int amg_dev_dense_apply(const double *Mt, const double *b, double *x, int n, void *stream);
+int amg_dev_gather(double *out, const double *in, const int *idx, long n, void *stream);
+
 /* Setup-time helper (hierarchy construction, not the cycle): Arnoldi iteration on
  * M = diag(dinv) * A_lvl (dinv NULL: M = A_lvl) as in pyamg/util/linalg.py:173-279, used for
  * the spectral-radius estimates behind omega and the Chebyshev bounds.  H is

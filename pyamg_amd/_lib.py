@@ -79,6 +79,13 @@ def lib():
         "amg_hier_relax": [V, I, I, c_dbl_p, c_dbl_p],
         "amg_hier_matvec": [V, I, I, c_dbl_p, c_dbl_p],
         "amg_hier_time_spmv": [V, I, I, I, I, c_dbl_p],
+        "amg_mat_apply": [V, I, V, V, V, V, V, D, V],
+        "amg_dev_scale": [V, V, D, C.c_long, V],
+        "amg_dev_axpy": [V, V, C.c_long, V],
+        "amg_dev_norm2": [V, C.c_long, V, V, V],
+        "amg_dev_dot": [V, V, C.c_long, V, V, V],
+        "amg_dev_dense_apply": [V, V, V, I, V],
+        "amg_dev_gather": [V, V, V, C.c_long, V],
         "amg_arnoldi": [V, I, c_dbl_p, c_dbl_p, I, D, c_dbl_p, c_int_p, c_int_p],
         "amg_arnoldi_combine": [V, c_dbl_p, I, c_dbl_p],
     }
@@ -106,6 +113,12 @@ def lib():
     L.amg_hier_dev_x.restype = V
     L.amg_hier_dev_b.argtypes = [V]
     L.amg_hier_dev_b.restype = V
+    L.amg_mat_create.argtypes = [I, I, I, c_int_p, c_int_p, c_dbl_p]
+    L.amg_mat_create.restype = V
+    L.amg_mat_destroy.argtypes = [V]
+    L.amg_mat_destroy.restype = None
+    L.amg_mat_nnz.argtypes = [V]
+    L.amg_mat_nnz.restype = C.c_long
     L.amg_arnoldi_free.argtypes = [V]
     L.amg_arnoldi_free.restype = None
     L.amg_set_stream_variant.argtypes = [I]

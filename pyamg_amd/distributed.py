@@ -1,0 +1,512 @@
+"""Row-partitioned multi-GPU solve: one process per GPU, every level of the
+hierarchy split into contiguous row blocks, neighbour halos moved with
+torch.distributed (backend "nccl" = RCCL over xGMI), one scalar all-reduce per
+iteration for the residual norm.
+
+The reference has no distributed path; the arithmetic contract is that of the
+single-GPU cycle (pyamg/multilevel.py:316-548): every row is summed exactly as
+before, its off-rank operands arriving through a halo appended to the local
+vector, so Jacobi / polynomial (Chebyshev) cycles produce iterates that are
+BIT-IDENTICAL to the one-GPU run whatever the number of ranks; only the
+residual norm differs in the last bits (per-rank partial sums are all-reduced).
+Gauss-Seidel sweeps are inherently sequential across ranks and are not offered
+here (hybrid GS is the C4 item still open).
+
+Layout per rank and level l (vector space V_l):  [ owned entries | halo ]
+ * owned = the contiguous index range bounds[l][rank] .. bounds[l][rank+1]
+ * halo  = the sorted off-rank indices any local row of A_l, R_l or P_{l-1}
+           gathers from V_l (grouped by owner because owners are contiguous),
+           so ONE exchange plan per level serves all three operators.
+Local operators keep their rows' entry order and only renumber columns
+(owned -> 0..n_own-1, halo -> n_own + position), so summation order is kept.
+
+The compute backend is pluggable: `HipBackend` (the product: csr_stream kernels
+through include/amgcore_hip.h section 3 on torch CUDA tensors).  tests/ plug a
+CPU backend built on the oracle to exercise partitioning, plans and exchange
+sequencing with gloo where no GPU exists.
+"""
+import ctypes as C
+
+import numpy as np
+import scipy.sparse as sparse
+
+MATVEC, MATVEC_ACC, RESIDUAL, POLY_FIRST, POLY_STEP, POLY_LAST, JACOBI, JACOBI_BSR1 = range(8)
+
+
+def split_rows(n, world):
+    return np.array([(n * p) // world for p in range(world + 1)], dtype=np.int64)
+
+
+class _Lazy(object):
+    """memory-mapped global CSR arrays with the small interface local_rows needs"""
+
+    def __init__(self, Ap, Aj, Ax, shape, bsr):
+        self.indptr, self.indices, self.data, self.shape, self._bsr = Ap, Aj, Ax, shape, bsr
+        self.nnz = int(Ap[-1])
+
+
+def _csr_view(M):
+    """(indptr, indices, data, is_bsr11) of a CSR or BSR(1,1) matrix"""
+    if isinstance(M, _Lazy):
+        return M.indptr, M.indices, M.data, M._bsr
+    if sparse.isspmatrix_bsr(M):
+        if M.blocksize != (1, 1):
+            raise NotImplementedError("the partitioned path supports scalar (CSR / BSR(1,1)) operators")
+        return M.indptr, M.indices, M.data.reshape(-1), True
+    if not sparse.isspmatrix_csr(M):
+        M = sparse.csr_matrix(M)
+    return M.indptr, M.indices, M.data, False
+
+
+def local_rows(M, lo, hi):
+    """rows [lo, hi) of a global operator: (Ap rebased, Aj global, Ax)"""
+    Ap, Aj, Ax, _ = _csr_view(M)
+    s, e = int(Ap[lo]), int(Ap[hi])
+    return (np.asarray(Ap[lo:hi + 1], dtype=np.int64) - s, np.asarray(Aj[s:e], dtype=np.int64),
+            np.asarray(Ax[s:e], dtype=np.float64))
+
+
+class HipBackend(object):
+    """csr_stream kernels + vector kernels on torch CUDA tensors (the product path)."""
+
+    def __init__(self, device):
+        import torch
+        from . import _lib
+        self.torch = torch
+        self._lib = _lib
+        self.L = _lib.lib()
+        self.device = int(device)
+        if _lib.device_count() <= self.device:
+            raise _lib.AmgDeviceError("no HIP device %d (no CPU fallback)" % self.device)
+        torch.cuda.set_device(self.device)
+        self.dev = torch.device("cuda", self.device)
+        self.scratch = torch.zeros(1100, dtype=torch.float64, device=self.dev)
+        self._mats = []
+
+    def stream(self):
+        return self.torch.cuda.current_stream(self.dev).cuda_stream
+
+    def vec(self, n):
+        return self.torch.zeros(max(int(n), 1), dtype=self.torch.float64, device=self.dev)
+
+    def ivec(self, a):
+        return self.torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(self.dev)
+
+    def from_host(self, t, a):
+        t[:len(a)].copy_(self.torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)))
+
+    def to_host(self, t, n):
+        return t[:n].cpu().numpy()
+
+    def mat(self, nrows, ncols, Ap, Aj, Ax):
+        Ap = np.ascontiguousarray(Ap, dtype=np.intc)
+        Aj = np.ascontiguousarray(Aj, dtype=np.intc)
+        Ax = np.ascontiguousarray(Ax, dtype=np.float64)
+        h = self.L.amg_mat_create(self.device, int(nrows), int(ncols), self._lib.ip(Ap), self._lib.ip(Aj),
+                                  self._lib.dp(Ax))
+        if not h:
+            raise self._lib.AmgError(self.L.amg_last_error().decode())
+        self._mats.append(h)
+        return h
+
+    @staticmethod
+    def _p(t):
+        return None if t is None else t.data_ptr()
+
+    def apply(self, m, mode, xg, b, v2, out, out2, c0):
+        self._lib.check(self.L.amg_mat_apply(m, mode, self._p(xg), self._p(b), self._p(v2), self._p(out),
+                                             self._p(out2), float(c0), self.stream()))
+
+    def scale(self, out, inp, c, n):
+        self._lib.check(self.L.amg_dev_scale(out.data_ptr(), inp.data_ptr(), float(c), int(n), self.stream()))
+
+    def axpy(self, x, h, n):
+        self._lib.check(self.L.amg_dev_axpy(x.data_ptr(), h.data_ptr(), int(n), self.stream()))
+
+    def gather(self, out, inp, idx, n):
+        self._lib.check(self.L.amg_dev_gather(out.data_ptr(), inp.data_ptr(), idx.data_ptr(), int(n), self.stream()))
+
+    def sumsq(self, x, n, out):
+        """out[0] = sum of squares of x[:n] (device tensor of 1 double)"""
+        self._lib.check(self.L.amg_dev_dot(x.data_ptr(), x.data_ptr(), int(n), self.scratch.data_ptr(),
+                                           out.data_ptr(), self.stream()))
+
+    def dense(self, Mt, b, x, n):
+        self._lib.check(self.L.amg_dev_dense_apply(Mt.data_ptr(), b.data_ptr(), x.data_ptr(), int(n), self.stream()))
+
+    def zero(self, t, n):
+        t[:n].zero_()
+
+    def synchronize(self):
+        self.torch.cuda.synchronize(self.dev)
+
+    def close(self):
+        for h in self._mats:
+            self.L.amg_mat_destroy(h)
+        self._mats = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class _Level(object):
+    pass
+
+
+class DistributedSolver(object):
+    """multilevel_solver.solve() on a row-partitioned hierarchy.
+
+    levels : list of dicts {A, P, R, pre, post} with GLOBAL scipy operators (P/R/pre/post absent
+             on the coarsest level) and smoother descriptors as in smoothing.py's `.desc`
+    coarse_dense : dense coarse operator (x = M b) or None
+    group : torch.distributed group for the halos / all-reduce (device tensors)
+    host_group : group able to move CPU tensors (gloo) for the setup-time index exchange
+    """
+
+    def __init__(self, levels, coarse_dense, backend, rank, world, group=None, host_group=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.be = backend
+        self.rank, self.world = rank, world
+        self.group, self.host_group = group, host_group if host_group is not None else group
+        self.nlevels = len(levels)
+        self.bounds = [split_rows(L["A"].shape[0], world) for L in levels]
+        self.lv = []
+        self._build(levels, coarse_dense)
+
+    # ------------------------------------------------------------------ setup
+    def _build(self, levels, coarse_dense):
+        torch, dist = self.torch, self.dist
+        r, W = self.rank, self.world
+        nl = self.nlevels
+        own = [(int(b[r]), int(b[r + 1])) for b in self.bounds]
+        loc = []
+        for l, L in enumerate(levels):
+            d = {"A": local_rows(L["A"], *own[l])}
+            d["bsr"] = bool(_csr_view(L["A"])[3])
+            if l < nl - 1:
+                d["P"] = local_rows(L["P"], *own[l])            # fine rows, coarse columns (V_{l+1})
+                d["R"] = local_rows(L["R"], *own[l + 1])        # coarse rows, fine columns (V_l)
+            loc.append(d)
+        # union halo of every vector space
+        halos = []
+        for l in range(nl):
+            lo, hi = own[l]
+            cols = [loc[l]["A"][1]]
+            if l < nl - 1:
+                cols.append(loc[l]["R"][1])
+            if l > 0:
+                cols.append(loc[l - 1]["P"][1])
+            c = np.concatenate(cols) if cols else np.zeros(0, dtype=np.int64)
+            c = c[(c < lo) | (c >= hi)]
+            halos.append(np.unique(c))
+        # tell every owner what we need (setup-time, host tensors)
+        for l in range(nl):
+            lv = _Level()
+            lo, hi = own[l]
+            lv.n_own = hi - lo
+            H = halos[l]
+            lv.n_halo = len(H)
+            owner = np.searchsorted(self.bounds[l], H, side="right") - 1
+            recv_counts = np.bincount(owner, minlength=W).astype(np.int64)
+            send_counts = np.zeros(W, dtype=np.int64)
+            if W > 1:
+                tc = torch.from_numpy(recv_counts.copy())
+                ts = torch.zeros(W, dtype=torch.int64)
+                dist.all_to_all_single(ts, tc, group=self.host_group)
+                send_counts = ts.numpy().copy()
+                req = torch.from_numpy(H.astype(np.int64))
+                got = torch.zeros(int(send_counts.sum()), dtype=torch.int64)
+                dist.all_to_all_single(got, req, [int(v) for v in send_counts], [int(v) for v in recv_counts],
+                                       group=self.host_group)
+                send_idx = got.numpy() - lo
+                if len(send_idx) and (send_idx.min() < 0 or send_idx.max() >= lv.n_own):
+                    raise RuntimeError("halo request outside the owner's range")
+            else:
+                send_idx = np.zeros(0, dtype=np.int64)
+            lv.recv_counts = [int(v) for v in recv_counts]
+            lv.send_counts = [int(v) for v in send_counts]
+            lv.n_send = int(send_counts.sum())
+            lv.send_idx = self.be.ivec(send_idx) if lv.n_send else None
+            lv.sendbuf = self.be.vec(lv.n_send)
+            lv.halo_ids = H
+            lv.comm = (lv.n_halo + lv.n_send) > 0
+            if W > 1:
+                flag = torch.tensor([1.0 if lv.comm else 0.0], dtype=torch.float64)
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.host_group)
+                lv.comm = bool(flag.item() > 0.5)      # every rank joins the exchange or none does
+            self.lv.append(lv)
+        # local operators with renumbered columns
+        def renum(cols, l):
+            lo, hi = own[l]
+            out = np.empty(len(cols), dtype=np.int64)
+            m = (cols >= lo) & (cols < hi)
+            out[m] = cols[m] - lo
+            out[~m] = self.lv[l].n_own + np.searchsorted(halos[l], cols[~m])
+            return out
+        for l, L in enumerate(levels):
+            lv = self.lv[l]
+            n_ext = lv.n_own + lv.n_halo
+            Ap, Aj, Ax = loc[l]["A"]
+            lv.A = self.be.mat(lv.n_own, n_ext, Ap, renum(Aj, l), Ax)
+            lv.A_bsr = loc[l]["bsr"]
+            lv.nnzA = len(Ax)
+            if l < nl - 1:
+                nxt = self.lv[l + 1]
+                Pp, Pj, Px = loc[l]["P"]
+                lv.P = self.be.mat(lv.n_own, nxt.n_own + nxt.n_halo, Pp, renum(Pj, l + 1), Px)
+                Rp, Rj, Rx = loc[l]["R"]
+                lv.R = self.be.mat(nxt.n_own, n_ext, Rp, renum(Rj, l), Rx)
+                lv.pre, lv.post = L.get("pre"), L.get("post")
+                for s in (lv.pre, lv.post):
+                    if s is not None and s.get("name") not in (None, "jacobi", "polynomial"):
+                        raise NotImplementedError(
+                            "smoother %r is sequential across ranks; the partitioned path offers jacobi / "
+                            "polynomial (chebyshev, richardson) / None" % (s.get("name"),))
+            for nm in ("x", "xalt", "b", "r", "h", "h2"):
+                setattr(lv, nm, self.be.vec(n_ext))
+        # coarse dense operator: replicated, applied redundantly on the gathered coarse rhs
+        self.coarse_Mt = None
+        nc = levels[-1]["A"].shape[0]
+        self.nc = nc
+        if coarse_dense is not None:
+            Mt = np.ascontiguousarray(np.asarray(coarse_dense, dtype=np.float64).T)
+            self.coarse_Mt = self.be.vec(nc * nc)
+            self.be.from_host(self.coarse_Mt, Mt.ravel())
+            self.coarse_full_b = self.be.vec(nc)
+            self.coarse_full_x = self.be.vec(nc)
+        self.nnz_coarse = int(levels[-1]["A"].nnz)
+        self.acc = self.be.vec(1)
+
+    # ------------------------------------------------------------------ communication
+    def exchange(self, l, v):
+        """refresh the halo part of v (a V_l vector) from its owners"""
+        lv = self.lv[l]
+        if self.world == 1 or not lv.comm:
+            return
+        if lv.n_send:
+            self.be.gather(lv.sendbuf, v, lv.send_idx, lv.n_send)
+        self.dist.all_to_all_single(v[lv.n_own:lv.n_own + lv.n_halo], lv.sendbuf[:lv.n_send],
+                                    lv.recv_counts, lv.send_counts, group=self.group)
+
+    def global_norm(self, v, n):
+        self.be.sumsq(v, n, self.acc)
+        if self.world > 1:
+            self.dist.all_reduce(self.acc, group=self.group)
+        return float(np.sqrt(self.be.to_host(self.acc, 1)[0]))
+
+    # ------------------------------------------------------------------ smoothers (relaxation.py)
+    def relax(self, l, s, xname, bvec, x_zero):
+        lv = self.lv[l]
+        if s is None or s.get("name") is None:
+            return
+        n = lv.n_own
+        it = int(s.get("iterations", 1))
+        if s["name"] == "jacobi":
+            for _ in range(it):
+                x, xalt = getattr(lv, xname), lv.xalt
+                self.exchange(l, x)
+                self.be.apply(lv.A, JACOBI_BSR1 if lv.A_bsr else JACOBI, x, bvec, x, xalt, None, s["omega"])
+                setattr(lv, xname, xalt)
+                lv.xalt = x
+            return
+        co = s["coefficients"]
+        for _ in range(it):
+            x = getattr(lv, xname)
+            hh, hn = lv.h, lv.h2
+            if x_zero:
+                rvec = bvec
+                self.be.scale(hh, bvec, co[0], n)
+            else:
+                self.exchange(l, x)
+                self.be.apply(lv.A, POLY_FIRST, x, bvec, None, lv.r, hh, co[0])
+                rvec = lv.r
+            if len(co) == 1:
+                self.be.axpy(x, hh, n)
+            else:
+                for c in co[1:-1]:
+                    self.exchange(l, hh)
+                    self.be.apply(lv.A, POLY_STEP, hh, rvec, None, hn, None, c)
+                    hh, hn = hn, hh
+                self.exchange(l, hh)
+                self.be.apply(lv.A, POLY_LAST, hh, rvec, x, x, None, co[-1])
+            x_zero = False
+
+    def coarse_solve(self):
+        lv = self.lv[-1]
+        if self.nnz_coarse == 0 or self.coarse_Mt is None:
+            self.be.zero(lv.x, lv.n_own)
+            return
+        nc = self.nc
+        if self.world > 1:
+            counts = [int(self.bounds[-1][p + 1] - self.bounds[-1][p]) for p in range(self.world)]
+            self._all_gather_uneven(lv.b[:lv.n_own], counts)
+        else:
+            self.coarse_full_b[:nc].copy_(lv.b[:nc])
+        self.be.dense(self.coarse_Mt, self.coarse_full_b, self.coarse_full_x, nc)
+        lo = int(self.bounds[-1][self.rank])
+        lv.x[:lv.n_own].copy_(self.coarse_full_x[lo:lo + lv.n_own])
+
+    def _all_gather_uneven(self, mine, counts):
+        # all_to_all with every rank sending its whole slice to everybody
+        W = self.world
+        inp = mine.repeat(W) if mine.numel() else mine
+        out = self.coarse_full_b[:self.nc]
+        self.dist.all_to_all_single(out, inp, counts, [int(mine.numel())] * W, group=self.group)
+
+    # ------------------------------------------------------------------ cycle (multilevel.py:473-548)
+    def cycle(self, l, cyc, x_zero):
+        lv, nx = self.lv[l], self.lv[l + 1]
+        self.relax(l, lv.pre, "x", lv.b, x_zero)
+        self.exchange(l, lv.x)
+        self.be.apply(lv.A, RESIDUAL, lv.x, lv.b, None, lv.r, None, 0.0)
+        self.exchange(l, lv.r)
+        self.be.apply(lv.R, MATVEC, lv.r, None, None, nx.b, None, 0.0)
+        self.be.zero(nx.x, nx.n_own)
+        if l == self.nlevels - 2:
+            self.coarse_solve()
+        elif cyc == "V":
+            self.cycle(l + 1, "V", True)
+        elif cyc == "W":
+            self.cycle(l + 1, cyc, True)
+            self.cycle(l + 1, cyc, False)
+        elif cyc == "F":
+            self.cycle(l + 1, cyc, True)
+            self.cycle(l + 1, "V", False)
+        else:
+            raise NotImplementedError("AMLI cycles are not implemented on the device path")
+        self.exchange(l + 1, nx.x)
+        self.be.apply(lv.P, MATVEC_ACC, nx.x, None, None, lv.x, None, 0.0)
+        self.relax(l, lv.post, "x", lv.b, False)
+
+    def residual_norm(self):
+        lv = self.lv[0]
+        self.exchange(0, lv.x)
+        self.be.apply(lv.A, RESIDUAL, lv.x, lv.b, None, lv.r, None, 0.0)
+        return self.global_norm(lv.r, lv.n_own)
+
+    def set_problem(self, b_local, x0_local=None):
+        lv = self.lv[0]
+        self.be.from_host(lv.b, b_local)
+        if x0_local is None:
+            self.be.zero(lv.x, lv.n_own)
+        else:
+            self.be.from_host(lv.x, x0_local)
+
+    def iterate(self, cyc, x_zero):
+        if self.nlevels == 1:
+            self.coarse_solve()
+        else:
+            self.cycle(0, cyc, x_zero)
+
+    def solve(self, b_local, x0_local=None, tol=1e-5, maxiter=100, cycle="V", fixed=False):
+        """multilevel.py:316-471 on the local slices; returns (x_local, residuals)"""
+        cycle = str(cycle).upper()
+        self.set_problem(b_local, x0_local)
+        lv = self.lv[0]
+        normb = self.global_norm(lv.b, lv.n_own)
+        if normb != 0:
+            tol = tol * normb
+        res = [self.residual_norm()]
+        x_zero = x0_local is None or not np.any(x0_local)
+        # x0 == 0 must hold on EVERY rank for the static shortcut
+        if self.world > 1:
+            flag = self.torch.tensor([1.0 if x_zero else 0.0], dtype=self.torch.float64)
+            self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN, group=self.host_group)
+            x_zero = bool(flag.item() > 0.5)
+        if fixed:
+            res.extend(self.run_fixed(maxiter, cycle, x_zero))
+        else:
+            while len(res) <= maxiter and res[-1] > tol:
+                self.iterate(cycle, x_zero)
+                x_zero = False
+                res.append(self.residual_norm())
+        return self.be.to_host(self.lv[0].x, lv.n_own), res
+
+    def run_fixed(self, steps, cycle="V", x_zero=False):
+        """exactly `steps` iterations (cycle + residual norm) with no host synchronisation inside:
+        the squared norms are all-reduced into a device history and read once at the end"""
+        lv = self.lv[0]
+        hist = self.be.vec(steps)
+        for k in range(steps):
+            self.iterate(cycle, x_zero)
+            x_zero = False
+            self.exchange(0, lv.x)
+            self.be.apply(lv.A, RESIDUAL, lv.x, lv.b, None, lv.r, None, 0.0)
+            self.be.sumsq(lv.r, lv.n_own, hist[k:k + 1])
+        if self.world > 1 and steps:
+            self.dist.all_reduce(hist[:steps], group=self.group)
+        return [float(v) for v in np.sqrt(self.be.to_host(hist, steps))]
+
+
+def levels_from_ml(ml):
+    """global level dicts (+ dense coarse operator) from a pyamg_amd.multilevel_solver"""
+    levels = []
+    for lvl in ml.levels:
+        L = {"A": lvl.A}
+        if hasattr(lvl, "P"):
+            L["P"], L["R"] = lvl.P, lvl.R
+            for side, fn in (("pre", getattr(lvl, "presmoother", None)), ("post", getattr(lvl, "postsmoother", None))):
+                d = getattr(fn, "desc", None)
+                if fn is not None and d is None:
+                    raise NotImplementedError("smoother without a device descriptor")
+                L[side] = dict(d) if d is not None else None
+        levels.append(L)
+    kind, M = ml.coarse_solver.device_form(ml.levels[-1].A)
+    if kind not in ("dense", "none"):
+        raise NotImplementedError("partitioned path: dense coarse solvers only")
+    return levels, (M if kind == "dense" else None)
+
+
+# --------------------------------------------------------------------------- shipping a hierarchy between ranks
+def save_levels(path, levels, coarse):
+    """rank 0 -> shared directory (e.g. /dev/shm/...): flat .npy files the other ranks memory-map"""
+    import json
+    import os
+    os.makedirs(path, exist_ok=True)
+    meta = {"nlevels": len(levels), "levels": []}
+    for l, L in enumerate(levels):
+        m = {}
+        for nm in ("A", "P", "R"):
+            if nm in L:
+                Ap, Aj, Ax, isb = _csr_view(L[nm])
+                np.save(os.path.join(path, "%s%d_p.npy" % (nm, l)), np.asarray(Ap))
+                np.save(os.path.join(path, "%s%d_j.npy" % (nm, l)), np.asarray(Aj))
+                np.save(os.path.join(path, "%s%d_x.npy" % (nm, l)), np.asarray(Ax))
+                m[nm] = {"shape": list(L[nm].shape), "bsr": bool(isb)}
+        for side in ("pre", "post"):
+            if side in L:
+                d = L[side]
+                m[side] = None if d is None else {k: (v if not isinstance(v, np.ndarray) else v.tolist())
+                                                  for k, v in d.items()}
+        meta["levels"].append(m)
+    if coarse is not None:
+        np.save(os.path.join(path, "coarse.npy"), np.asarray(coarse))
+    meta["coarse"] = coarse is not None
+    with open(os.path.join(path, "meta.json"), "w") as f:
+        json.dump(meta, f)
+
+
+def load_levels(path):
+    import json
+    import os
+    meta = json.load(open(os.path.join(path, "meta.json")))
+    levels = []
+    for l, m in enumerate(meta["levels"]):
+        L = {}
+        for nm in ("A", "P", "R"):
+            if nm in m:
+                Ap = np.load(os.path.join(path, "%s%d_p.npy" % (nm, l)), mmap_mode="r")
+                Aj = np.load(os.path.join(path, "%s%d_j.npy" % (nm, l)), mmap_mode="r")
+                Ax = np.load(os.path.join(path, "%s%d_x.npy" % (nm, l)), mmap_mode="r")
+                L[nm] = _Lazy(Ap, Aj, Ax, tuple(m[nm]["shape"]), m[nm]["bsr"])
+        for side in ("pre", "post"):
+            if side in m:
+                L[side] = m[side]
+        levels.append(L)
+    coarse = np.load(os.path.join(path, "coarse.npy")) if meta["coarse"] else None
+    return levels, coarse
