@@ -50,6 +50,13 @@ def lib():
         raise ImportError(
             "pyamg_amd: %s is missing -- build it with `make -C pyamg_amd/csrc` "
             "(or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
+    # When PyTorch is present, load it first: torch ships its own libamdhip64 and both libraries
+    # must share ONE HIP runtime in the process (the multi-GPU driver hands torch tensors to the
+    # kernels); loaded in the other order torch finds "No HIP GPUs".
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     L = C.CDLL(LIB_PATH)
     I, D, V = C.c_int, C.c_double, C.c_void_p
     arr = [c_int_p, I, c_int_p, I, c_dbl_p, I]          # Ap, Aj, Ax with sizes
