@@ -34,6 +34,9 @@ template <class T> static int dev_alloc(T **p, long count, long *acct)
     size_t bytes = sizeof(T) * (size_t)(count + PAD);
     AMG_HIP(hipMalloc((void **)p, bytes));
     AMG_HIP(hipMemset(*p, 0, bytes));
+    // the fill runs on the NULL stream and is asynchronous to the host; the hierarchy's stream is
+    // non-blocking, so without this wait a later copy/kernel on it could be overtaken by the fill
+    AMG_HIP(hipDeviceSynchronize());
     if (acct) *acct += (long)bytes;
     return 0;
 }
