@@ -236,6 +236,10 @@ int amg_arnoldi(amg_hier *h, int lvl, const double *dinv, const double *v0, int 
 int amg_arnoldi_combine(amg_hier *h, const double *coef, int m, double *v);
 void amg_arnoldi_free(amg_hier *h);
 
+/* replay each iteration (cycle + residual norm) from a hipGraph once its launch sequence has
+ * been seen (default on; env AMG_HIP_GRAPHS=0 disables).  Speed only: same kernels, same order. */
+void amg_hier_use_graphs(amg_hier *h, int on);
+
 /* tuning knobs (speed only): 0 = scalar loads, 1 = 16-byte loads in the CSR stream kernel;
  * XCD chunk: consecutive row blocks given to one XCD (0 = round-robin dispatch order) */
 void amg_set_stream_variant(int v);

@@ -130,6 +130,8 @@ def lib():
     L.amg_arnoldi_free.restype = None
     L.amg_set_stream_variant.argtypes = [I]
     L.amg_set_stream_variant.restype = None
+    L.amg_hier_use_graphs.argtypes = [V, I]
+    L.amg_hier_use_graphs.restype = None
     L.amg_set_tile_target.argtypes = [I]
     L.amg_set_tile_target.restype = None
     L.amg_set_xcd_chunk.argtypes = [I]

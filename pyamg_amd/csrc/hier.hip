@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace amg {
@@ -444,6 +445,83 @@ static int residual_norm_to(amg_hier *h, double *slot)
     return launch_norm2(L0.r, L0.A.nrows, h->norm_scratch, slot, h->stream);
 }
 
+// One solve() iteration = cycle + residual norm into `slot`, replayed from a hipGraph once the
+// same buffer state has been seen before (the first occurrence runs eagerly, the second is
+// captured, later ones are replays).  Everything inside is kernel / memset / D2D-copy nodes on
+// h->stream; no host synchronisation.
+static std::vector<double *> buffer_state(amg_hier *h)
+{
+    std::vector<double *> s;
+    for (auto &L : h->lv) { s.push_back(L.x); s.push_back(L.xalt); }
+    return s;
+}
+
+static int iteration_with_norm(amg_hier *h, int cyc, bool x_zero, double *slot)
+{
+    CHK(one_iteration(h, cyc, x_zero));
+    return residual_norm_to(h, slot);
+}
+
+static int graph_iteration(amg_hier *h, int cyc, bool x_zero, double *dst)
+{
+    hipStream_t st = h->stream;
+    double *slot = h->norm_scratch + 1028;
+    if (!h->use_graphs) return iteration_with_norm(h, cyc, x_zero, dst);
+    std::vector<double *> state = buffer_state(h);
+    GraphEntry *ge = nullptr;
+    for (auto &g : h->graphs)
+        if (g.cyc == cyc && g.x_zero == x_zero && g.state_in == state) { ge = &g; break; }
+    if (!ge) {
+        h->graphs.emplace_back();
+        ge = &h->graphs.back();
+        ge->cyc = cyc; ge->x_zero = x_zero; ge->state_in = state;
+    }
+    if (!ge->exec && ge->seen < 1) {           // first encounter: eager
+        ge->seen++;
+        return iteration_with_norm(h, cyc, x_zero, dst);
+    }
+    if (!ge->exec) {                            // second encounter: capture
+        hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+        if (e != hipSuccess) { h->use_graphs = 0; return iteration_with_norm(h, cyc, x_zero, dst); }
+        int rc = iteration_with_norm(h, cyc, x_zero, slot);
+        hipGraph_t graph = nullptr;
+        e = hipStreamEndCapture(st, &graph);
+        if (rc != 0 || e != hipSuccess || !graph) {
+            // capture failed: the pointer swaps already happened but nothing ran -> restore and go eager
+            if (graph) hipGraphDestroy(graph);
+            for (size_t l = 0; l < h->lv.size(); ++l) { h->lv[l].x = state[2 * l]; h->lv[l].xalt = state[2 * l + 1]; }
+            h->use_graphs = 0;
+            (void)hipGetLastError();
+            return iteration_with_norm(h, cyc, x_zero, dst);
+        }
+        hipGraphExec_t exec = nullptr;
+        e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        if (e != hipSuccess) {
+            hipGraphDestroy(graph);
+            for (size_t l = 0; l < h->lv.size(); ++l) { h->lv[l].x = state[2 * l]; h->lv[l].xalt = state[2 * l + 1]; }
+            h->use_graphs = 0;
+            (void)hipGetLastError();
+            return iteration_with_norm(h, cyc, x_zero, dst);
+        }
+        ge->graph = graph; ge->exec = exec;
+        ge->state_out = buffer_state(h);
+    } else {
+        for (size_t l = 0; l < h->lv.size(); ++l) { h->lv[l].x = ge->state_out[2 * l]; h->lv[l].xalt = ge->state_out[2 * l + 1]; }
+    }
+    AMG_HIP(hipGraphLaunch(ge->exec, st));
+    AMG_HIP(hipMemcpyAsync(dst, slot, sizeof(double), hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+static void drop_graphs(amg_hier *h)
+{
+    for (auto &g : h->graphs) {
+        if (g.exec) hipGraphExecDestroy(g.exec);
+        if (g.graph) hipGraphDestroy(g.graph);
+    }
+    h->graphs.clear();
+}
+
 // ------------------------------------------------------------------ C API
 extern "C" {
 
@@ -502,6 +580,7 @@ void amg_hier_destroy(amg_hier *h)
     if (!h) return;
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
+    drop_graphs(h);
     for (auto &L : h->lv) {
         free_smoother(L.sm[0]);
         free_smoother(L.sm[1]);
@@ -731,6 +810,11 @@ int amg_hier_finalize(amg_hier *h)
         return AMG_EINVAL;
     }
     if (!h->norm_scratch) CHK(dev_alloc(&h->norm_scratch, 1024 + 8, &h->dev_bytes));
+    drop_graphs(h);
+    {
+        const char *env = getenv("AMG_HIP_GRAPHS");
+        if (env) h->use_graphs = atoi(env);
+    }
     h->finalized = true;
     return 0;
 }
@@ -791,9 +875,8 @@ int amg_hier_solve(amg_hier *h, const double *b, double *x, double tol, int maxi
     const bool fixed = (flags & AMG_SOLVE_NO_EARLY_STOP) != 0;
     AMG_HIP(hipEventRecord(h->ev0, st));
     while (k <= maxiter && (fixed || residuals[k - 1] > tol)) {                   // :454
-        CHK(one_iteration(h, cyc, x_zero));
+        CHK(graph_iteration(h, cyc, x_zero, h->res_dev + k));                     // :459-461
         x_zero = false;
-        CHK(residual_norm_to(h, h->res_dev + k));                                 // :461
         if (!fixed) {
             AMG_HIP(hipMemcpyAsync(&residuals[k], h->res_dev + k, sizeof(double), hipMemcpyDeviceToHost, st));
             AMG_HIP(hipStreamSynchronize(st));
@@ -1039,5 +1122,6 @@ void amg_arnoldi_free(amg_hier *h)
 void amg_set_stream_variant(int v) { amg::set_stream_variant(v); }
 void amg_set_xcd_chunk(int c) { amg::set_xcd_chunk(c); }
 void amg_set_tile_target(int t) { amg::set_tile_target(t); }
+void amg_hier_use_graphs(amg_hier *h, int on) { if (h) { h->use_graphs = on; if (!on) drop_graphs(h); } }
 
 }  // extern "C"

@@ -61,6 +61,19 @@ struct Level {
 
 }  // namespace amg
 
+namespace amg {
+// One captured iteration (cycle + residual norm) for a given buffer state: Jacobi-type smoothers
+// swap x/xalt as they go, so the launch sequence depends on which buffer each level's x lives in.
+struct GraphEntry {
+    std::vector<double *> state_in, state_out;   // (x, xalt) of every level before / after
+    int cyc = 0;
+    bool x_zero = false;
+    int seen = 0;                                // times this state was run eagerly
+    hipGraphExec_t exec = nullptr;
+    hipGraph_t graph = nullptr;
+};
+}  // namespace amg
+
 struct amg_hier {
     int device = 0;
     int nlevels = 0;
@@ -82,6 +95,9 @@ struct amg_hier {
     double *arn_coef = nullptr;
     int arn_m = 0;
     long arn_n = 0;
+    // hipGraph replay of the iteration (launch-bound hierarchies: small levels, level-scheduled GS)
+    std::vector<amg::GraphEntry> graphs;
+    int use_graphs = 1;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double last_ms = 0.0;
     long dev_bytes = 0;
