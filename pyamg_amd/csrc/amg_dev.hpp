@@ -81,12 +81,6 @@ void set_xcd_chunk(int c);
 void set_tile_target(int t);
 int rows_per_wg_for(long nnz, long rows);
 
-// a run of small (<= GS_CHAIN_MAX rows) Gauss-Seidel levels in ONE single-workgroup launch
-constexpr int GS_CHAIN_MAX = 1024;
-int launch_gs_chain(bool bsr1, const int *Ap, const int *Aj, const double *Ax, const int *rowmap,
-                    const int *diagpos, const int *level_ptr_dev, int lbeg, int lend, int step, double *x,
-                    const double *b, hipStream_t st);
-
 // thread-per-row fallbacks for non-unit strides / index lists (exact same arithmetic)
 int launch_jacobi_rows(const DevCsr &A, const double *temp, const double *b, double *x,
                        int row_start, int count, int row_step, double omega, hipStream_t st);

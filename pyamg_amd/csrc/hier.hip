@@ -122,8 +122,7 @@ void Schedule::release()
     if (rowmap) hipFree(rowmap);
     if (diagpos) hipFree(diagpos);
     if (rows) hipFree(rows);
-    if (level_ptr_dev) hipFree(level_ptr_dev);
-    rowmap = diagpos = rows = level_ptr_dev = nullptr;
+    rowmap = diagpos = rows = nullptr;
 }
 
 int build_levels(int n, const int *Ap, const int *Aj, const int *tasks, int ntasks,
@@ -197,8 +196,6 @@ int build_csr_schedule(const int *Ap, const int *Aj, const double *Ax, int n, co
     CHK(dev_alloc(&S.diagpos, ntasks, (long *)nullptr));
     AMG_HIP(hipMemcpy(S.rowmap, rowmap.data(), sizeof(int) * (size_t)ntasks, hipMemcpyHostToDevice));
     AMG_HIP(hipMemcpy(S.diagpos, dpos.data(), sizeof(int) * (size_t)ntasks, hipMemcpyHostToDevice));
-    CHK(dev_alloc(&S.level_ptr_dev, (long)S.level_ptr.size(), (long *)nullptr));
-    AMG_HIP(hipMemcpy(S.level_ptr_dev, S.level_ptr.data(), sizeof(int) * S.level_ptr.size(), hipMemcpyHostToDevice));
     return 0;
 }
 
@@ -236,31 +233,18 @@ int spmv(const DevCsr &M, StreamMode mode, const double *xg, const double *b, co
     return launch_stream(mode, a, st);
 }
 
-// one directional sweep of a scheduled (CSR flavour) Gauss-Seidel: big levels go through the
-// stream kernel one launch each, runs of small levels through one chained single-workgroup launch
-int gs_sweep_csr(const Schedule &S, bool bsr1, double *x, const double *b, bool reverse, hipStream_t st)
+// one directional sweep of a scheduled (CSR flavour) Gauss-Seidel
+static int gs_sweep_csr(const Schedule &S, bool bsr1, double *x, const double *b, bool reverse,
+                        hipStream_t st)
 {
     StreamArgs a = base_args(S.G);
     a.xg = x; a.b = b; a.out = x; a.rowmap = S.rowmap; a.diagpos = S.diagpos;
-    const int nl = S.nlevels();
-    const int step = reverse ? -1 : 1;
-    auto small = [&](int l) { return S.level_ptr[l + 1] - S.level_ptr[l] <= GS_CHAIN_MAX; };
-    int l = reverse ? nl - 1 : 0;
-    const int lend = reverse ? -1 : nl;
-    while (l != lend) {
-        if (S.level_ptr_dev && small(l)) {
-            int m = l;
-            while (m != lend && small(m)) m += step;
-            if (m - l != step) {             // at least two levels: chain them
-                CHK(launch_gs_chain(bsr1, S.G.Ap, S.G.Aj, S.G.Ax, S.rowmap, S.diagpos, S.level_ptr_dev, l, m, step, x, b, st));
-                l = m;
-                continue;
-            }
-        }
+    int nl = S.nlevels();
+    for (int q = 0; q < nl; ++q) {
+        int l = reverse ? nl - 1 - q : q;
         a.row_lo = S.level_ptr[l];
         a.row_hi = S.level_ptr[l + 1];
         CHK(launch_stream(bsr1 ? SM_GS_BSR1 : SM_GS, a, st));
-        l += step;
     }
     return 0;
 }

@@ -23,7 +23,6 @@ struct Schedule {
     int *diagpos = nullptr;       // device: position of the diagonal entry in G (-1 if none)
     // BSR flavour: block rows listed in level order
     int *rows = nullptr;          // device
-    int *level_ptr_dev = nullptr; // device copy of level_ptr (chained small levels)
     int nlevels() const { return (int)level_ptr.size() - 1; }
     void release();
 };

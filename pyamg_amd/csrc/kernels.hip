@@ -285,58 +285,6 @@ int launch_stream(StreamMode mode, const StreamArgs &a, hipStream_t st)
 }
 
 // ---------------------------------------------------------------------------
-// Gauss-Seidel: a CHAIN of small dependency levels in one launch.  Coarse AMG levels have
-// hundreds of levels of a few dozen rows each; one kernel per level costs ~4-5 us of launch +
-// memory latency.  Here one 1024-thread workgroup walks levels lbeg, lbeg+step, ... (each of at
-// most 1024 rows), one row per thread, with a workgroup barrier between levels (a workgroup
-// lives on one CU: the barrier's workgroup-scope release/acquire makes the x it just wrote
-// visible to its other waves).  Same per-row arithmetic as the stream kernel's GS modes.
-// ---------------------------------------------------------------------------
-constexpr int CHAIN_THREADS = 1024;
-
-template <bool SUB>
-__global__ __launch_bounds__(CHAIN_THREADS) void gs_chain_kernel(const int *Ap, const int *Aj, const double *Ax,
-                                                                const int *rowmap, const int *diagpos,
-                                                                const int *level_ptr, int lbeg, int lend, int step,
-                                                                double *x, const double *b)
-{
-    for (int l = lbeg; l != lend; l += step) {
-        const int r0 = level_ptr[l], r1 = level_ptr[l + 1];
-        const int i = r0 + (int)threadIdx.x;
-        if (i < r1) {
-            const int row = rowmap[i];
-            const int dpos = diagpos[i];
-            const int s = Ap[i], e = Ap[i + 1];
-            double acc = SUB ? b[row] : 0.0;
-            for (int k = s; k < e; ++k) {
-                if (k == dpos) continue;
-                double p = Ax[k] * x[Aj[k]];
-                acc = SUB ? (acc - p) : (acc + p);
-            }
-            const double d = (dpos >= 0) ? Ax[dpos] : 0.0;
-            if (d != 0.0) x[row] = SUB ? (acc / d) : ((b[row] - acc) / d);
-        }
-        __syncthreads();
-    }
-}
-
-int launch_gs_chain(bool bsr1, const int *Ap, const int *Aj, const double *Ax, const int *rowmap,
-                    const int *diagpos, const int *level_ptr_dev, int lbeg, int lend, int step, double *x,
-                    const double *b, hipStream_t st)
-{
-    if (lbeg == lend) return 0;
-    if (bsr1)
-        hipLaunchKernelGGL(gs_chain_kernel<true>, dim3(1), dim3(CHAIN_THREADS), 0, st, Ap, Aj, Ax, rowmap, diagpos,
-                           level_ptr_dev, lbeg, lend, step, x, b);
-    else
-        hipLaunchKernelGGL(gs_chain_kernel<false>, dim3(1), dim3(CHAIN_THREADS), 0, st, Ap, Aj, Ax, rowmap, diagpos,
-                           level_ptr_dev, lbeg, lend, step, x, b);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return hip_fail(e, "gs_chain launch", __FILE__, __LINE__);
-    return 0;
-}
-
-// ---------------------------------------------------------------------------
 // thread-per-row Jacobi for strided row ranges (amg_core.jacobi with a
 // row_step other than +-1): same arithmetic, rows are independent.
 // ---------------------------------------------------------------------------
