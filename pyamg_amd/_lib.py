@@ -87,6 +87,8 @@ def lib():
         "amg_hier_matvec": [V, I, I, c_dbl_p, c_dbl_p],
         "amg_hier_time_spmv": [V, I, I, I, I, c_dbl_p],
         "amg_mat_apply": [V, I, V, V, V, V, V, D, V],
+        "amg_mat_build_gs": [V, c_int_p, I],
+        "amg_mat_gs_sweep": [V, V, V, I, I, V],
         "amg_dev_scale": [V, V, D, C.c_long, V],
         "amg_dev_axpy": [V, V, C.c_long, V],
         "amg_dev_norm2": [V, C.c_long, V, V, V],
@@ -124,6 +126,8 @@ def lib():
     L.amg_mat_create.restype = V
     L.amg_mat_destroy.argtypes = [V]
     L.amg_mat_destroy.restype = None
+    L.amg_mat_gs_levels.argtypes = [V]
+    L.amg_mat_gs_levels.restype = I
     L.amg_mat_nnz.argtypes = [V]
     L.amg_mat_nnz.restype = C.c_long
     L.amg_arnoldi_free.argtypes = [V]

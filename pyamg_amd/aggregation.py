@@ -66,6 +66,8 @@ def host_lib():
         L.amgsetup_smooth_prolongator.argtypes = [C.c_int, C.c_int, lp, ip, dp, dp, C.c_double, lp, ip, dp,
                                                   lp, ip, dp]
         L.amgsetup_smooth_prolongator.restype = C.c_int64
+        L.amgsetup_greedy_coloring.argtypes = [C.c_int, ip, ip, ip]
+        L.amgsetup_greedy_coloring.restype = C.c_int
         L.amgsetup_num_threads.restype = C.c_int
         _host = L
     return _host
@@ -81,6 +83,20 @@ def _lp(a):
 
 def _dp(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def greedy_colouring(A):
+    """colour of every row of the (symmetrised) pattern of A, first-fit in natural order"""
+    M = A if (isspmatrix_csr(A) or isspmatrix_bsr(A)) else csr_matrix(A)
+    if isspmatrix_bsr(M) and M.blocksize != (1, 1):
+        M = M.tocsr()
+    S = csr_matrix((np.ones(len(M.indices), dtype=np.int8), M.indices, M.indptr), shape=M.shape)
+    S = (S + S.T).tocsr()                     # a colouring must respect both a_ij and a_ji
+    Ap = np.ascontiguousarray(S.indptr, dtype=np.intc)
+    Aj = np.ascontiguousarray(S.indices, dtype=np.intc)
+    colour = np.empty(S.shape[0], dtype=np.intc)
+    ncol = host_lib().amgsetup_greedy_coloring(S.shape[0], _ip(Ap), _ip(Aj), _ip(colour))
+    return colour, ncol
 
 
 def unpack_arg(v):

@@ -8,6 +8,7 @@
 
 namespace amg {
 int upload_csr(DevCsr &M, int nrows, int ncols, const int *Ap, const int *Aj, const double *Ax, long *acct);
+int gs_sweep_csr(const Schedule &S, bool bsr1, double *x, const double *b, bool reverse, hipStream_t st);
 }
 using namespace amg;
 
@@ -21,6 +22,7 @@ struct amg_mat {
     int device = 0;
     DevCsr M;
     int rpw = 256;
+    Schedule *sched = nullptr;     // Gauss-Seidel over the local rows (amg_mat_build_gs)
 };
 
 __global__ void gather_kernel(double *out, const double *in, const int *idx, long n)
@@ -54,7 +56,41 @@ void amg_mat_destroy(amg_mat *m)
     if (m->M.Ap) hipFree(m->M.Ap);
     if (m->M.Aj) hipFree(m->M.Aj);
     if (m->M.Ax) hipFree(m->M.Ax);
+    if (m->sched) { m->sched->release(); delete m->sched; }
     delete m;
+}
+
+// Dependency-level schedule for Gauss-Seidel over this operator's rows in the given order
+// (order == NULL: rows 0..nrows-1).  Columns >= nrows (the halo of a partitioned operator) are
+// operands that no local row writes: they stay frozen during the sweep -- "GS inside the rank,
+// Jacobi across ranks" (configuration C4).
+int amg_mat_build_gs(amg_mat *m, const int *order, int norder)
+{
+    if (!m) { set_error("null matrix"); return AMG_EINVAL; }
+    AMG_HIP(hipSetDevice(m->device));
+    const int n = m->M.nrows;
+    std::vector<int> ap((size_t)n + 1), aj((size_t)m->M.nnz);
+    std::vector<double> ax((size_t)m->M.nnz);
+    AMG_HIP(hipMemcpy(ap.data(), m->M.Ap, sizeof(int) * ap.size(), hipMemcpyDeviceToHost));
+    if (m->M.nnz) {
+        AMG_HIP(hipMemcpy(aj.data(), m->M.Aj, sizeof(int) * aj.size(), hipMemcpyDeviceToHost));
+        AMG_HIP(hipMemcpy(ax.data(), m->M.Ax, sizeof(double) * ax.size(), hipMemcpyDeviceToHost));
+    }
+    if (m->sched) { m->sched->release(); delete m->sched; m->sched = nullptr; }
+    m->sched = new Schedule();
+    int rc = build_csr_schedule(ap.data(), aj.data(), ax.data(), n, order, order ? norder : n, *m->sched, nullptr);
+    if (rc != 0) { m->sched->release(); delete m->sched; m->sched = nullptr; }
+    return rc;
+}
+
+int amg_mat_gs_levels(amg_mat *m) { return (m && m->sched) ? m->sched->nlevels() : 0; }
+
+// one directional sweep (reverse != 0: the reversed order); bsr1 selects bsr_gauss_seidel's rounding
+int amg_mat_gs_sweep(amg_mat *m, double *x, const double *b, int reverse, int bsr1, void *stream)
+{
+    if (!m || !m->sched) { set_error("amg_mat_build_gs was not called"); return AMG_ESTATE; }
+    AMG_HIP(hipSetDevice(m->device));
+    return gs_sweep_csr(*m->sched, bsr1 != 0, x, b, reverse != 0, (hipStream_t)stream);
 }
 
 long amg_mat_nnz(amg_mat *m) { return m ? m->M.nnz : 0; }

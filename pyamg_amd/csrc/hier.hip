@@ -234,8 +234,8 @@ int spmv(const DevCsr &M, StreamMode mode, const double *xg, const double *b, co
 }
 
 // one directional sweep of a scheduled (CSR flavour) Gauss-Seidel
-static int gs_sweep_csr(const Schedule &S, bool bsr1, double *x, const double *b, bool reverse,
-                        hipStream_t st)
+int gs_sweep_csr(const Schedule &S, bool bsr1, double *x, const double *b, bool reverse,
+                 hipStream_t st)
 {
     StreamArgs a = base_args(S.G);
     a.xg = x; a.b = b; a.out = x; a.rowmap = S.rowmap; a.diagpos = S.diagpos;

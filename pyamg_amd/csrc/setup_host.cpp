@@ -356,6 +356,30 @@ int64_t amgsetup_smooth_prolongator(int n, int n_agg, const int64_t *Sp, const i
     return Pp[n];
 }
 
+// Greedy (first-fit) vertex colouring in natural order: colour[i] = smallest colour not used by
+// an already coloured neighbour.  Rows of one colour are mutually independent, so a Gauss-Seidel
+// sweep ordered colour by colour (an index list for gauss_seidel_indexed,
+// pyamg/relaxation/relaxation.py:671-741) has as many dependency levels as colours.
+// Returns the number of colours.
+int amgsetup_greedy_coloring(int n, const int *Ap, const int *Aj, int *colour)
+{
+    std::vector<int> mark;
+    int ncol = 0;
+    for (int i = 0; i < n; i++) colour[i] = -1;
+    for (int i = 0; i < n; i++) {
+        if ((int)mark.size() < ncol + 1) mark.resize((size_t)ncol + 1, -1);
+        for (int jj = Ap[i]; jj < Ap[i + 1]; jj++) {
+            int j = Aj[jj];
+            if (j != i && j >= 0 && j < n && colour[j] >= 0) mark[colour[j]] = i;
+        }
+        int c = 0;
+        while (c < ncol && mark[c] == i) c++;
+        colour[i] = c;
+        if (c == ncol) { ncol++; mark.resize((size_t)ncol + 1, -1); }
+    }
+    return ncol;
+}
+
 int amgsetup_num_threads(void)
 {
 #ifdef _OPENMP

@@ -126,6 +126,16 @@ class HipBackend(object):
     def gather(self, out, inp, idx, n):
         self._lib.check(self.L.amg_dev_gather(out.data_ptr(), inp.data_ptr(), idx.data_ptr(), int(n), self.stream()))
 
+    def build_gs(self, m, order):
+        if order is None:
+            self._lib.check(self.L.amg_mat_build_gs(m, None, 0))
+        else:
+            o = np.ascontiguousarray(order, dtype=np.intc)
+            self._lib.check(self.L.amg_mat_build_gs(m, self._lib.ip(o), len(o)))
+
+    def gs_sweep(self, m, x, b, reverse, bsr1):
+        self._lib.check(self.L.amg_mat_gs_sweep(m, x.data_ptr(), b.data_ptr(), int(reverse), int(bsr1), self.stream()))
+
     def sumsq(self, x, n, out):
         """out[0] = sum of squares of x[:n] (device tensor of 1 double)"""
         self._lib.check(self.L.amg_dev_dot(x.data_ptr(), x.data_ptr(), int(n), self.scratch.data_ptr(),
@@ -263,10 +273,22 @@ class DistributedSolver(object):
                 lv.R = self.be.mat(nxt.n_own, n_ext, Rp, renum(Rj, l), Rx)
                 lv.pre, lv.post = L.get("pre"), L.get("post")
                 for s in (lv.pre, lv.post):
-                    if s is not None and s.get("name") not in (None, "jacobi", "polynomial"):
+                    nm = None if s is None else s.get("name")
+                    if nm not in (None, "jacobi", "polynomial", "gauss_seidel", "gauss_seidel_indexed"):
                         raise NotImplementedError(
-                            "smoother %r is sequential across ranks; the partitioned path offers jacobi / "
-                            "polynomial (chebyshev, richardson) / None" % (s.get("name"),))
+                            "smoother %r has no partitioned form; offered: jacobi / polynomial (chebyshev, "
+                            "richardson) / gauss_seidel and gauss_seidel_indexed as HYBRID sweeps (Gauss-Seidel "
+                            "inside a rank, Jacobi across ranks) / None" % (nm,))
+                    if nm in ("gauss_seidel", "gauss_seidel_indexed") and W > 1 and not getattr(self, "allow_hybrid", True):
+                        raise NotImplementedError("hybrid Gauss-Seidel disabled")
+                    if nm == "gauss_seidel_indexed":
+                        idx = np.asarray(s["indices"], dtype=np.int64)
+                        lo_, hi_ = own[l]
+                        s["_local_order"] = (idx[(idx >= lo_) & (idx < hi_)] - lo_).astype(np.intc)
+                        self.be.build_gs(lv.A, s["_local_order"])
+                    elif nm == "gauss_seidel" and not getattr(lv, "_gs_natural", False):
+                        self.be.build_gs(lv.A, None)
+                        lv._gs_natural = True
             for nm in ("x", "xalt", "b", "r", "h", "h2"):
                 setattr(lv, nm, self.be.vec(n_ext))
         # coarse dense operator: replicated, applied redundantly on the gathered coarse rhs
@@ -306,6 +328,19 @@ class DistributedSolver(object):
             return
         n = lv.n_own
         it = int(s.get("iterations", 1))
+        if s["name"] in ("gauss_seidel", "gauss_seidel_indexed"):
+            # hybrid sweep: halo refreshed once per directional sweep and frozen during it
+            x = getattr(lv, xname)
+            bsr1 = lv.A_bsr and s["name"] == "gauss_seidel"
+            sweep = s.get("sweep", "forward")
+            for _ in range(it):
+                if sweep in ("forward", "symmetric"):
+                    self.exchange(l, x)
+                    self.be.gs_sweep(lv.A, x, bvec, False, bsr1)
+                if sweep in ("backward", "symmetric"):
+                    self.exchange(l, x)
+                    self.be.gs_sweep(lv.A, x, bvec, True, bsr1)
+            return
         if s["name"] == "jacobi":
             for _ in range(it):
                 x, xalt = getattr(lv, xname), lv.xalt

@@ -65,6 +65,27 @@ class OracleBackend(object):
         else:
             raise ValueError(mode)
 
+    def build_gs(self, m, order):
+        self._gs_order = getattr(self, "_gs_order", {})
+        self._gs_order[id(m)] = None if order is None else np.ascontiguousarray(order, dtype=np.intc)
+
+    def gs_sweep(self, m, x, b, reverse, bsr1):
+        n, nc, Ap, Aj, Ax = m
+        order = self._gs_order[id(m)]
+        xe = np.ascontiguousarray(x.numpy()[:max(nc, 1)]).copy()
+        bb = np.ascontiguousarray(b.numpy()[:max(n, 1)])
+        if order is None:
+            rs, re, rt = (n - 1, -1, -1) if reverse else (0, n, 1)
+            if bsr1:
+                self.lib.oracle_bsr_gauss_seidel(ip(Ap), ip(Aj), dp(Ax), dp(xe), dp(bb), rs, re, rt, 1)
+            else:
+                self.lib.oracle_gauss_seidel(ip(Ap), ip(Aj), dp(Ax), dp(xe), dp(bb), rs, re, rt)
+        else:
+            m_ = len(order)
+            rs, re, rt = (m_ - 1, -1, -1) if reverse else (0, m_, 1)
+            self.lib.oracle_gauss_seidel_indexed(ip(Ap), ip(Aj), dp(Ax), dp(xe), dp(bb), ip(order), rs, re, rt)
+        x[:n] = torch.from_numpy(xe[:n])
+
     def scale(self, out, inp, c, n):
         out[:n] = torch.from_numpy(c * inp.numpy()[:n])
 

@@ -54,3 +54,39 @@ def test_two_ranks_equal_single_gpu(case, tmp_path):
     assert np.allclose(res, res1, rtol=1e-12, atol=1e-13 * res1[0])
     rf = np.load(tmp_path / "res_fixed.npy")
     assert len(rf) == 6 and np.allclose(rf, res1[:6], rtol=1e-12, atol=1e-13 * res1[0])
+
+
+def _worker_hybrid(rank, world, port, case, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pyamg_amd.distributed import DistributedSolver, HipBackend, split_rows
+        g = golden_io.load_hier(case)
+        S = DistributedSolver(g["levels"], g["coarse_pinv"], HipBackend(0), rank, world)
+        n = g["levels"][0]["A"].shape[0]
+        bnd = split_rows(n, world)
+        lo, hi = int(bnd[rank]), int(bnd[rank + 1])
+        x, res = S.solve(g["b"][lo:hi], None, tol=0.0, maxiter=3, cycle="V", fixed=True)
+        np.save(os.path.join(out_dir, "x_%d.npy" % rank), x)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["sa_gs_3d", "rs_gs_2d"])
+def test_hybrid_gauss_seidel_on_gpu_matches_partition_emulation(case, tmp_path):
+    """C4's smoother: GS inside a rank (level-scheduled HIP kernels), Jacobi across ranks; oracle =
+    the partition-emulating CPU run (tests/test_distributed_cpu.py)."""
+    import oracle_lib
+    from pyamg_amd.distributed import split_rows
+    from test_distributed_cpu import _hybrid_cycle
+    world = 2
+    g = golden_io.load_hier(case)
+    mp.spawn(_worker_hybrid, args=(world, _free_port(), case, str(tmp_path)), nprocs=world, join=True)
+    x = np.concatenate([np.load(tmp_path / ("x_%d.npy" % r)) for r in range(world)])
+    lib = oracle_lib.load()
+    bounds = [split_rows(L["A"].shape[0], world) for L in g["levels"]]
+    xe = np.zeros_like(g["b"])
+    for _ in range(3):
+        _hybrid_cycle(lib, g["levels"], g["coarse_pinv"], bounds, 0, xe, np.ascontiguousarray(g["b"]))
+    assert np.array_equal(x, xe), np.abs(x - xe).max()

@@ -262,3 +262,27 @@ def test_norm_matches_numpy():
         out = C.c_double()
         _lib.check(_lib.lib().amgcore_norm2_f64(_lib.dp(v), n, C.byref(out)))
         assert abs(out.value - np.linalg.norm(v)) <= 4e-16 * np.linalg.norm(v) * max(1, np.log2(n))
+
+
+def test_multicolor_gauss_seidel_equals_indexed_oracle():
+    """The fast GS-type smoother: greedy multicolour ordering relaxed with gauss_seidel_indexed
+    semantics (relaxation.py:671-741).  Oracle = reference-kernel restatement with the same index list."""
+    g = golden_io.load_hier("sa_gs_3d")
+    ml = golden_io.build_ml(g)
+    spec = ("multicolor_gauss_seidel", {"sweep": "symmetric"})
+    pyamg_amd.change_smoothers(ml, spec, spec)
+    res = []
+    x = ml.solve(g["b"], tol=1e-10, residuals=res)
+    levels = []
+    for lvl, L in zip(ml.levels, g["levels"]):
+        d = dict(L)
+        if "P" in L:
+            d["pre"] = dict(lvl.presmoother.desc)
+            d["post"] = dict(lvl.postsmoother.desc)
+            assert d["pre"]["name"] == "gauss_seidel_indexed"
+        levels.append(d)
+    assert ml.levels[0].presmoother.ncolours == 2            # 7-point stencil: red-black
+    H = oracle_lib.Hierarchy(levels, g["coarse_pinv"])
+    xo, reso = H.solve(g["b"], tol=1e-10)
+    assert len(res) == len(reso) and len(res) < 30             # it converges like a GS smoother
+    assert np.array_equal(x, xo)
