@@ -356,6 +356,158 @@ int64_t amgsetup_smooth_prolongator(int n, int n_agg, const int64_t *Sp, const i
     return Pp[n];
 }
 
+// ---- classical (Ruge-Stuben) setup, pyamg/amg_core/ruge_stuben.h --------------------------------
+// :46-99 classical strength: keep off-diagonals with |a_ij| >= theta * max_k!=i |a_ik|, and the diagonal
+int amgsetup_classical_strength(int n_row, double theta, const int *Ap, const int *Aj, const double *Ax,
+                                int *Sp, int *Sj, double *Sx)
+{
+    int nnz = 0;
+    Sp[0] = 0;
+    for (int i = 0; i < n_row; i++) {
+        double max_offdiagonal = 2.2250738585072014e-308;   // std::numeric_limits<double>::min()
+        for (int jj = Ap[i]; jj < Ap[i + 1]; jj++)
+            if (Aj[jj] != i) max_offdiagonal = std::max(max_offdiagonal, std::fabs(Ax[jj]));
+        double threshold = theta * max_offdiagonal;
+        for (int jj = Ap[i]; jj < Ap[i + 1]; jj++) {
+            double norm_jj = std::fabs(Ax[jj]);
+            if (norm_jj >= threshold && Aj[jj] != i) { Sj[nnz] = Aj[jj]; Sx[nnz] = Ax[jj]; nnz++; }
+            if (Aj[jj] == i) { Sj[nnz] = Aj[jj]; Sx[nnz] = Ax[jj]; nnz++; }
+        }
+        Sp[i + 1] = nnz;
+    }
+    return nnz;
+}
+
+// :158-310 Ruge-Stuben first-pass C/F splitting (S without diagonal, T = S^T).  F=0, C=1.
+void amgsetup_rs_cf_splitting(int n_nodes, const int *Sp, const int *Sj, const int *Tp, const int *Tj,
+                              int *splitting)
+{
+    const int F_NODE = 0, C_NODE = 1, U_NODE = 2;
+    std::vector<int> lambda((size_t)n_nodes, 0);
+    for (int i = 0; i < n_nodes; i++) lambda[i] = Tp[i + 1] - Tp[i];
+    std::vector<int> interval_ptr((size_t)n_nodes + 1, 0), interval_count((size_t)n_nodes + 1, 0);
+    std::vector<int> index_to_node((size_t)n_nodes), node_to_index((size_t)n_nodes);
+    for (int i = 0; i < n_nodes; i++) interval_count[lambda[i]]++;
+    for (int i = 0, cumsum = 0; i < n_nodes; i++) {
+        interval_ptr[i] = cumsum;
+        cumsum += interval_count[i];
+        interval_count[i] = 0;
+    }
+    for (int i = 0; i < n_nodes; i++) {
+        int lambda_i = lambda[i];
+        int index = interval_ptr[lambda_i] + interval_count[lambda_i];
+        index_to_node[index] = i;
+        node_to_index[i] = index;
+        interval_count[lambda_i]++;
+    }
+    std::fill(splitting, splitting + n_nodes, U_NODE);
+    for (int i = 0; i < n_nodes; i++)
+        if (lambda[i] == 0 || (lambda[i] == 1 && Tj[Tp[i]] == i)) splitting[i] = F_NODE;
+    for (int top_index = n_nodes - 1; top_index != -1; top_index--) {
+        int i = index_to_node[top_index];
+        int lambda_i = lambda[i];
+        interval_count[lambda_i]--;
+        if (splitting[i] == F_NODE) continue;
+        splitting[i] = C_NODE;
+        for (int jj = Tp[i]; jj < Tp[i + 1]; jj++) {
+            int j = Tj[jj];
+            if (splitting[j] == U_NODE) {
+                splitting[j] = F_NODE;
+                for (int kk = Sp[j]; kk < Sp[j + 1]; kk++) {
+                    int k = Sj[kk];
+                    if (splitting[k] == U_NODE) {
+                        if (lambda[k] >= n_nodes - 1) continue;
+                        int lambda_k = lambda[k];
+                        int old_pos = node_to_index[k];
+                        int new_pos = interval_ptr[lambda_k] + interval_count[lambda_k] - 1;
+                        node_to_index[index_to_node[old_pos]] = new_pos;
+                        node_to_index[index_to_node[new_pos]] = old_pos;
+                        std::swap(index_to_node[old_pos], index_to_node[new_pos]);
+                        interval_count[lambda_k] -= 1;
+                        interval_count[lambda_k + 1] += 1;
+                        interval_ptr[lambda_k + 1] = new_pos;
+                        lambda[k]++;
+                    }
+                }
+            }
+        }
+        for (int jj = Sp[i]; jj < Sp[i + 1]; jj++) {
+            int j = Sj[jj];
+            if (splitting[j] == U_NODE) {
+                if (lambda[j] == 0) continue;
+                int lambda_j = lambda[j];
+                int old_pos = node_to_index[j];
+                int new_pos = interval_ptr[lambda_j];
+                node_to_index[index_to_node[old_pos]] = new_pos;
+                node_to_index[index_to_node[new_pos]] = old_pos;
+                std::swap(index_to_node[old_pos], index_to_node[new_pos]);
+                interval_count[lambda_j] -= 1;
+                interval_count[lambda_j - 1] += 1;
+                interval_ptr[lambda_j] += 1;
+                interval_ptr[lambda_j - 1] = interval_ptr[lambda_j] - interval_count[lambda_j - 1];
+                lambda[j]--;
+            }
+        }
+    }
+}
+
+// :497-600 direct interpolation.  pass 1: row pointer of P; pass 2: entries
+int amgsetup_rs_direct_interpolation_pass1(int n_nodes, const int *Sp, const int *Sj, const int *splitting, int *Bp)
+{
+    int nnz = 0;
+    Bp[0] = 0;
+    for (int i = 0; i < n_nodes; i++) {
+        if (splitting[i] == 1) {
+            nnz++;
+        } else {
+            for (int jj = Sp[i]; jj < Sp[i + 1]; jj++)
+                if (splitting[Sj[jj]] == 1 && Sj[jj] != i) nnz++;
+        }
+        Bp[i + 1] = nnz;
+    }
+    return nnz;
+}
+
+void amgsetup_rs_direct_interpolation_pass2(int n_nodes, const int *Ap, const int *Aj, const double *Ax,
+                                            const int *Sp, const int *Sj, const double *Sx,
+                                            const int *splitting, const int *Bp, int *Bj, double *Bx)
+{
+    for (int i = 0; i < n_nodes; i++) {
+        if (splitting[i] == 1) {
+            Bj[Bp[i]] = i;
+            Bx[Bp[i]] = 1;
+        } else {
+            double sum_strong_pos = 0, sum_strong_neg = 0;
+            for (int jj = Sp[i]; jj < Sp[i + 1]; jj++)
+                if (splitting[Sj[jj]] == 1 && Sj[jj] != i) {
+                    if (Sx[jj] < 0) sum_strong_neg += Sx[jj];
+                    else sum_strong_pos += Sx[jj];
+                }
+            double sum_all_pos = 0, sum_all_neg = 0, diag = 0;
+            for (int jj = Ap[i]; jj < Ap[i + 1]; jj++) {
+                if (Aj[jj] == i) diag += Ax[jj];
+                else if (Ax[jj] < 0) sum_all_neg += Ax[jj];
+                else sum_all_pos += Ax[jj];
+            }
+            double alpha = sum_all_neg / sum_strong_neg;
+            double beta = sum_all_pos / sum_strong_pos;
+            if (sum_strong_pos == 0) { diag += sum_all_pos; beta = 0; }
+            double neg_coeff = -alpha / diag;
+            double pos_coeff = -beta / diag;
+            int nnz = Bp[i];
+            for (int jj = Sp[i]; jj < Sp[i + 1]; jj++)
+                if (splitting[Sj[jj]] == 1 && Sj[jj] != i) {
+                    Bj[nnz] = Sj[jj];
+                    Bx[nnz] = (Sx[jj] < 0) ? neg_coeff * Sx[jj] : pos_coeff * Sx[jj];
+                    nnz++;
+                }
+        }
+    }
+    std::vector<int> map((size_t)n_nodes);
+    for (int i = 0, sum = 0; i < n_nodes; i++) { map[i] = sum; sum += splitting[i]; }
+    for (int i = 0; i < Bp[n_nodes]; i++) Bj[i] = map[Bj[i]];
+}
+
 // Greedy (first-fit) vertex colouring in natural order: colour[i] = smallest colour not used by
 // an already coloured neighbour.  Rows of one colour are mutually independent, so a Gauss-Seidel
 // sweep ordered colour by colour (an index list for gauss_seidel_indexed,
