@@ -421,8 +421,50 @@ static int cycle(amg_hier *h, int lvl, double *&x, double *&xalt, const double *
         CHK(cycle(h, lvl + 1, Lc.x, Lc.xalt, Lc.b, cyc, true));                            // :509-511
         CHK(cycle(h, lvl + 1, Lc.x, Lc.xalt, Lc.b, AMG_CYCLE_V, false));
     } else {
-        set_error("AMLI cycles are not implemented on the device path");
-        return AMG_ENOTIMPL;
+        // AMLI (multilevel.py:512-540): two coarse cycles from an all-ones guess, A-orthogonalised
+        // and combined with optimal step lengths.  The inner products come back to the host
+        // (5 scalars per level), so AMLI iterations are not graph-replayed.
+        const int nAMLI = 2;
+        const size_t bytes = sizeof(double) * (size_t)nc;
+        for (int q = 0; q < 4; ++q)
+            if (!Lc.amli[q]) CHK(dev_alloc(&Lc.amli[q], nc, &h->dev_bytes));
+        double *p[2] = {Lc.amli[0], Lc.amli[1]};
+        double *Apk = Lc.amli[2], *Apj = Lc.amli[3];
+        double *slot = h->norm_scratch + 1030;
+        auto dot = [&](const double *a, const double *bb, double *out) -> int {
+            CHK(launch_dot(a, bb, nc, h->norm_scratch, slot, st));
+            AMG_HIP(hipMemcpyAsync(out, slot, sizeof(double), hipMemcpyDeviceToHost, st));
+            AMG_HIP(hipStreamSynchronize(st));
+            return 0;
+        };
+        for (int k = 0; k < nAMLI; ++k) {
+            CHK(launch_scale(p[k], p[k], 0.0, nc, st));                    // p[k,:] = 1
+            {
+                std::vector<double> ones((size_t)nc, 1.0);
+                AMG_HIP(hipMemcpyAsync(p[k], ones.data(), bytes, hipMemcpyHostToDevice, st));
+                AMG_HIP(hipStreamSynchronize(st));
+            }
+            double *pk = p[k], *alt = Lc.xalt;
+            CHK(cycle(h, lvl + 1, pk, alt, Lc.b, cyc, false));
+            if (pk != p[k]) {                                              // Jacobi swapped the buffers
+                AMG_HIP(hipMemcpyAsync(p[k], pk, bytes, hipMemcpyDeviceToDevice, st));
+            }
+            for (int j = 0; j < k; ++j) {
+                double num = 0, den = 0;
+                CHK(spmv(Lc.A, SM_MATVEC, p[k], nullptr, nullptr, Apk, nullptr, 0.0, st));
+                CHK(spmv(Lc.A, SM_MATVEC, p[j], nullptr, nullptr, Apj, nullptr, 0.0, st));
+                CHK(dot(p[j], Apk, &num));
+                CHK(dot(p[j], Apj, &den));
+                CHK(launch_axmy(p[k], p[j], num / den, nc, st));           // p[k] -= beta*p[j]
+            }
+            double num = 0, den = 0;
+            CHK(spmv(Lc.A, SM_MATVEC, p[k], nullptr, nullptr, Apk, nullptr, 0.0, st));
+            CHK(dot(p[k], Lc.b, &num));
+            CHK(dot(p[k], Apk, &den));
+            const double alpha = num / den;
+            CHK(launch_axmy(Lc.x, p[k], -alpha, nc, st));                  // coarse_x += alpha*p[k]
+            CHK(launch_axmy(Lc.b, Apk, alpha, nc, st));                    // coarse_b -= alpha*Ap
+        }
     }
 
     CHK(spmv(L.P, SM_MATVEC_ACC, Lc.x, nullptr, nullptr, x, nullptr, 0.0, st));            // :544
@@ -466,7 +508,7 @@ static int graph_iteration(amg_hier *h, int cyc, bool x_zero, double *dst)
 {
     hipStream_t st = h->stream;
     double *slot = h->norm_scratch + 1028;
-    if (!h->use_graphs) return iteration_with_norm(h, cyc, x_zero, dst);
+    if (!h->use_graphs || cyc == AMG_CYCLE_AMLI) return iteration_with_norm(h, cyc, x_zero, dst);
     std::vector<double *> state = buffer_state(h);
     GraphEntry *ge = nullptr;
     for (auto &g : h->graphs)
@@ -587,7 +629,7 @@ void amg_hier_destroy(amg_hier *h)
         if (L.sched_csr && L.sched_csr.use_count() == 1) L.sched_csr->release();
         if (L.sched_blk && L.sched_blk.use_count() == 1) L.sched_blk->release();
         free_csr(L.A); free_csr(L.P); free_csr(L.Rm); free_bsr(L.Ab);
-        for (double *p : {L.x, L.xalt, L.b, L.r, L.h, L.h2}) if (p) hipFree(p);
+        for (double *p : {L.x, L.xalt, L.b, L.r, L.h, L.h2, L.amli[0], L.amli[1], L.amli[2], L.amli[3]}) if (p) hipFree(p);
     }
     free_smoother(h->coarse_sm);
     if (h->coarse_Mt) hipFree(h->coarse_Mt);

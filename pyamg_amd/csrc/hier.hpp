@@ -56,6 +56,7 @@ struct Level {
     Smoother sm[2];
     // work vectors (device), length n
     double *x = nullptr, *xalt = nullptr, *b = nullptr, *r = nullptr, *h = nullptr, *h2 = nullptr;
+    double *amli[4] = {nullptr, nullptr, nullptr, nullptr};   // p0, p1, A*p, A*p_j (AMLI cycles, lazily)
     std::shared_ptr<Schedule> sched_csr, sched_blk;   // natural-order schedules, shared pre/post
 };
 

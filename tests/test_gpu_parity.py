@@ -77,7 +77,7 @@ def test_amg_core_kernel_bit_exact_vs_reference(name):
             name, k, np.abs(v - c[k]).max())
 
 
-DEVICE_CASES = [c for c in golden_io.hier_cases() if c != "sa_amli_2d"]
+DEVICE_CASES = [c for c in golden_io.hier_cases() if c != "sa_amli_2d"]     # AMLI: tolerance test below
 
 
 @pytest.mark.parametrize("case", DEVICE_CASES)
@@ -102,11 +102,20 @@ def test_solve_history_vs_reference_and_oracle(case):
     assert np.allclose(res, reso, rtol=1e-12, atol=tol.min())
 
 
-def test_amli_is_refused_not_faked():
+def test_amli_cycle():
+    """AMLI cycles (multilevel.py:512-540).  Their inner products are np.inner (BLAS, order
+    unspecified) in the reference, a sequential sum in the oracle and a tree reduction on the device,
+    so the bar is the stated floating-point tolerance, not bit equality."""
     g = golden_io.load_hier("sa_amli_2d")
     ml = golden_io.build_ml(g)
-    with pytest.raises(NotImplementedError):
-        ml.solve(g["b"], cycle="AMLI", maxiter=2)
+    res = []
+    x = ml.solve(g["b"], cycle="AMLI", tol=g["meta"]["tol"], maxiter=g["meta"]["maxiter"], residuals=res)
+    ref = g["residuals"]
+    assert len(res) == len(ref)
+    assert np.all(np.abs(np.array(res) - ref) <= 1e-10 * ref)
+    assert np.linalg.norm(x - g["x"]) <= 1e-10 * np.linalg.norm(g["x"])
+    with pytest.raises(ValueError):
+        ml.solve(g["b"], cycle="AMLI", accel="cg")          # AMLI needs fgmres or no accel (multilevel.py:383-385)
 
 
 def test_callback_and_residual_semantics():
