@@ -438,12 +438,7 @@ static int cycle(amg_hier *h, int lvl, double *&x, double *&xalt, const double *
             return 0;
         };
         for (int k = 0; k < nAMLI; ++k) {
-            CHK(launch_scale(p[k], p[k], 0.0, nc, st));                    // p[k,:] = 1
-            {
-                std::vector<double> ones((size_t)nc, 1.0);
-                AMG_HIP(hipMemcpyAsync(p[k], ones.data(), bytes, hipMemcpyHostToDevice, st));
-                AMG_HIP(hipStreamSynchronize(st));
-            }
+            CHK(launch_fill(p[k], 1.0, nc, st));                           // p[k,:] = 1
             double *pk = p[k], *alt = Lc.xalt;
             CHK(cycle(h, lvl + 1, pk, alt, Lc.b, cyc, false));
             if (pk != p[k]) {                                              // Jacobi swapped the buffers

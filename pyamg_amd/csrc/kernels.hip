@@ -336,6 +336,11 @@ __global__ void scale_kernel(double *out, const double *in, double c, long n)
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
         out[i] = c * in[i];
 }
+__global__ void fill_kernel(double *out, double v, long n)
+{
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        out[i] = v;
+}
 __global__ void sor_combine_kernel(double *x, const double *xold, double omega, long n)
 {
     // relaxation.py:166-168: x *= omega; x_old *= (1-omega); x += x_old
@@ -376,6 +381,12 @@ int launch_scale(double *out, const double *in, double c, long n, hipStream_t st
     if (n <= 0) return 0;
     hipLaunchKernelGGL(scale_kernel, dim3(vec_grid(n)), dim3(256), 0, st, out, in, c, n);
     LAUNCH_CHECK("scale");
+}
+int launch_fill(double *out, double v, long n, hipStream_t st)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(fill_kernel, dim3(vec_grid(n)), dim3(256), 0, st, out, v, n);
+    LAUNCH_CHECK("fill");
 }
 int launch_sor_combine(double *x, const double *xold, double omega, long n, hipStream_t st)
 {
