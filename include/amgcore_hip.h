@@ -202,6 +202,9 @@ double *amg_hier_dev_b(amg_hier *h);
  * `reps` back-to-back launches timed with hipEvents on the hierarchy stream;
  * returns average ms per launch in *ms. */
 int amg_hier_time_spmv(amg_hier *h, int lvl, int which, int mode, int reps, double *ms);
+/* same for one application of a stored smoother (which = AMG_PRE / AMG_POST / 2 = coarse smoother)
+ * to the level's resident vectors */
+int amg_hier_time_relax(amg_hier *h, int lvl, int which, int reps, double *ms);
 
 /* ------------------------------------------------------------------------ */
 /* 3. Device-pointer API: one operator in HBM + the vector kernels on        */

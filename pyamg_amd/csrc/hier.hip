@@ -1156,6 +1156,26 @@ void amg_arnoldi_free(amg_hier *h)
     h->arn_m = 0; h->arn_n = 0;
 }
 
+// average device time (ms, hipEvents on the hierarchy stream) of one application of a stored
+// smoother to the level's resident x and b; which = AMG_PRE / AMG_POST / 2 (coarse smoother)
+int amg_hier_time_relax(amg_hier *h, int lvl, int which, int reps, double *ms)
+{
+    ENTER(h);
+    if (!h->finalized) { set_error("hierarchy not finalised"); return AMG_ESTATE; }
+    if (lvl < 0 || lvl >= h->nlevels || which < 0 || which > 2 || reps < 1 || !ms) { set_error("bad arguments"); return AMG_EINVAL; }
+    Level &L = h->lv[lvl];
+    Smoother &s = (which == 2) ? h->coarse_sm : L.sm[which];
+    CHK(relax(h, L, s, L.x, L.xalt, L.b, false));
+    AMG_HIP(hipEventRecord(h->ev0, h->stream));
+    for (int r = 0; r < reps; ++r) CHK(relax(h, L, s, L.x, L.xalt, L.b, false));
+    AMG_HIP(hipEventRecord(h->ev1, h->stream));
+    AMG_HIP(hipStreamSynchronize(h->stream));
+    float t = 0.f;
+    AMG_HIP(hipEventElapsedTime(&t, h->ev0, h->ev1));
+    *ms = t / reps;
+    return 0;
+}
+
 void amg_set_stream_variant(int v) { amg::set_stream_variant(v); }
 void amg_set_xcd_chunk(int c) { amg::set_xcd_chunk(c); }
 void amg_set_tile_target(int t) { amg::set_tile_target(t); }

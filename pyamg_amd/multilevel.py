@@ -177,6 +177,11 @@ class _DeviceHierarchy(object):
         _lib.check(self.L.amg_hier_time_spmv(self.h, lvl, which, mode, reps, _lib.C.byref(ms)))
         return ms.value
 
+    def time_relax(self, lvl, which, reps=5):
+        ms = _lib.C.c_double(0.0)
+        _lib.check(self.L.amg_hier_time_relax(self.h, lvl, which, reps, _lib.C.byref(ms)))
+        return ms.value
+
     def close(self):
         if getattr(self, "h", None):
             self.L.amg_hier_destroy(self.h)
