@@ -118,4 +118,19 @@ struct BlockArgs {
 };
 int launch_block(BlockMode m, const BlockArgs &a, hipStream_t st);
 
+// streamed variant over a contiguous range of block rows of a (possibly level-permuted) BSR operator
+struct BsrStreamArgs {
+    const int *Ap; const int *Aj; const double *Ax;   // BSR arrays of the operator being streamed
+    int bs;
+    int brow_lo, brow_hi;   // block rows [lo, hi) of that operator
+    const int *rowmap;      // permuted operator: original block row of each row (x / b / Dinv index); else null
+    int intra_reverse;
+    const double *xin;      // operand vector (temp for Jacobi, the live x for GS)
+    double *xout;
+    const double *b;
+    const double *Dinv;
+    double omega;
+};
+int launch_bsr_stream(BlockMode m, const BsrStreamArgs &a, long nblocks_hint, hipStream_t st);
+
 }  // namespace amg

@@ -122,6 +122,7 @@ void Schedule::release()
     if (rowmap) hipFree(rowmap);
     if (diagpos) hipFree(diagpos);
     if (rows) hipFree(rows);
+    free_bsr(Gb);
     rowmap = diagpos = rows = nullptr;
 }
 
@@ -200,7 +201,7 @@ int build_csr_schedule(const int *Ap, const int *Aj, const double *Ax, int n, co
 }
 
 int build_block_schedule(const int *Ap, const int *Aj, int nb, const int *tasks, int ntasks,
-                         Schedule &S, hipStream_t st)
+                         Schedule &S, hipStream_t st, const double *Ax, int bs)
 {
     (void)st;
     std::vector<int> order;
@@ -210,6 +211,22 @@ int build_block_schedule(const int *Ap, const int *Aj, int nb, const int *tasks,
     for (int k = 0; k < ntasks; ++k) rows[k] = tasks ? tasks[order[k]] : order[k];
     CHK(dev_alloc(&S.rows, ntasks, (long *)nullptr));
     AMG_HIP(hipMemcpy(S.rows, rows.data(), sizeof(int) * (size_t)ntasks, hipMemcpyHostToDevice));
+    if (Ax && bs > 0) {
+        // block rows copied in level order so that every level is one contiguous, streamable slice
+        const long B2 = (long)bs * bs;
+        std::vector<int> gp((size_t)ntasks + 1);
+        long nblk = 0;
+        for (int k = 0; k < ntasks; ++k) { gp[k] = (int)nblk; nblk += Ap[rows[k] + 1] - Ap[rows[k]]; }
+        gp[ntasks] = (int)nblk;
+        std::vector<int> gj((size_t)nblk);
+        std::vector<double> gx((size_t)(nblk * B2));
+        for (int k = 0; k < ntasks; ++k) {
+            int i = rows[k], len = Ap[i + 1] - Ap[i];
+            std::memcpy(gj.data() + gp[k], Aj + Ap[i], sizeof(int) * (size_t)len);
+            std::memcpy(gx.data() + (long)gp[k] * B2, Ax + (long)Ap[i] * B2, sizeof(double) * (size_t)(len * B2));
+        }
+        CHK(upload_bsr(S.Gb, ntasks, bs, gp.data(), gj.data(), gx.data(), nullptr));
+    }
     return 0;
 }
 
@@ -252,12 +269,26 @@ int gs_sweep_csr(const Schedule &S, bool bsr1, double *x, const double *b, bool 
 static int gs_sweep_block(const Schedule &S, const DevBsr &Ab, BlockMode mode, const double *Dinv,
                           double *x, const double *b, bool reverse, hipStream_t st)
 {
+    const int nl = S.nlevels();
+    if (S.Gb.Ap) {
+        BsrStreamArgs a;
+        std::memset(&a, 0, sizeof(a));
+        a.Ap = S.Gb.Ap; a.Aj = S.Gb.Aj; a.Ax = S.Gb.Ax; a.bs = S.Gb.bs;
+        a.rowmap = S.rows; a.intra_reverse = reverse ? 1 : 0;
+        a.xin = x; a.xout = x; a.b = b; a.Dinv = Dinv; a.omega = 1.0;
+        for (int q = 0; q < nl; ++q) {
+            int l = reverse ? nl - 1 - q : q;
+            a.brow_lo = S.level_ptr[l];
+            a.brow_hi = S.level_ptr[l + 1];
+            CHK(launch_bsr_stream(mode, a, (long)S.Gb.nblocks * (a.brow_hi - a.brow_lo) / (S.ntasks ? S.ntasks : 1), st));
+        }
+        return 0;
+    }
     BlockArgs a;
     std::memset(&a, 0, sizeof(a));
     a.Ap = Ab.Ap; a.Aj = Ab.Aj; a.Ax = Ab.Ax; a.bs = Ab.bs;
     a.xin = x; a.xout = x; a.b = b; a.Dinv = Dinv; a.omega = 1.0;
     a.intra_reverse = reverse ? 1 : 0;
-    int nl = S.nlevels();
     for (int q = 0; q < nl; ++q) {
         int l = reverse ? nl - 1 - q : q;
         a.rows = S.rows + S.level_ptr[l];
@@ -265,6 +296,17 @@ static int gs_sweep_block(const Schedule &S, const DevBsr &Ab, BlockMode mode, c
         CHK(launch_block(mode, a, st));
     }
     return 0;
+}
+
+static int bsr_stream_all(const DevBsr &Ab, BlockMode mode, const double *Dinv, const double *xin, double *xout,
+                          const double *b, double omega, hipStream_t st)
+{
+    BsrStreamArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.Ap = Ab.Ap; a.Aj = Ab.Aj; a.Ax = Ab.Ax; a.bs = Ab.bs;
+    a.brow_lo = 0; a.brow_hi = Ab.nbrows;
+    a.xin = xin; a.xout = xout; a.b = b; a.Dinv = Dinv; a.omega = omega;
+    return launch_bsr_stream(mode, a, Ab.nblocks, st);
 }
 
 }  // namespace amg
@@ -288,12 +330,7 @@ static int relax(amg_hier *h, Level &L, Smoother &s, double *&x, double *&xalt, 
             if (bsr && L.R > 1) {
                 // bsr_jacobi: temp = x (relaxation.h:303-305), then x updated in place
                 AMG_HIP(hipMemcpyAsync(xalt, x, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st));
-                BlockArgs a;
-                std::memset(&a, 0, sizeof(a));
-                a.Ap = L.Ab.Ap; a.Aj = L.Ab.Aj; a.Ax = L.Ab.Ax; a.bs = L.Ab.bs;
-                a.first = 0; a.step = 1; a.count = L.Ab.nbrows;
-                a.xin = xalt; a.xout = x; a.b = b; a.omega = s.omega;
-                CHK(launch_block(BM_BSR_JACOBI, a, st));
+                CHK(bsr_stream_all(L.Ab, BM_BSR_JACOBI, nullptr, xalt, x, b, s.omega, st));
             } else {
                 CHK(spmv(L.A, bsr ? SM_JACOBI_BSR1 : SM_JACOBI, x, b, x, xalt, nullptr, s.omega, st));
                 std::swap(x, xalt);
@@ -356,12 +393,7 @@ static int relax(amg_hier *h, Level &L, Smoother &s, double *&x, double *&xalt, 
         // relaxation.py:430-506
         const DevBsr &Ab = s.Ablk_owned ? s.Ablk : L.Ab;
         for (int it = 0; it < s.iterations; ++it) {
-            BlockArgs a;
-            std::memset(&a, 0, sizeof(a));
-            a.Ap = Ab.Ap; a.Aj = Ab.Aj; a.Ax = Ab.Ax; a.bs = Ab.bs;
-            a.first = 0; a.step = 1; a.count = Ab.nbrows;
-            a.xin = x; a.xout = xalt; a.b = b; a.Dinv = s.Dinv; a.omega = s.omega;
-            CHK(launch_block(BM_BLOCK_JACOBI, a, st));
+            CHK(bsr_stream_all(Ab, BM_BLOCK_JACOBI, s.Dinv, x, xalt, b, s.omega, st));
             std::swap(x, xalt);
         }
         return 0;
@@ -769,10 +801,15 @@ static int need_schedule(amg_hier *h, Level &L, Smoother &s)
         if (bsr_pt) {
             if (!L.sched_blk) {
                 std::vector<int> bp((size_t)L.Ab.nbrows + 1), bj((size_t)L.Ab.nblocks);
+                std::vector<double> bx((size_t)L.Ab.nblocks * L.Ab.bs * L.Ab.bs);
                 AMG_HIP(hipMemcpy(bp.data(), L.Ab.Ap, sizeof(int) * bp.size(), hipMemcpyDeviceToHost));
-                if (!bj.empty()) AMG_HIP(hipMemcpy(bj.data(), L.Ab.Aj, sizeof(int) * bj.size(), hipMemcpyDeviceToHost));
+                if (!bj.empty()) {
+                    AMG_HIP(hipMemcpy(bj.data(), L.Ab.Aj, sizeof(int) * bj.size(), hipMemcpyDeviceToHost));
+                    AMG_HIP(hipMemcpy(bx.data(), L.Ab.Ax, sizeof(double) * bx.size(), hipMemcpyDeviceToHost));
+                }
                 L.sched_blk = std::make_shared<Schedule>();
-                CHK(build_block_schedule(bp.data(), bj.data(), L.Ab.nbrows, nullptr, L.Ab.nbrows, *L.sched_blk, h->stream));
+                CHK(build_block_schedule(bp.data(), bj.data(), L.Ab.nbrows, nullptr, L.Ab.nbrows, *L.sched_blk, h->stream,
+                                         bx.data(), L.Ab.bs));
             }
             s.sched = L.sched_blk;
         } else {
@@ -808,10 +845,15 @@ static int need_schedule(amg_hier *h, Level &L, Smoother &s)
         }
         if (s.kind == AMG_SM_BLOCK_GAUSS_SEIDEL) {
             std::vector<int> bp((size_t)Ab->nbrows + 1), bj((size_t)Ab->nblocks);
+            std::vector<double> bx((size_t)Ab->nblocks * Ab->bs * Ab->bs);
             AMG_HIP(hipMemcpy(bp.data(), Ab->Ap, sizeof(int) * bp.size(), hipMemcpyDeviceToHost));
-            if (!bj.empty()) AMG_HIP(hipMemcpy(bj.data(), Ab->Aj, sizeof(int) * bj.size(), hipMemcpyDeviceToHost));
+            if (!bj.empty()) {
+                AMG_HIP(hipMemcpy(bj.data(), Ab->Aj, sizeof(int) * bj.size(), hipMemcpyDeviceToHost));
+                AMG_HIP(hipMemcpy(bx.data(), Ab->Ax, sizeof(double) * bx.size(), hipMemcpyDeviceToHost));
+            }
             s.sched = std::make_shared<Schedule>();
-            CHK(build_block_schedule(bp.data(), bj.data(), Ab->nbrows, nullptr, Ab->nbrows, *s.sched, h->stream));
+            CHK(build_block_schedule(bp.data(), bj.data(), Ab->nbrows, nullptr, Ab->nbrows, *s.sched, h->stream,
+                                     bx.data(), Ab->bs));
         }
     }
     return 0;

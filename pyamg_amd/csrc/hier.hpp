@@ -23,6 +23,7 @@ struct Schedule {
     int *diagpos = nullptr;       // device: position of the diagonal entry in G (-1 if none)
     // BSR flavour: block rows listed in level order
     int *rows = nullptr;          // device
+    DevBsr Gb;                    // BSR flavour with values: block rows copied in level order (streamed)
     int nlevels() const { return (int)level_ptr.size() - 1; }
     void release();
 };
@@ -32,7 +33,7 @@ int build_levels(int n, const int *Ap, const int *Aj, const int *tasks, int ntas
 int build_csr_schedule(const int *Ap, const int *Aj, const double *Ax, int n, const int *tasks,
                        int ntasks, Schedule &S, hipStream_t st);
 int build_block_schedule(const int *Ap, const int *Aj, int nb, const int *tasks, int ntasks,
-                         Schedule &S, hipStream_t st);
+                         Schedule &S, hipStream_t st, const double *Ax = nullptr, int bs = 0);
 
 struct Smoother {
     int kind = AMG_SM_NONE;

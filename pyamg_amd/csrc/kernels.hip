@@ -666,6 +666,145 @@ __global__ void block_kernel(BlockArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------
+// bsr_stream: the block / point-BSR smoothers with the matrix STREAMED.  A workgroup owns `rpb`
+// consecutive block rows (rpb*bs <= 256); their blocks are one contiguous slice of the BSR data
+// array, streamed through LDS in tiles of whole blocks with lane-contiguous loads (each entry
+// multiplied by its operand x[col*bs + c] on the way in); then thread (block row, r) forms, block
+// by block, v = sum_c p[r][c] left to right and folds v into its row sum -- exactly the order of
+// gemm + "rsum += v" in relaxation.h:697-709, 787-799 (and "rsum -= Axloc", :138-146, 317-325).
+// The small dense epilogue (Dinv*t, or the point sweep over the diagonal block) goes through LDS.
+// ---------------------------------------------------------------------------
+template <int BMODE>
+__global__ __launch_bounds__(WG) void bsr_stream_kernel(BsrStreamArgs a, int rpb)
+{
+    __shared__ double sp[TILE];
+    __shared__ int sbj[TILE];          // block column of every block in the tile
+    __shared__ int sAp[WG + 1];
+    __shared__ double st[WG];
+
+    const int t = threadIdx.x;
+    const int bs = a.bs, B2 = bs * bs;
+    const int r0 = a.brow_lo + blockIdx.x * rpb;
+    const int nr = min(rpb, a.brow_hi - r0);
+    for (int i = t; i <= nr; i += WG) sAp[i] = a.Ap[r0 + i];
+    __syncthreads();
+    const int bbeg = sAp[0], bend = sAp[nr];
+    const int tile_blocks = TILE / B2;
+
+    const int li = t / bs, r = t - li * bs;
+    const bool active = li < nr;
+    const int prow = r0 + li;                                  // position in the (permuted) operator
+    const int brow = active ? (a.rowmap ? a.rowmap[prow] : prow) : 0;   // block row in x / b numbering
+    const int my_s = active ? sAp[li] : bend, my_e = active ? sAp[li + 1] : bend;
+    const long ib = (long)brow * bs;
+    constexpr bool point = (BMODE == BM_BSR_JACOBI || BMODE == BM_BSR_GS);
+    double rsum = 0.0;
+    if (point && active) rsum = a.b[ib + r];
+    long dptr = -1;
+
+    for (int tb = bbeg; tb < bend; tb += tile_blocks) {
+        const int te = min(tb + tile_blocks, bend);
+        const long ebase = (long)tb * B2, ecount = (long)(te - tb) * B2;
+        for (long q = t; q < ecount; q += WG) {
+            const int lb = (int)(q / B2);
+            const int rc = (int)(q - (long)lb * B2);
+            const int c = rc % bs;
+            const int col = a.Aj[tb + lb];
+            if (rc == 0) sbj[lb] = col;
+            sp[q] = a.Ax[ebase + q] * a.xin[(long)col * bs + c];
+        }
+        __syncthreads();
+        if (active) {
+            const int s = max(my_s, tb), e = min(my_e, te);
+            for (int jj = s; jj < e; ++jj) {
+                if (sbj[jj - tb] == brow) { dptr = (long)jj * B2; continue; }
+                const double *p = &sp[(long)(jj - tb) * B2 + r * bs];
+                double v = 0.0;
+                for (int c = 0; c < bs; ++c) v = v + p[c];
+                rsum = point ? (rsum - v) : (rsum + v);
+            }
+        }
+        __syncthreads();
+    }
+
+    if (BMODE == BM_BLOCK_JACOBI || BMODE == BM_BLOCK_GS) {
+        if (active) st[t] = a.b[ib + r] - rsum;
+        __syncthreads();
+        if (active) {
+            const double *D = a.Dinv + (long)brow * B2 + r * bs;
+            const double *tv = &st[li * bs];
+            double v = 0.0;
+            for (int c = 0; c < bs; ++c) v = v + D[c] * tv[c];
+            if (BMODE == BM_BLOCK_JACOBI) {
+                double t1 = (1.0 - a.omega) * a.xin[ib + r];
+                double t2 = a.omega * v;
+                a.xout[ib + r] = t1 + t2;
+            } else {
+                a.xout[ib + r] = v;
+            }
+        }
+    } else if (BMODE == BM_BSR_JACOBI) {
+        // point Jacobi over the diagonal block (relaxation.h:339-351): rows independent (they read temp)
+        if (active && dptr != -1) {
+            const int step = a.intra_reverse ? -1 : 1;
+            const int k0 = a.intra_reverse ? bs - 1 : 0, k1 = a.intra_reverse ? -1 : bs;
+            double diag = 1.0;
+            for (int kk = k0; kk != k1; kk += step) {
+                if (kk == r) diag = a.Ax[dptr + r * bs + kk];
+                else rsum = rsum - a.Ax[dptr + r * bs + kk] * a.xin[ib + kk];
+            }
+            if (diag != 0.0) {
+                double t1 = (1.0 - a.omega) * a.xin[ib + r];
+                double t2 = (a.omega * rsum) / diag;
+                a.xout[ib + r] = t1 + t2;
+            }
+        }
+    } else {
+        // point Gauss-Seidel over the diagonal block (relaxation.h:151-163): sequential inside the
+        // block, so one thread per block row finishes it from the row sums parked in LDS
+        if (active) st[t] = rsum;
+        __syncthreads();
+        if (active && r == 0 && dptr != -1) {
+            const int step = a.intra_reverse ? -1 : 1;
+            const int k0 = a.intra_reverse ? bs - 1 : 0, k1 = a.intra_reverse ? -1 : bs;
+            for (int k = k0; k != k1; k += step) {
+                double rs = st[li * bs + k];
+                double diag = 1.0;
+                for (int kk = k0; kk != k1; kk += step) {
+                    if (k == kk) diag = a.Ax[dptr + k * bs + kk];
+                    else rs = rs - a.Ax[dptr + k * bs + kk] * a.xout[ib + kk];
+                }
+                if (diag != 0.0) a.xout[ib + k] = rs / diag;
+            }
+        }
+    }
+}
+
+int launch_bsr_stream(BlockMode m, const BsrStreamArgs &a, long nblocks_hint, hipStream_t st)
+{
+    const int rows = a.brow_hi - a.brow_lo;
+    if (rows <= 0) return 0;
+    if (a.bs > MAXBS || a.bs < 1) { set_error("block kernels support blocksize 1..16"); return -5; }
+    const int B2 = a.bs * a.bs;
+    int rpb = WG / a.bs;
+    // aim at about one LDS tile of products per workgroup
+    if (nblocks_hint > 0) {
+        double per_row = (double)nblocks_hint * B2 / (double)rows;
+        int want = (int)(g_tile_target / (per_row > 1.0 ? per_row : 1.0));
+        if (want < 1) want = 1;
+        if (want < rpb) rpb = want;
+    }
+    dim3 g((rows + rpb - 1) / rpb), b(WG);
+    switch (m) {
+    case BM_BSR_JACOBI: hipLaunchKernelGGL(bsr_stream_kernel<BM_BSR_JACOBI>, g, b, 0, st, a, rpb); break;
+    case BM_BLOCK_JACOBI: hipLaunchKernelGGL(bsr_stream_kernel<BM_BLOCK_JACOBI>, g, b, 0, st, a, rpb); break;
+    case BM_BSR_GS: hipLaunchKernelGGL(bsr_stream_kernel<BM_BSR_GS>, g, b, 0, st, a, rpb); break;
+    case BM_BLOCK_GS: hipLaunchKernelGGL(bsr_stream_kernel<BM_BLOCK_GS>, g, b, 0, st, a, rpb); break;
+    }
+    LAUNCH_CHECK("bsr_stream kernel");
+}
+
 int launch_block(BlockMode m, const BlockArgs &a, hipStream_t st)
 {
     if (a.count <= 0) return 0;
