@@ -675,7 +675,7 @@ __global__ void block_kernel(BlockArgs a)
 // gemm + "rsum += v" in relaxation.h:697-709, 787-799 (and "rsum -= Axloc", :138-146, 317-325).
 // The small dense epilogue (Dinv*t, or the point sweep over the diagonal block) goes through LDS.
 // ---------------------------------------------------------------------------
-template <int BMODE>
+template <int BMODE, int BS>      // BS > 0: compile-time block size (index arithmetic folds); 0: a.bs
 __global__ __launch_bounds__(WG) void bsr_stream_kernel(BsrStreamArgs a, int rpb)
 {
     __shared__ double sp[TILE];
@@ -684,7 +684,7 @@ __global__ __launch_bounds__(WG) void bsr_stream_kernel(BsrStreamArgs a, int rpb
     __shared__ double st[WG];
 
     const int t = threadIdx.x;
-    const int bs = a.bs, B2 = bs * bs;
+    const int bs = BS > 0 ? BS : a.bs, B2 = bs * bs;
     const int r0 = a.brow_lo + blockIdx.x * rpb;
     const int nr = min(rpb, a.brow_hi - r0);
     for (int i = t; i <= nr; i += WG) sAp[i] = a.Ap[r0 + i];
@@ -796,12 +796,23 @@ int launch_bsr_stream(BlockMode m, const BsrStreamArgs &a, long nblocks_hint, hi
         if (want < rpb) rpb = want;
     }
     dim3 g((rows + rpb - 1) / rpb), b(WG);
-    switch (m) {
-    case BM_BSR_JACOBI: hipLaunchKernelGGL(bsr_stream_kernel<BM_BSR_JACOBI>, g, b, 0, st, a, rpb); break;
-    case BM_BLOCK_JACOBI: hipLaunchKernelGGL(bsr_stream_kernel<BM_BLOCK_JACOBI>, g, b, 0, st, a, rpb); break;
-    case BM_BSR_GS: hipLaunchKernelGGL(bsr_stream_kernel<BM_BSR_GS>, g, b, 0, st, a, rpb); break;
-    case BM_BLOCK_GS: hipLaunchKernelGGL(bsr_stream_kernel<BM_BLOCK_GS>, g, b, 0, st, a, rpb); break;
+#define BSR_LAUNCH(MODE, BSV) hipLaunchKernelGGL((bsr_stream_kernel<MODE, BSV>), g, b, 0, st, a, rpb)
+#define BSR_BY_BS(MODE)                                 \
+    switch (a.bs) {                                     \
+    case 2: BSR_LAUNCH(MODE, 2); break;                 \
+    case 3: BSR_LAUNCH(MODE, 3); break;                 \
+    case 4: BSR_LAUNCH(MODE, 4); break;                 \
+    case 6: BSR_LAUNCH(MODE, 6); break;                 \
+    default: BSR_LAUNCH(MODE, 0); break;                \
     }
+    switch (m) {
+    case BM_BSR_JACOBI: BSR_BY_BS(BM_BSR_JACOBI); break;
+    case BM_BLOCK_JACOBI: BSR_BY_BS(BM_BLOCK_JACOBI); break;
+    case BM_BSR_GS: BSR_BY_BS(BM_BSR_GS); break;
+    case BM_BLOCK_GS: BSR_BY_BS(BM_BLOCK_GS); break;
+    }
+#undef BSR_BY_BS
+#undef BSR_LAUNCH
     LAUNCH_CHECK("bsr_stream kernel");
 }
 
