@@ -78,8 +78,45 @@ def partitioned_main(args, rank, local_rank, world, torch, dist):
     from pyamg_amd.distributed import (DistributedSolver, HipBackend, levels_from_ml, load_levels, save_levels,
                                        split_rows)
     host_group = dist.new_group(backend="gloo")
-    shared = "/dev/shm/amg_bench_%s" % os.environ.get("MASTER_PORT", "0")
     n = args.grid ** 3
+    # where to ship the hierarchy: a memory-backed directory with room for ~0.32 KB per fine unknown
+    need = int(330.0 * n) + (1 << 28)
+    shared = None
+    if rank == 0:
+        for base in ("/dev/shm", os.environ.get("TMPDIR", "/tmp"), "/tmp", ROOT):
+            try:
+                if shutil.disk_usage(base).free > need:
+                    shared = os.path.join(base, "amg_bench_%s" % os.environ.get("MASTER_PORT", "0"))
+                    break
+            except OSError:
+                pass
+        if shared is None:
+            shared = os.path.join("/tmp", "amg_bench_%s" % os.environ.get("MASTER_PORT", "0"))
+    box = [shared]
+    dist.broadcast_object_list(box, src=0, group=host_group)
+    shared = box[0]
+    # RCCL self-test (uneven all_to_all + all_reduce on device tensors); on any failure every rank
+    # falls back to moving the halos through the gloo group (same code path, slower transport)
+    dev_group = None
+    ok = 1.0
+    try:
+        tin = torch.arange(world + rank, dtype=torch.float64, device="cuda")[:world].contiguous()
+        tout = torch.empty(world, dtype=torch.float64, device="cuda")
+        dist.all_to_all_single(tout, tin, [1] * world, [1] * world)
+        tt = torch.ones(1, dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt)
+        torch.cuda.synchronize()
+        if abs(tt.item() - world) > 0:
+            ok = 0.0
+    except Exception as e:   # noqa: BLE001
+        log("[bench] rank %d: device collective self-test failed: %r" % (rank, e))
+        ok = 0.0
+    flag = torch.tensor([ok], dtype=torch.float64)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=host_group)
+    transport = "RCCL"
+    if flag.item() < 0.5:
+        dev_group = host_group
+        transport = "gloo (RCCL self-test failed)"
     t_gen = t_setup = 0.0
     if rank == 0:
         shutil.rmtree(shared, ignore_errors=True)
@@ -95,7 +132,7 @@ def partitioned_main(args, rank, local_rank, world, torch, dist):
     dist.barrier(group=host_group)
     levels, coarse = load_levels(shared)
     t0 = time.time()
-    S = DistributedSolver(levels, coarse, HipBackend(local_rank), rank, world, group=None, host_group=host_group)
+    S = DistributedSolver(levels, coarse, HipBackend(local_rank), rank, world, group=dev_group, host_group=host_group)
     bnd = split_rows(n, world)
     lo, hi = int(bnd[rank]), int(bnd[rank + 1])
     b = np.load(os.path.join(shared, "b.npy"), mmap_mode="r")[lo:hi]
@@ -108,13 +145,13 @@ def partitioned_main(args, rank, local_rank, world, torch, dist):
 
     r0 = S.residual_norm()
     warm = S.run_fixed(args.warmup, "V", x_zero=True)
-    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+    torch.cuda.synchronize(); dist.barrier(group=host_group); torch.cuda.synchronize()
     t0 = time.perf_counter()
     timed = S.run_fixed(args.steps, "V", x_zero=False)
-    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+    torch.cuda.synchronize(); dist.barrier(group=host_group); torch.cuda.synchronize()
     wall = time.perf_counter() - t0
-    tw = torch.tensor([wall], dtype=torch.float64, device="cuda")
-    dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+    tw = torch.tensor([wall], dtype=torch.float64)
+    dist.all_reduce(tw, op=dist.ReduceOp.MAX, group=host_group)
     wall = float(tw.item())
     # level-0 A-application on this rank's slab, hipEvents on the launch stream
     lv = S.lv[0]
@@ -139,7 +176,7 @@ def partitioned_main(args, rank, local_rank, world, torch, dist):
                                    "%s pre/post smoother, V(1,1), b=rand seed 0" %
                                    (args.grid, args.grid, args.grid, n / 1e6, len(S.lv), args.smoother),
                        "parallelism": "rows of every level partitioned over %d GPUs, halo exchange + residual "
-                                      "all-reduce over RCCL" % world,
+                                      "all-reduce over %s" % (world, transport),
                        "levels": shape_info, "halo_per_level_rank0": [lv_.n_halo for lv_ in S.lv],
                        "setup_seconds": {"matrix": round(t_gen, 1), "hierarchy": round(t_setup, 1)},
                        "residuals": [r0, warm[-1] if warm else r0, timed[-1]]},
@@ -150,7 +187,7 @@ def partitioned_main(args, rank, local_rank, world, torch, dist):
             "cpu_baseline": None,
         }
         print(json.dumps(out), flush=True)
-    dist.barrier()
+    dist.barrier(group=host_group)
     dist.destroy_process_group()
 
 
