@@ -221,7 +221,7 @@ long amg_mat_nnz(amg_mat *m);
  * 4 out=c0*b+Mx  5 out=v2+(c0*b+Mx)  6 Jacobi (CSR rounding)  7 Jacobi (BSR(1,1) rounding);
  * xg is the gathered vector (owned entries followed by the halo) */
 int amg_mat_apply(amg_mat *m, int mode, const double *xg, const double *b, const double *v2, double *out,
-                  double *out2, double c0, void *stream);
+                  double *out2, double c0, double gscale, void *stream);   /* products are a_ij*(gscale*xg_j); 0 = 1 */
 /* Gauss-Seidel over the operator's own rows (order NULL: 0..nrows-1, else an index list as for
  * gauss_seidel_indexed); columns >= nrows (halo) stay frozen: GS inside a rank, Jacobi across */
 int amg_mat_build_gs(amg_mat *m, const int *order, int norder);
@@ -229,6 +229,7 @@ int amg_mat_gs_levels(amg_mat *m);
 int amg_mat_gs_sweep(amg_mat *m, double *x, const double *b, int reverse, int bsr1, void *stream);
 int amg_dev_scale(double *out, const double *in, double c, long n, void *stream);
 int amg_dev_axpy(double *x, const double *h, long n, void *stream);
+int amg_dev_axpy_scaled(double *x, const double *r, double c, long n, void *stream);   /* x += c*r */
 int amg_dev_norm2(const double *x, long n, double *scratch, double *result_dev, void *stream);
 int amg_dev_dot(const double *x, const double *y, long n, double *scratch, double *result_dev, void *stream);
 int amg_dev_dense_apply(const double *Mt, const double *b, double *x, int n, void *stream);

@@ -54,6 +54,8 @@ enum StreamMode {
     SM_JACOBI_BSR1,     // rs=b[i]; rs-=p..; out[i] = (1-w)*v2[i] + w*rs/d   (relaxation.h:268-360, bs=1)
     SM_GS,              // out[row] = (b[row]-s)/d                      (relaxation.h:34-62, one level)
     SM_GS_BSR1,         // rs=b[row]; rs-=p..; out[row] = rs/d          (relaxation.h:90-173, bs=1)
+    SM_RESIDUAL_SUMSQ,  // out2[block] = sum over the block's rows of (b[i]-s)^2; r is not stored
+                        // (the outer residual norm, multilevel.py:461, without the 16n vector round trip)
 };
 
 struct StreamArgs {
@@ -71,10 +73,15 @@ struct StreamArgs {
     const int *diagpos;      // GS levels: position of the diagonal entry of permuted row i (-1: none)
     long nnz_total;          // entries in Aj/Ax (bound for 16-byte loads)
     int rows_per_wg;         // rows handled by one workgroup (1..256; 0 -> 256)
+    double gscale;           // operand scaling: products are a_ij * (gscale * xg[j]); 0 is read as 1.
+                             // (polynomial smoother: gather c0*r straight from r, relaxation.py:663-666)
 };
 
 // variant: 0 = scalar (8 B / 4 B per lane) loads, 1 = 16-byte vector loads
 int launch_stream(StreamMode mode, const StreamArgs &a, hipStream_t st);
+int stream_blocks(const StreamArgs &a);   // workgroups launch_stream will use (partials of SM_RESIDUAL_SUMSQ)
+int launch_sum_sqrt(const double *partial, long np, double *result_dev, hipStream_t st);   // sqrt(sum) in fixed order
+int launch_axpy_scaled(double *x, const double *r, double c, long n, hipStream_t st);        // x += c*r
 void set_stream_variant(int v);
 int stream_variant();
 void set_xcd_chunk(int c);

@@ -97,7 +97,7 @@ long amg_mat_nnz(amg_mat *m) { return m ? m->M.nnz : 0; }
 
 // mode: 0 MATVEC, 1 MATVEC_ACC, 2 RESIDUAL, 3 POLY_FIRST, 4 POLY_STEP, 5 POLY_LAST, 6 JACOBI, 7 JACOBI_BSR1
 int amg_mat_apply(amg_mat *m, int mode, const double *xg, const double *b, const double *v2, double *out,
-                  double *out2, double c0, void *stream)
+                  double *out2, double c0, double gscale, void *stream)
 {
     if (!m) { set_error("null matrix"); return AMG_EINVAL; }
     if (mode < 0 || mode > SM_JACOBI_BSR1) { set_error("bad mode"); return AMG_EINVAL; }
@@ -106,7 +106,7 @@ int amg_mat_apply(amg_mat *m, int mode, const double *xg, const double *b, const
     std::memset(&a, 0, sizeof(a));
     a.Ap = m->M.Ap; a.Aj = m->M.Aj; a.Ax = m->M.Ax;
     a.row_lo = 0; a.row_hi = m->M.nrows; a.nnz_total = m->M.nnz; a.rows_per_wg = m->rpw;
-    a.xg = xg; a.b = b; a.v2 = v2; a.out = out; a.out2 = out2; a.c0 = c0;
+    a.xg = xg; a.b = b; a.v2 = v2; a.out = out; a.out2 = out2; a.c0 = c0; a.gscale = gscale;
     return launch_stream((StreamMode)mode, a, (hipStream_t)stream);
 }
 
@@ -114,6 +114,8 @@ int amg_dev_scale(double *out, const double *in, double c, long n, void *stream)
 { return launch_scale(out, in, c, n, (hipStream_t)stream); }
 int amg_dev_axpy(double *x, const double *h, long n, void *stream)
 { return launch_axpy_inplace(x, h, n, (hipStream_t)stream); }
+int amg_dev_axpy_scaled(double *x, const double *r, double c, long n, void *stream)
+{ return launch_axpy_scaled(x, r, c, n, (hipStream_t)stream); }
 // result_dev[0] = ||x||_2 of the LOCAL part; scratch >= 1040 doubles
 int amg_dev_norm2(const double *x, long n, double *scratch, double *result_dev, void *stream)
 { return launch_norm2(x, n, scratch, result_dev, (hipStream_t)stream); }

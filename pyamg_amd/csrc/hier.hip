@@ -250,6 +250,15 @@ int spmv(const DevCsr &M, StreamMode mode, const double *xg, const double *b, co
     return launch_stream(mode, a, st);
 }
 
+// products a_ij * (gscale * xg_j): the polynomial smoother gathers h = c0*r straight from r
+static int spmv_scaled(const DevCsr &M, StreamMode mode, const double *xg, double gscale, const double *b,
+                       const double *v2, double *out, double c0, hipStream_t st)
+{
+    StreamArgs a = base_args(M);
+    a.xg = xg; a.b = b; a.v2 = v2; a.out = out; a.c0 = c0; a.gscale = gscale;
+    return launch_stream(mode, a, st);
+}
+
 // one directional sweep of a scheduled (CSR flavour) Gauss-Seidel
 int gs_sweep_csr(const Schedule &S, bool bsr1, double *x, const double *b, bool reverse,
                  hipStream_t st)
@@ -365,21 +374,26 @@ static int relax(amg_hier *h, Level &L, Smoother &s, double *&x, double *&xalt, 
     }
     case AMG_SM_POLYNOMIAL: {
         // relaxation.py:593-668.  r = b when x == 0 is bitwise identical to b - A*0.
+        // h = c0*r is never stored: the next operator application gathers c0*r[j] from r on the fly
+        // (the same single rounding), which saves one vector write per application (and the whole
+        // scale pass when x == 0).
         const int nc = (int)s.coef.size();
         for (int it = 0; it < s.iterations; ++it) {
             const double *r;
-            double *hh = L.h, *hn = L.h2;
             if (x_zero) {
                 r = b;
-                CHK(launch_scale(hh, b, s.coef[0], n, st));
             } else {
-                CHK(spmv(L.A, SM_POLY_FIRST, x, b, nullptr, L.r, hh, s.coef[0], st));
+                CHK(spmv(L.A, SM_RESIDUAL, x, b, nullptr, L.r, nullptr, 0.0, st));
                 r = L.r;
             }
             if (nc == 1) {
-                CHK(launch_axpy_inplace(x, hh, n, st));
+                CHK(launch_axpy_scaled(x, r, s.coef[0], n, st));
+            } else if (nc == 2) {
+                CHK(spmv_scaled(L.A, SM_POLY_LAST, r, s.coef[0], r, x, x, s.coef[1], st));
             } else {
-                for (int c = 1; c < nc - 1; ++c) {
+                double *hh = L.h, *hn = L.h2;
+                CHK(spmv_scaled(L.A, SM_POLY_STEP, r, s.coef[0], r, nullptr, hh, s.coef[1], st));
+                for (int c = 2; c < nc - 1; ++c) {
                     CHK(spmv(L.A, SM_POLY_STEP, hh, r, nullptr, hn, nullptr, s.coef[c], st));
                     std::swap(hh, hn);
                 }
@@ -508,10 +522,15 @@ static int one_iteration(amg_hier *h, int cyc, bool x_zero)
 
 static int residual_norm_to(amg_hier *h, double *slot)
 {
-    // util/linalg.py:109-112
+    // util/linalg.py:109-112: ||b - A x||.  The residual is not stored: every workgroup of the
+    // operator application reduces its rows' squares, a second kernel adds the partials in order.
     Level &L0 = h->lv[0];
-    CHK(spmv(L0.A, SM_RESIDUAL, L0.x, L0.b, nullptr, L0.r, nullptr, 0.0, h->stream));
-    return launch_norm2(L0.r, L0.A.nrows, h->norm_scratch, slot, h->stream);
+    StreamArgs a = base_args(L0.A);
+    a.xg = L0.x; a.b = L0.b; a.out2 = h->sumsq_partials;
+    const int nb = stream_blocks(a);
+    if (nb > h->sumsq_cap) { set_error("sumsq partial buffer too small"); return AMG_ESTATE; }
+    CHK(launch_stream(SM_RESIDUAL_SUMSQ, a, h->stream));
+    return launch_sum_sqrt(h->sumsq_partials, nb, slot, h->stream);
 }
 
 // One solve() iteration = cycle + residual norm into `slot`, replayed from a hipGraph once the
@@ -664,6 +683,7 @@ void amg_hier_destroy(amg_hier *h)
     if (h->arn_dinv) hipFree(h->arn_dinv);
     if (h->arn_coef) hipFree(h->arn_coef);
     if (h->norm_scratch) hipFree(h->norm_scratch);
+    if (h->sumsq_partials) hipFree(h->sumsq_partials);
     if (h->res_dev) hipFree(h->res_dev);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
@@ -889,6 +909,16 @@ int amg_hier_finalize(amg_hier *h)
         return AMG_EINVAL;
     }
     if (!h->norm_scratch) CHK(dev_alloc(&h->norm_scratch, 1024 + 8, &h->dev_bytes));
+    {
+        StreamArgs a0 = base_args(h->lv[0].A);
+        long need = stream_blocks(a0) + 8;
+        if (need > h->sumsq_cap) {
+            if (h->sumsq_partials) hipFree(h->sumsq_partials);
+            h->sumsq_partials = nullptr;
+            CHK(dev_alloc(&h->sumsq_partials, need, &h->dev_bytes));
+            h->sumsq_cap = need;
+        }
+    }
     drop_graphs(h);
     {
         const char *env = getenv("AMG_HIP_GRAPHS");

@@ -89,6 +89,8 @@ struct amg_hier {
     amg::Smoother coarse_sm;
     // scratch
     double *norm_scratch = nullptr;   // 1024 partials
+    double *sumsq_partials = nullptr; // one partial per workgroup of the level-0 residual kernel
+    long sumsq_cap = 0;
     double *res_dev = nullptr;        // residual history on device
     int res_cap = 0;
     // Arnoldi workspace for setup-time spectral-radius estimates

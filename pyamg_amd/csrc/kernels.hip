@@ -60,6 +60,21 @@ __device__ __forceinline__ int remap_block(int b, int nb, int chunk)
     return base + start + j;
 }
 
+__device__ __forceinline__ double block_reduce_sum(double v, double *smem)
+{
+    // wave64 butterfly, then 4 waves through LDS
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) smem[w] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0) {
+        int nw = blockDim.x >> 6;
+        for (int k = 0; k < nw; ++k) r += smem[k];
+    }
+    return r;
+}
+
 template <int MODE> struct ModeTraits {
     static constexpr bool jac = (MODE == SM_JACOBI || MODE == SM_JACOBI_BSR1);
     static constexpr bool gs = (MODE == SM_GS || MODE == SM_GS_BSR1);
@@ -70,6 +85,7 @@ template <int MODE, int VEC>
 __global__ __launch_bounds__(WG) void csr_stream_kernel(StreamArgs a, int xcd_chunk, int rpb)
 {
     const long nnz_total = a.nnz_total;
+    const double gscale = a.gscale;      // 1.0 unless the operand is scaled on the fly (1.0*x is exact)
     using MT = ModeTraits<MODE>;
     __shared__ double sp[TILE];
     __shared__ int sAp[WG + 1];
@@ -137,7 +153,7 @@ __global__ __launch_bounds__(WG) void csr_stream_kernel(StreamArgs a, int xcd_ch
                 double v[4] = {av[p][0].x, av[p][0].y, av[p][1].x, av[p][1].y};
                 double xv[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) xv[u] = a.xg[c[u]];
+                for (int u = 0; u < 4; ++u) xv[u] = gscale * a.xg[c[u]];
                 double pr[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -170,7 +186,7 @@ __global__ __launch_bounds__(WG) void csr_stream_kernel(StreamArgs a, int xcd_ch
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 int k = tile_lo + u * WG + t;
-                xv[u] = (k < tile_hi) ? a.xg[c[u]] : 0.0;
+                xv[u] = (k < tile_hi) ? gscale * a.xg[c[u]] : 0.0;
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -200,6 +216,15 @@ __global__ __launch_bounds__(WG) void csr_stream_kernel(StreamArgs a, int xcd_ch
         __syncthreads();
     }
 
+    if (MODE == SM_RESIDUAL_SUMSQ) {
+        // per-workgroup partial of ||b - A x||^2 (fixed order: lanes by shuffle tree, waves in order)
+        double sq = 0.0;
+        if (t < nr) { double rr = a.b[r0 + t] - acc; sq = rr * rr; }
+        __syncthreads();
+        double tot = block_reduce_sum(sq, sp);
+        if (t == 0) a.out2[blk] = tot;
+        return;
+    }
     if (t >= nr) return;
     const int i = r0 + t;
     if (MODE == SM_MATVEC) {
@@ -257,13 +282,23 @@ static int launch_stream_mode(const StreamArgs &a, hipStream_t st)
     int rpb = a.rows_per_wg;
     if (rpb < 1 || rpb > WG) rpb = WG;
     int nb = (rows + rpb - 1) / rpb;
+    StreamArgs b = a;
+    if (b.gscale == 0.0) b.gscale = 1.0;
     if (g_stream_variant)
-        hipLaunchKernelGGL((csr_stream_kernel<MODE, 1>), dim3(nb), dim3(WG), 0, st, a, g_xcd_chunk, rpb);
+        hipLaunchKernelGGL((csr_stream_kernel<MODE, 1>), dim3(nb), dim3(WG), 0, st, b, g_xcd_chunk, rpb);
     else
-        hipLaunchKernelGGL((csr_stream_kernel<MODE, 0>), dim3(nb), dim3(WG), 0, st, a, g_xcd_chunk, rpb);
+        hipLaunchKernelGGL((csr_stream_kernel<MODE, 0>), dim3(nb), dim3(WG), 0, st, b, g_xcd_chunk, rpb);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "csr_stream launch", __FILE__, __LINE__);
     return 0;
+}
+
+int stream_blocks(const StreamArgs &a)
+{
+    int rows = a.row_hi - a.row_lo;
+    int rpb = a.rows_per_wg;
+    if (rpb < 1 || rpb > WG) rpb = WG;
+    return rows > 0 ? (rows + rpb - 1) / rpb : 0;
 }
 
 int launch_stream(StreamMode mode, const StreamArgs &a, hipStream_t st)
@@ -279,6 +314,7 @@ int launch_stream(StreamMode mode, const StreamArgs &a, hipStream_t st)
     case SM_JACOBI_BSR1: return launch_stream_mode<SM_JACOBI_BSR1>(a, st);
     case SM_GS: return launch_stream_mode<SM_GS>(a, st);
     case SM_GS_BSR1: return launch_stream_mode<SM_GS_BSR1>(a, st);
+    case SM_RESIDUAL_SUMSQ: return launch_stream_mode<SM_RESIDUAL_SUMSQ>(a, st);
     }
     set_error("launch_stream: bad mode");
     return -1;
@@ -419,21 +455,6 @@ int launch_copy_strided(double *dst, const double *src, int start, int count, in
 // ---------------------------------------------------------------------------
 constexpr int NORM_BLOCKS = 1024;
 
-__device__ __forceinline__ double block_reduce_sum(double v, double *smem)
-{
-    // wave64 butterfly, then 4 waves through LDS
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (lane == 0) smem[w] = v;
-    __syncthreads();
-    double r = 0.0;
-    if (threadIdx.x == 0) {
-        int nw = blockDim.x >> 6;
-        for (int k = 0; k < nw; ++k) r += smem[k];
-    }
-    return r;
-}
-
 __global__ __launch_bounds__(256) void sumsq_stage1(const double *x, long n, double *partial)
 {
     __shared__ double smem[4];
@@ -457,6 +478,34 @@ __global__ __launch_bounds__(256) void sumsq_stage2(const double *partial, int n
     for (int i = threadIdx.x; i < np; i += blockDim.x) s += partial[i];
     double r = block_reduce_sum(s, smem);
     if (threadIdx.x == 0) *result = sqrt(r);
+}
+
+__global__ __launch_bounds__(256) void sum_sqrt_kernel(const double *partial, long np, double *result)
+{
+    __shared__ double smem[4];
+    double s = 0.0;
+    for (long i = threadIdx.x; i < np; i += blockDim.x) s += partial[i];
+    double r = block_reduce_sum(s, smem);
+    if (threadIdx.x == 0) *result = sqrt(r);
+}
+int launch_sum_sqrt(const double *partial, long np, double *result_dev, hipStream_t st)
+{
+    hipLaunchKernelGGL(sum_sqrt_kernel, dim3(1), dim3(256), 0, st, partial, np, result_dev);
+    LAUNCH_CHECK("sum_sqrt");
+}
+__global__ void axpy_scaled_kernel(double *x, const double *r, double c, long n)
+{
+    // relaxation.py:663,668 with one coefficient: h = c*r; x += h
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        double h = c * r[i];
+        x[i] = x[i] + h;
+    }
+}
+int launch_axpy_scaled(double *x, const double *r, double c, long n, hipStream_t st)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(axpy_scaled_kernel, dim3(vec_grid(n)), dim3(256), 0, st, x, r, c, n);
+    LAUNCH_CHECK("axpy_scaled");
 }
 
 int launch_norm2(const double *x, long n, double *scratch, double *result_dev, hipStream_t st)

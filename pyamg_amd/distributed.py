@@ -113,9 +113,12 @@ class HipBackend(object):
     def _p(t):
         return None if t is None else t.data_ptr()
 
-    def apply(self, m, mode, xg, b, v2, out, out2, c0):
+    def apply(self, m, mode, xg, b, v2, out, out2, c0, gscale=1.0):
         self._lib.check(self.L.amg_mat_apply(m, mode, self._p(xg), self._p(b), self._p(v2), self._p(out),
-                                             self._p(out2), float(c0), self.stream()))
+                                             self._p(out2), float(c0), float(gscale), self.stream()))
+
+    def axpy_scaled(self, x, r, c, n):
+        self._lib.check(self.L.amg_dev_axpy_scaled(x.data_ptr(), r.data_ptr(), float(c), int(n), self.stream()))
 
     def scale(self, out, inp, c, n):
         self._lib.check(self.L.amg_dev_scale(out.data_ptr(), inp.data_ptr(), float(c), int(n), self.stream()))
@@ -351,24 +354,29 @@ class DistributedSolver(object):
             return
         co = s["coefficients"]
         for _ in range(it):
+            # h = c0*r is gathered from r on the fly (one rounding either way); see hier.hip relax()
             x = getattr(lv, xname)
-            hh, hn = lv.h, lv.h2
             if x_zero:
                 rvec = bvec
-                self.be.scale(hh, bvec, co[0], n)
             else:
                 self.exchange(l, x)
-                self.be.apply(lv.A, POLY_FIRST, x, bvec, None, lv.r, hh, co[0])
+                self.be.apply(lv.A, RESIDUAL, x, bvec, None, lv.r, None, 0.0)
                 rvec = lv.r
             if len(co) == 1:
-                self.be.axpy(x, hh, n)
+                self.be.axpy_scaled(x, rvec, co[0], n)
             else:
-                for c in co[1:-1]:
+                self.exchange(l, rvec)
+                if len(co) == 2:
+                    self.be.apply(lv.A, POLY_LAST, rvec, rvec, x, x, None, co[1], co[0])
+                else:
+                    hh, hn = lv.h, lv.h2
+                    self.be.apply(lv.A, POLY_STEP, rvec, rvec, None, hh, None, co[1], co[0])
+                    for c in co[2:-1]:
+                        self.exchange(l, hh)
+                        self.be.apply(lv.A, POLY_STEP, hh, rvec, None, hn, None, c)
+                        hh, hn = hn, hh
                     self.exchange(l, hh)
-                    self.be.apply(lv.A, POLY_STEP, hh, rvec, None, hn, None, c)
-                    hh, hn = hn, hh
-                self.exchange(l, hh)
-                self.be.apply(lv.A, POLY_LAST, hh, rvec, x, x, None, co[-1])
+                    self.be.apply(lv.A, POLY_LAST, hh, rvec, x, x, None, co[-1])
             x_zero = False
 
     def coarse_solve(self):

@@ -30,9 +30,9 @@ class OracleBackend(object):
         return (int(nrows), int(ncols), np.ascontiguousarray(Ap, dtype=np.intc),
                 np.ascontiguousarray(Aj, dtype=np.intc), np.ascontiguousarray(Ax, dtype=np.float64))
 
-    def apply(self, m, mode, xg, b, v2, out, out2, c0):
+    def apply(self, m, mode, xg, b, v2, out, out2, c0, gscale=1.0):
         n, nc, Ap, Aj, Ax = m
-        xg_np = np.ascontiguousarray(xg.numpy()[:max(nc, 1)])
+        xg_np = np.ascontiguousarray(gscale * xg.numpy()[:max(nc, 1)])
         if mode in (JACOBI, JACOBI_BSR1):
             x = xg_np.copy()
             temp = xg_np.copy()
@@ -88,6 +88,9 @@ class OracleBackend(object):
 
     def scale(self, out, inp, c, n):
         out[:n] = torch.from_numpy(c * inp.numpy()[:n])
+
+    def axpy_scaled(self, x, r, c, n):
+        x[:n] = torch.from_numpy(x.numpy()[:n] + c * r.numpy()[:n])
 
     def axpy(self, x, h, n):
         x[:n] = torch.from_numpy(x.numpy()[:n] + h.numpy()[:n])
