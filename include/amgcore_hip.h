@@ -178,6 +178,13 @@ int amg_hier_finalize(amg_hier *h);
  * residuals must have room for maxiter+1 doubles; *nres = number written. */
 int amg_hier_solve(amg_hier *h, const double *b, double *x, double tol, int maxiter, int cycle,
                    double *residuals, int *nres, int flags);
+/* multilevel_solver.solve(b, x0, tol, maxiter, cycle, accel='cg'): conjugate gradients
+ * (pyamg/krylov/_cg.py:84-179) preconditioned by one cycle from a zero guess
+ * (aspreconditioner, multilevel.py:306-314), all vectors resident.  residuals (room for
+ * maxiter+1) receives the preconditioner-norm history sqrt(<r,Mr>); *info = 0, or -1 when
+ * an indefinite operator / preconditioner stops the iteration as in the reference. */
+int amg_hier_pcg(amg_hier *h, const double *b, double *x, double tol, int maxiter, int cycle,
+                 double *residuals, int *nres, int *info, int flags);
 /* one multilevel_solver.__solve(0, x, b, cycle) (multilevel.py:473-548) on
  * host (flags=0) or device (AMG_SOLVE_DEVICE_VECTORS) vectors */
 int amg_hier_cycle(amg_hier *h, const double *b, double *x, int cycle, int flags);

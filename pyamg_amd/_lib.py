@@ -83,6 +83,7 @@ def lib():
         "amg_hier_finalize": [V],
         "amg_hier_solve": [V, V, V, D, I, I, c_dbl_p, c_int_p, I],
         "amg_hier_cycle": [V, V, V, I, I],
+        "amg_hier_pcg": [V, V, V, D, I, I, c_dbl_p, c_int_p, c_int_p, I],
         "amg_hier_relax": [V, I, I, c_dbl_p, c_dbl_p],
         "amg_hier_matvec": [V, I, I, c_dbl_p, c_dbl_p],
         "amg_hier_time_spmv": [V, I, I, I, I, c_dbl_p],

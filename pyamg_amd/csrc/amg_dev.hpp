@@ -95,6 +95,7 @@ int launch_jacobi_rows(const DevCsr &A, const double *temp, const double *b, dou
 // ---------------------------------------------------------------- vector kernels
 int launch_scale(double *out, const double *in, double c, long n, hipStream_t st);          // out = c*in
 int launch_fill(double *out, double v, long n, hipStream_t st);                               // out = v
+int launch_scale_add(double *p, double beta, const double *z, long n, hipStream_t st);          // p = beta*p + z
 int launch_sor_combine(double *x, const double *xold, double omega, long n, hipStream_t st); // x = w*x + (1-w)*xold
 int launch_axpy_inplace(double *x, const double *h, long n, hipStream_t st);                 // x += h
 int launch_sub(double *out, const double *a, const double *b, long n, hipStream_t st);       // out = a - b

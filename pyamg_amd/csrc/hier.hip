@@ -684,6 +684,7 @@ void amg_hier_destroy(amg_hier *h)
     if (h->arn_coef) hipFree(h->arn_coef);
     if (h->norm_scratch) hipFree(h->norm_scratch);
     if (h->sumsq_partials) hipFree(h->sumsq_partials);
+    for (double *q : h->pcg) if (q) hipFree(q);
     if (h->res_dev) hipFree(h->res_dev);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
@@ -914,6 +915,7 @@ int amg_hier_finalize(amg_hier *h)
         long need = stream_blocks(a0) + 8;
         if (need > h->sumsq_cap) {
             if (h->sumsq_partials) hipFree(h->sumsq_partials);
+    for (double *q : h->pcg) if (q) hipFree(q);
             h->sumsq_partials = nullptr;
             CHK(dev_alloc(&h->sumsq_partials, need, &h->dev_bytes));
             h->sumsq_cap = need;
@@ -997,6 +999,96 @@ int amg_hier_solve(amg_hier *h, const double *b, double *x, double tol, int maxi
         AMG_HIP(hipMemcpyAsync(residuals + 1, h->res_dev + 1, sizeof(double) * (size_t)(k - 1), hipMemcpyDeviceToHost, st));
     *nres = k;
     CHK(store_x(h, x, flags));
+    float ms = 0.f;
+    AMG_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    h->last_ms = ms;
+    return 0;
+}
+
+// Preconditioned conjugate gradients with one multigrid cycle (from a zero guess) as M:
+// multilevel_solver.solve(accel='cg') = pyamg/krylov/_cg.py:84-179 with
+// M = aspreconditioner(cycle) (pyamg/multilevel.py:306-314), all vectors in HBM.  residuals[k] is the
+// preconditioner norm sqrt(<r_k, M r_k>) as in the reference.  *info: 0 converged / maxiter reached,
+// -1 indefinite operator or preconditioner (the reference warns and stops).
+int amg_hier_pcg(amg_hier *h, const double *b, double *x, double tol, int maxiter, int cyc,
+                 double *residuals, int *nres, int *info, int flags)
+{
+    ENTER(h);
+    if (!h->finalized) { set_error("hierarchy not finalised"); return AMG_ESTATE; }
+    if (!b || !x || !residuals || !nres || !info || maxiter < 1) { set_error("bad pcg arguments"); return AMG_EINVAL; }
+    if (cyc == AMG_CYCLE_AMLI) { set_error("AMLI cycles require fgmres or no acceleration"); return AMG_EINVAL; }
+    Level &L0 = h->lv[0];
+    hipStream_t st = h->stream;
+    const long n = L0.A.nrows;
+    const size_t bytes = sizeof(double) * (size_t)n;
+    for (int q = 0; q < 4; ++q)
+        if (!h->pcg[q]) CHK(dev_alloc(&h->pcg[q], n, &h->dev_bytes));
+    double *xk = h->pcg[0], *r = h->pcg[1], *p = h->pcg[2], *Ap = h->pcg[3];
+    double *slot = h->norm_scratch + 1026;
+    hipMemcpyKind in_kind = (flags & AMG_SOLVE_DEVICE_VECTORS) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    hipMemcpyKind out_kind = (flags & AMG_SOLVE_DEVICE_VECTORS) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    // b lives in Ap until r is formed, then in L0.r (kept for the periodic r = b - A x)
+    double *bdev = L0.r;
+    AMG_HIP(hipMemcpyAsync(bdev, b, bytes, in_kind, st));
+    if (flags & AMG_SOLVE_X0_ZERO) AMG_HIP(hipMemsetAsync(xk, 0, bytes, st));
+    else AMG_HIP(hipMemcpyAsync(xk, x, bytes, in_kind, st));
+    auto fetch = [&](double *dst) -> int {
+        AMG_HIP(hipMemcpyAsync(dst, slot, sizeof(double), hipMemcpyDeviceToHost, st));
+        AMG_HIP(hipStreamSynchronize(st));
+        return 0;
+    };
+    auto dot = [&](const double *u, const double *v, double *out) -> int {
+        CHK(launch_dot(u, v, n, h->norm_scratch, slot, st));
+        return fetch(out);
+    };
+    auto precond = [&](const double *rhs) -> int {      // z = M rhs -> L0.x
+        AMG_HIP(hipMemsetAsync(L0.x, 0, bytes, st));
+        if (h->nlevels == 1) return coarse_solve(h, rhs, L0.x, L0.xalt);
+        return cycle(h, 0, L0.x, L0.xalt, rhs, cyc, true);
+    };
+    int k = 0;
+    *info = 0;
+    CHK(spmv(L0.A, SM_RESIDUAL, xk, bdev, nullptr, r, nullptr, 0.0, st));          // r = b - A x
+    CHK(precond(r));                                                              // z = M r
+    AMG_HIP(hipMemcpyAsync(p, L0.x, bytes, hipMemcpyDeviceToDevice, st));          // p = z.copy()
+    double rz = 0.0, normb = 0.0;
+    CHK(dot(r, L0.x, &rz));
+    double normr = std::sqrt(rz);
+    residuals[k++] = normr;
+    CHK(launch_norm2(bdev, n, h->norm_scratch, slot, st));
+    CHK(fetch(&normb));
+    if (normb == 0.0) normb = 1.0;
+    bool done = normr < tol * normb;
+    if (!done && normr != 0.0) tol = tol * normr;
+    const int recompute_r = 8;
+    int iter = 0;
+    AMG_HIP(hipEventRecord(h->ev0, st));
+    while (!done) {
+        CHK(spmv(L0.A, SM_MATVEC, p, nullptr, nullptr, Ap, nullptr, 0.0, st));     // Ap = A p
+        const double rz_old = rz;
+        double pAp = 0.0;
+        CHK(dot(Ap, p, &pAp));
+        if (pAp < 0.0) { *info = -1; break; }
+        const double alpha = rz / pAp;
+        CHK(launch_axmy(xk, p, -alpha, n, st));                                    // x += alpha p
+        if ((iter % recompute_r) && iter > 0) CHK(launch_axmy(r, Ap, alpha, n, st));   // r -= alpha Ap
+        else CHK(spmv(L0.A, SM_RESIDUAL, xk, bdev, nullptr, r, nullptr, 0.0, st));
+        CHK(precond(r));
+        CHK(dot(r, L0.x, &rz));
+        if (rz < 0.0) { *info = -1; break; }
+        const double beta = rz / rz_old;
+        CHK(launch_scale_add(p, beta, L0.x, n, st));                               // p = beta p + z
+        ++iter;
+        normr = std::sqrt(rz);
+        if (k <= maxiter) residuals[k++] = normr;
+        if (normr < tol) break;
+        if (rz == 0.0) { *info = -1; break; }
+        if (iter >= maxiter) break;                                               // scipy-style cap (the reference has none)
+    }
+    AMG_HIP(hipEventRecord(h->ev1, st));
+    *nres = k;
+    AMG_HIP(hipMemcpyAsync(x, xk, bytes, out_kind, st));
+    AMG_HIP(hipStreamSynchronize(st));
     float ms = 0.f;
     AMG_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1));
     h->last_ms = ms;

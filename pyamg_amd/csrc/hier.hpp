@@ -89,6 +89,7 @@ struct amg_hier {
     amg::Smoother coarse_sm;
     // scratch
     double *norm_scratch = nullptr;   // 1024 partials
+    double *pcg[4] = {nullptr, nullptr, nullptr, nullptr};   // x, r, p, A*p of the device PCG (lazily)
     double *sumsq_partials = nullptr; // one partial per workgroup of the level-0 residual kernel
     long sumsq_cap = 0;
     double *res_dev = nullptr;        // residual history on device

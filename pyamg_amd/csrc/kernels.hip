@@ -424,6 +424,20 @@ int launch_fill(double *out, double v, long n, hipStream_t st)
     hipLaunchKernelGGL(fill_kernel, dim3(vec_grid(n)), dim3(256), 0, st, out, v, n);
     LAUNCH_CHECK("fill");
 }
+__global__ void scale_add_kernel(double *p, double beta, const double *z, long n)
+{
+    // krylov/_cg.py:155-156: p *= beta; p += z
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        double t = p[i] * beta;
+        p[i] = t + z[i];
+    }
+}
+int launch_scale_add(double *p, double beta, const double *z, long n, hipStream_t st)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(scale_add_kernel, dim3(vec_grid(n)), dim3(256), 0, st, p, beta, z, n);
+    LAUNCH_CHECK("scale_add");
+}
 int launch_sor_combine(double *x, const double *xold, double omega, long n, hipStream_t st)
 {
     if (n <= 0) return 0;

@@ -147,6 +147,14 @@ class _DeviceHierarchy(object):
                                          _CYCLE[cycle], _lib.dp(res), _lib.C.byref(nres), flags))
         return res[:nres.value]
 
+    def pcg(self, b, x, tol, maxiter, cycle, x0_zero=False):
+        res = np.zeros(maxiter + 2, dtype=np.float64)
+        nres, info = _lib.C.c_int(0), _lib.C.c_int(0)
+        _lib.check(self.L.amg_hier_pcg(self.h, b.ctypes.data, x.ctypes.data, float(tol), int(maxiter),
+                                       _CYCLE[cycle], _lib.dp(res), _lib.C.byref(nres), _lib.C.byref(info),
+                                       _X0_ZERO if x0_zero else 0))
+        return res[:nres.value], info.value
+
     def cycle(self, b, x, cycle, x0_zero=False):
         _lib.check(self.L.amg_hier_cycle(self.h, b.ctypes.data, x.ctypes.data, _CYCLE[cycle],
                                          _X0_ZERO if x0_zero else 0))
@@ -363,6 +371,19 @@ class multilevel_solver:
         scipy.sparse.linalg interface, :404-422)."""
         if (accel != "fgmres") and (cycle == "AMLI"):
             raise ValueError("AMLI cycles require acceleration (accel) to be fgmres, or no acceleration")
+        if accel == "cg" and callback is None:
+            # device-resident PCG (pyamg/krylov/_cg.py semantics, preconditioner-norm history)
+            n = self.levels[0].A.shape[0]
+            b1 = np.ascontiguousarray(np.ravel(b), dtype=np.float64)
+            x1 = np.zeros(n) if x0 is None else np.ascontiguousarray(np.ravel(np.array(x0)), dtype=np.float64)
+            if maxiter is None:
+                maxiter = int(1.3 * n) + 2
+            res, info = self.device_hierarchy().pcg(b1, x1, tol, maxiter, cycle, x0_zero=not np.any(x1))
+            if info < 0:
+                warn("Indefinite matrix or preconditioner detected in CG, aborting")
+            if residuals is not None:
+                residuals[:] = [float(r) for r in res]
+            return x1.reshape(np.asarray(b).shape)
         import scipy.sparse.linalg as spla
         if isinstance(accel, str):
             if not hasattr(spla, accel):

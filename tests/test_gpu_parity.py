@@ -360,3 +360,32 @@ def test_full_cycle_at_scale_vs_oracle(smoother):
     bs_ = A * xs
     y = ml.solve(bs_, x0=xs, tol=0.0, maxiter=1)
     assert np.linalg.norm(y - xs) <= 1e-10 * np.linalg.norm(xs)
+
+
+def test_device_pcg_matches_reference_cg_semantics():
+    """solve(accel='cg') on the device vs a host restatement of pyamg/krylov/_cg.py:84-179 whose
+    preconditioner is the oracle's cycle from zero; dots are BLAS / tree / numpy sums, so the bar is
+    1e-10 relative on the preconditioner-norm history."""
+    g = golden_io.load_hier("sa_cheb2_3d")
+    ml = golden_io.build_ml(g)
+    A = g["levels"][0]["A"]; b = g["b"]
+    res = []
+    x = ml.solve(b, tol=1e-10, maxiter=40, accel="cg", residuals=res)
+    H = oracle_lib.Hierarchy(g["levels"], g["coarse_pinv"])
+
+    def M(r):
+        z = np.zeros_like(r); H.cycle(z, np.ascontiguousarray(r), "V"); return z
+    xr = np.zeros_like(b); r = b - A * xr; z = M(r); p = z.copy(); rz = np.inner(r, z)
+    hist = [np.sqrt(rz)]; tol = 1e-10 * hist[0]; it = 0
+    while True:
+        Ap = A * p; rz_old = rz; alpha = rz / np.inner(Ap, p); xr += alpha * p
+        r = r - alpha * Ap if (it % 8 and it > 0) else b - A * xr
+        z = M(r); rz = np.inner(r, z); p = p * (rz / rz_old) + z; it += 1
+        hist.append(np.sqrt(rz))
+        if hist[-1] < tol or it >= 40:
+            break
+    assert len(res) == len(hist)
+    assert np.allclose(res, hist, rtol=1e-9, atol=1e-14 * hist[0])
+    assert np.linalg.norm(x - xr) <= 1e-9 * np.linalg.norm(xr)
+    assert np.linalg.norm(b - A * x) <= 1e-8 * np.linalg.norm(b)
+    assert len(res) < 0.5 * len(g["residuals"])          # CG needs far fewer cycles than the stand-alone iteration
