@@ -1027,8 +1027,9 @@ int amg_hier_pcg(amg_hier *h, const double *b, double *x, double tol, int maxite
     double *slot = h->norm_scratch + 1026;
     hipMemcpyKind in_kind = (flags & AMG_SOLVE_DEVICE_VECTORS) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     hipMemcpyKind out_kind = (flags & AMG_SOLVE_DEVICE_VECTORS) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
-    // b lives in Ap until r is formed, then in L0.r (kept for the periodic r = b - A x)
-    double *bdev = L0.r;
+    // b is kept in L0.b (the cycle is always called with rhs = r, so L0.b is free; L0.r is the
+    // cycle's own residual scratch and must not be used here)
+    double *bdev = L0.b;
     AMG_HIP(hipMemcpyAsync(bdev, b, bytes, in_kind, st));
     if (flags & AMG_SOLVE_X0_ZERO) AMG_HIP(hipMemsetAsync(xk, 0, bytes, st));
     else AMG_HIP(hipMemcpyAsync(xk, x, bytes, in_kind, st));
