@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libamgcore_hip.so")
+LIB_PATH = os.environ.get("AMGCORE_HIP_LIB") or os.path.join(HERE, "lib", "libamgcore_hip.so")   # env: A/B builds
 
 c_int_p = C.POINTER(C.c_int)
 c_dbl_p = C.POINTER(C.c_double)

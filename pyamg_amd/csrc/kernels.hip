@@ -19,7 +19,31 @@
 namespace amg {
 
 constexpr int WG = 256;      // threads = rows per workgroup
-constexpr int TILE = 2048;   // products staged in LDS per pass (16 KiB)
+#ifndef AMG_TILE
+#define AMG_TILE 2048
+#endif
+constexpr int TILE = AMG_TILE;   // products staged in LDS per pass (16 KiB at 2048)
+
+// 16-byte loads of the matrix stream; AMG_NT_LOADS marks them non-temporal (streamed once: keep
+// the gathered vector, not the matrix, in L2 / Infinity Cache)
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v4i load_v4i(const int *p)
+{
+#ifdef AMG_NT_LOADS
+    return __builtin_nontemporal_load(reinterpret_cast<const v4i *>(p));
+#else
+    return *reinterpret_cast<const v4i *>(p);
+#endif
+}
+__device__ __forceinline__ v2d load_v2d(const double *p)
+{
+#ifdef AMG_NT_LOADS
+    return __builtin_nontemporal_load(reinterpret_cast<const v2d *>(p));
+#else
+    return *reinterpret_cast<const v2d *>(p);
+#endif
+}
 
 static int g_stream_variant = 1;
 static int g_xcd_chunk = 32;   // consecutive row blocks per XCD (PMC: -15 % L2-miss traffic, time -1..2 %)
@@ -119,20 +143,21 @@ __global__ __launch_bounds__(WG) void csr_stream_kernel(StreamArgs a, int xcd_ch
     for (int tile_lo = abeg; tile_lo < kend; tile_lo += TILE) {
         const int tile_hi = min(tile_lo + TILE, kend);
         if (VEC) {
-            // each thread: 2 quads of 4 consecutive entries
-            int e[2];
-            int4 cj[2];
-            double2 av[2][2];
-            bool full[2], any[2];
+            // each thread: NQ quads of 4 consecutive entries
+            constexpr int NQ = TILE / (4 * WG);
+            int e[NQ];
+            v4i cj[NQ];
+            v2d av[NQ][2];
+            bool full[NQ], any[NQ];
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
+            for (int p = 0; p < NQ; ++p) {
                 e[p] = tile_lo + p * (4 * WG) + 4 * t;
                 any[p] = e[p] < tile_hi;
                 full[p] = any[p] && ((long)e[p] + 4 <= nnz_total);
                 if (full[p]) {
-                    cj[p] = *reinterpret_cast<const int4 *>(a.Aj + e[p]);
-                    av[p][0] = *reinterpret_cast<const double2 *>(a.Ax + e[p]);
-                    av[p][1] = *reinterpret_cast<const double2 *>(a.Ax + e[p] + 2);
+                    cj[p] = load_v4i(a.Aj + e[p]);
+                    av[p][0] = load_v2d(a.Ax + e[p]);
+                    av[p][1] = load_v2d(a.Ax + e[p] + 2);
                 } else if (any[p]) {
                     int c[4]; double v[4];
 #pragma unroll
@@ -141,13 +166,13 @@ __global__ __launch_bounds__(WG) void csr_stream_kernel(StreamArgs a, int xcd_ch
                         c[u] = ok ? a.Aj[e[p] + u] : 0;
                         v[u] = ok ? a.Ax[e[p] + u] : 0.0;
                     }
-                    cj[p] = make_int4(c[0], c[1], c[2], c[3]);
-                    av[p][0] = make_double2(v[0], v[1]);
-                    av[p][1] = make_double2(v[2], v[3]);
+                    cj[p] = v4i{c[0], c[1], c[2], c[3]};
+                    av[p][0] = v2d{v[0], v[1]};
+                    av[p][1] = v2d{v[2], v[3]};
                 }
             }
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
+            for (int p = 0; p < NQ; ++p) {
                 if (!any[p]) continue;
                 int c[4] = {cj[p].x, cj[p].y, cj[p].z, cj[p].w};
                 double v[4] = {av[p][0].x, av[p][0].y, av[p][1].x, av[p][1].y};

@@ -179,7 +179,8 @@ class DistributedSolver(object):
     host_group : group able to move CPU tensors (gloo) for the setup-time index exchange
     """
 
-    def __init__(self, levels, coarse_dense, backend, rank, world, group=None, host_group=None):
+    def __init__(self, levels, coarse_dense, backend, rank, world, group=None, host_group=None,
+                 replicate_below=500000):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -188,6 +189,19 @@ class DistributedSolver(object):
         self.group, self.host_group = group, host_group if host_group is not None else group
         self.nlevels = len(levels)
         self.bounds = [split_rows(L["A"].shape[0], world) for L in levels]
+        # Coarse levels at or below `replicate_below` unknowns are REPLICATED: every rank holds them
+        # whole and computes them redundantly (bit-identical everywhere), so they need no halo
+        # exchange at all -- one all-gather of the restricted right-hand side enters the replicated
+        # part of the hierarchy, nothing is needed to leave it.  Exchange latency, not bandwidth,
+        # is what the small levels cost.
+        sizes = [L["A"].shape[0] for L in levels]
+        self.first_rep = self.nlevels
+        if world > 1:
+            for l in range(self.nlevels - 1, 0, -1):
+                if sizes[l] <= replicate_below:
+                    self.first_rep = l
+                else:
+                    break
         self.lv = []
         self._build(levels, coarse_dense)
 
@@ -196,14 +210,22 @@ class DistributedSolver(object):
         torch, dist = self.torch, self.dist
         r, W = self.rank, self.world
         nl = self.nlevels
-        own = [(int(b[r]), int(b[r + 1])) for b in self.bounds]
+        fr = self.first_rep
+        own = [(int(b[r]), int(b[r + 1])) if l < fr else (0, int(b[-1])) for l, b in enumerate(self.bounds)]
+        # rows of R_l a rank computes: its slice of the coarse rows, also at the transition into the
+        # replicated part (the slices are then all-gathered); everything inside the replicated part
+        rrows = [((int(self.bounds[l + 1][r]), int(self.bounds[l + 1][r + 1])) if l + 1 <= fr else own[l + 1])
+                 for l in range(nl - 1)]
+        if fr < nl and fr >= 1:
+            rrows[fr - 1] = (int(self.bounds[fr][r]), int(self.bounds[fr][r + 1]))
+        self.rrows = rrows
         loc = []
         for l, L in enumerate(levels):
             d = {"A": local_rows(L["A"], *own[l])}
             d["bsr"] = bool(_csr_view(L["A"])[3])
             if l < nl - 1:
                 d["P"] = local_rows(L["P"], *own[l])            # fine rows, coarse columns (V_{l+1})
-                d["R"] = local_rows(L["R"], *own[l + 1])        # coarse rows, fine columns (V_l)
+                d["R"] = local_rows(L["R"], *rrows[l])          # coarse rows, fine columns (V_l)
             loc.append(d)
         # union halo of every vector space
         halos = []
@@ -273,7 +295,8 @@ class DistributedSolver(object):
                 Pp, Pj, Px = loc[l]["P"]
                 lv.P = self.be.mat(lv.n_own, nxt.n_own + nxt.n_halo, Pp, renum(Pj, l + 1), Px)
                 Rp, Rj, Rx = loc[l]["R"]
-                lv.R = self.be.mat(nxt.n_own, n_ext, Rp, renum(Rj, l), Rx)
+                lv.R = self.be.mat(rrows[l][1] - rrows[l][0], n_ext, Rp, renum(Rj, l), Rx)
+                lv.rslice = self.be.vec(rrows[l][1] - rrows[l][0]) if (l + 1 == fr and W > 1) else None
                 lv.pre, lv.post = L.get("pre"), L.get("post")
                 for s in (lv.pre, lv.post):
                     nm = None if s is None else s.get("name")
@@ -333,6 +356,7 @@ class DistributedSolver(object):
         it = int(s.get("iterations", 1))
         if s["name"] in ("gauss_seidel", "gauss_seidel_indexed"):
             # hybrid sweep: halo refreshed once per directional sweep and frozen during it
+            # (on a replicated level there is no halo and the sweep is the exact sequential one)
             x = getattr(lv, xname)
             bsr1 = lv.A_bsr and s["name"] == "gauss_seidel"
             sweep = s.get("sweep", "forward")
@@ -385,6 +409,10 @@ class DistributedSolver(object):
             self.be.zero(lv.x, lv.n_own)
             return
         nc = self.nc
+        if self.first_rep <= self.nlevels - 1:
+            # the coarsest level is replicated: b is already whole on every rank
+            self.be.dense(self.coarse_Mt, lv.b, lv.x, nc)
+            return
         if self.world > 1:
             counts = [int(self.bounds[-1][p + 1] - self.bounds[-1][p]) for p in range(self.world)]
             self._all_gather_uneven(lv.b[:lv.n_own], counts)
@@ -394,11 +422,12 @@ class DistributedSolver(object):
         lo = int(self.bounds[-1][self.rank])
         lv.x[:lv.n_own].copy_(self.coarse_full_x[lo:lo + lv.n_own])
 
-    def _all_gather_uneven(self, mine, counts):
+    def _all_gather_uneven(self, mine, counts, out=None):
         # all_to_all with every rank sending its whole slice to everybody
         W = self.world
         inp = mine.repeat(W) if mine.numel() else mine
-        out = self.coarse_full_b[:self.nc]
+        if out is None:
+            out = self.coarse_full_b[:self.nc]
         self.dist.all_to_all_single(out, inp, counts, [int(mine.numel())] * W, group=self.group)
 
     # ------------------------------------------------------------------ cycle (multilevel.py:473-548)
@@ -408,7 +437,14 @@ class DistributedSolver(object):
         self.exchange(l, lv.x)
         self.be.apply(lv.A, RESIDUAL, lv.x, lv.b, None, lv.r, None, 0.0)
         self.exchange(l, lv.r)
-        self.be.apply(lv.R, MATVEC, lv.r, None, None, nx.b, None, 0.0)
+        if lv.rslice is not None:
+            # entering the replicated part: each rank restricts its slice of the coarse rows, then all gather
+            self.be.apply(lv.R, MATVEC, lv.r, None, None, lv.rslice, None, 0.0)
+            counts = [int(self.bounds[l + 1][p + 1] - self.bounds[l + 1][p]) for p in range(self.world)]
+            lo_, hi_ = self.rrows[l]
+            self._all_gather_uneven(lv.rslice[:hi_ - lo_], counts, out=nx.b[:nx.n_own])
+        else:
+            self.be.apply(lv.R, MATVEC, lv.r, None, None, nx.b, None, 0.0)
         self.be.zero(nx.x, nx.n_own)
         if l == self.nlevels - 2:
             self.coarse_solve()

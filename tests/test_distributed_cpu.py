@@ -20,7 +20,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, case, cycle, out_dir):
+def _worker(rank, world, port, case, cycle, out_dir, replicate_below=0):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -34,7 +34,7 @@ def _worker(rank, world, port, case, cycle, out_dir):
             save_levels(shared, g["levels"], g["coarse_pinv"])
         dist.barrier()
         levels, coarse = load_levels(shared)
-        S = DistributedSolver(levels, coarse, OracleBackend(), rank, world)
+        S = DistributedSolver(levels, coarse, OracleBackend(), rank, world, replicate_below=replicate_below)
         n = g["levels"][0]["A"].shape[0]
         bnd = split_rows(n, world)
         lo, hi = int(bnd[rank]), int(bnd[rank + 1])
@@ -48,9 +48,10 @@ def _worker(rank, world, port, case, cycle, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case,world", [("sa_jacobi_2d", 2), ("sa_cheb2_3d", 2), ("sa_cheb2_3d", 3),
-                                        ("sa_mixed_W_2d", None)])
-def test_partitioned_cycle_equals_single_process(case, world, tmp_path):
+@pytest.mark.parametrize("case,world,rep", [("sa_jacobi_2d", 2, 0), ("sa_cheb2_3d", 2, 0), ("sa_cheb2_3d", 3, 0),
+                                            ("sa_jacobi_2d", 2, 300), ("sa_cheb2_3d", 3, 600), ("sa_cheb2_3d", 2, 20),
+                                            ("sa_mixed_W_2d", None, 0)])
+def test_partitioned_cycle_equals_single_process(case, world, rep, tmp_path):
     g = golden_io.load_hier(case)
     m = g["meta"]
     if world is None:
@@ -61,7 +62,9 @@ def test_partitioned_cycle_equals_single_process(case, world, tmp_path):
             DistributedSolver(g["levels"], g["coarse_pinv"], OracleBackend(), 0, 1)
         return
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, case, m["cycle"], str(tmp_path)), nprocs=world, join=True)
+    # rep = replicate_below: 0 partitions every level; larger values replicate the coarse levels
+    # (sa_jacobi_2d: 2304/392/49/6 rows; sa_cheb2_3d: 4096/517/13)
+    mp.spawn(_worker, args=(world, port, case, m["cycle"], str(tmp_path), rep), nprocs=world, join=True)
     x = np.concatenate([np.load(tmp_path / ("x_%d.npy" % r)) for r in range(world)])
     res = np.load(tmp_path / "res.npy")
     H = oracle_lib.Hierarchy(g["levels"], g["coarse_pinv"])
@@ -133,14 +136,14 @@ def _hybrid_cycle(lib, levels, coarse, bounds, l, x, b):
                 _hybrid_sweep(lib, A, x, b, bounds[l], True, bsr)
 
 
-def _worker_hybrid(rank, world, port, case, out_dir):
+def _worker_hybrid(rank, world, port, case, out_dir, rep=0):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from cpu_backend import OracleBackend
         from pyamg_amd.distributed import DistributedSolver, split_rows
         g = golden_io.load_hier(case)
-        S = DistributedSolver(g["levels"], g["coarse_pinv"], OracleBackend(), rank, world)
+        S = DistributedSolver(g["levels"], g["coarse_pinv"], OracleBackend(), rank, world, replicate_below=rep)
         n = g["levels"][0]["A"].shape[0]
         bnd = split_rows(n, world); lo, hi = int(bnd[rank]), int(bnd[rank + 1])
         x, res = S.solve(g["b"][lo:hi], None, tol=0.0, maxiter=3, cycle="V", fixed=True)
@@ -149,15 +152,28 @@ def _worker_hybrid(rank, world, port, case, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case", ["sa_gs_3d", "rs_gs_2d"])
-def test_hybrid_gauss_seidel_matches_partition_emulation(case, tmp_path):
+def hybrid_bounds(g, world, rep):
+    """partition of every level as DistributedSolver makes it: split rows, except that levels at or
+    below `rep` unknowns (from the first such level down) are replicated = one block"""
     from pyamg_amd.distributed import split_rows
+    sizes = [L["A"].shape[0] for L in g["levels"]]
+    first_rep = len(sizes)
+    for l in range(len(sizes) - 1, 0, -1):
+        if sizes[l] <= rep:
+            first_rep = l
+        else:
+            break
+    return [split_rows(n, world) if l < first_rep else np.array([0, n]) for l, n in enumerate(sizes)]
+
+
+@pytest.mark.parametrize("case,rep", [("sa_gs_3d", 0), ("rs_gs_2d", 0), ("rs_gs_2d", 450)])
+def test_hybrid_gauss_seidel_matches_partition_emulation(case, rep, tmp_path):
     world = 2
     g = golden_io.load_hier(case)
-    mp.spawn(_worker_hybrid, args=(world, _free_port(), case, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker_hybrid, args=(world, _free_port(), case, str(tmp_path), rep), nprocs=world, join=True)
     x = np.concatenate([np.load(tmp_path / ("x_%d.npy" % r)) for r in range(world)])
     lib = oracle_lib.load()
-    bounds = [split_rows(L["A"].shape[0], world) for L in g["levels"]]
+    bounds = hybrid_bounds(g, world, rep)
     xe = np.zeros_like(g["b"])
     for _ in range(3):
         _hybrid_cycle(lib, g["levels"], g["coarse_pinv"], bounds, 0, xe, np.ascontiguousarray(g["b"]))

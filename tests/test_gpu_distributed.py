@@ -25,7 +25,8 @@ def _worker(rank, world, port, case, out_dir):
     try:
         from pyamg_amd.distributed import DistributedSolver, HipBackend, split_rows
         g = golden_io.load_hier(case)
-        S = DistributedSolver(g["levels"], g["coarse_pinv"], HipBackend(0), rank, world)
+        S = DistributedSolver(g["levels"], g["coarse_pinv"], HipBackend(0), rank, world,
+                              replicate_below=(0 if case == "sa_jacobi_2d" else 600))
         n = g["levels"][0]["A"].shape[0]
         bnd = split_rows(n, world)
         lo, hi = int(bnd[rank]), int(bnd[rank + 1])
@@ -56,14 +57,14 @@ def test_two_ranks_equal_single_gpu(case, tmp_path):
     assert len(rf) == 6 and np.allclose(rf, res1[:6], rtol=1e-12, atol=1e-13 * res1[0])
 
 
-def _worker_hybrid(rank, world, port, case, out_dir):
+def _worker_hybrid(rank, world, port, case, out_dir, rep=0):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from pyamg_amd.distributed import DistributedSolver, HipBackend, split_rows
         g = golden_io.load_hier(case)
-        S = DistributedSolver(g["levels"], g["coarse_pinv"], HipBackend(0), rank, world)
+        S = DistributedSolver(g["levels"], g["coarse_pinv"], HipBackend(0), rank, world, replicate_below=rep)
         n = g["levels"][0]["A"].shape[0]
         bnd = split_rows(n, world)
         lo, hi = int(bnd[rank]), int(bnd[rank + 1])
@@ -73,19 +74,19 @@ def _worker_hybrid(rank, world, port, case, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case", ["sa_gs_3d", "rs_gs_2d"])
-def test_hybrid_gauss_seidel_on_gpu_matches_partition_emulation(case, tmp_path):
+@pytest.mark.parametrize("case,rep", [("sa_gs_3d", 0), ("rs_gs_2d", 450)])
+def test_hybrid_gauss_seidel_on_gpu_matches_partition_emulation(case, rep, tmp_path):
     """C4's smoother: GS inside a rank (level-scheduled HIP kernels), Jacobi across ranks; oracle =
     the partition-emulating CPU run (tests/test_distributed_cpu.py)."""
     import oracle_lib
     from pyamg_amd.distributed import split_rows
-    from test_distributed_cpu import _hybrid_cycle
+    from test_distributed_cpu import _hybrid_cycle, hybrid_bounds
     world = 2
     g = golden_io.load_hier(case)
-    mp.spawn(_worker_hybrid, args=(world, _free_port(), case, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker_hybrid, args=(world, _free_port(), case, str(tmp_path), rep), nprocs=world, join=True)
     x = np.concatenate([np.load(tmp_path / ("x_%d.npy" % r)) for r in range(world)])
     lib = oracle_lib.load()
-    bounds = [split_rows(L["A"].shape[0], world) for L in g["levels"]]
+    bounds = hybrid_bounds(g, world, rep)
     xe = np.zeros_like(g["b"])
     for _ in range(3):
         _hybrid_cycle(lib, g["levels"], g["coarse_pinv"], bounds, 0, xe, np.ascontiguousarray(g["b"]))

@@ -17,7 +17,7 @@ op = _DeviceOperator(A)
 _lib.check(L.amg_hier_finalize(op.h))
 print("grid %d  n=%d nnz=%d  bytes/app=%.3f GB" % (grid, n, A.nnz, bytes_app / 1e9))
 for variant in (0, 1):
-    for chunk in (0, 1, 4, 16, 64, 256):
+    for chunk in (0, 16, 64):
         L.amg_set_stream_variant(variant); L.amg_set_xcd_chunk(chunk)
         ms = C.c_double()
         for mode in (0, 1):
