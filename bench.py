@@ -143,6 +143,22 @@ def partitioned_main(args, rank, local_rank, world, torch, dist):
     if rank == 0:
         shutil.rmtree(shared, ignore_errors=True)
 
+    # self-check of the overlapped exchange on THIS machine: one cycle with and without it must give
+    # bit-identical iterates on every rank; otherwise fall back to the plain exchange
+    lv0 = S.lv[0]
+    S.overlap = False
+    S.run_fixed(1, "V", x_zero=True)
+    xa = lv0.x[:lv0.n_own].clone()
+    S.set_problem(np.asarray(b), None)
+    S.overlap = True
+    S.run_fixed(1, "V", x_zero=True)
+    same = torch.tensor([1.0 if torch.equal(xa, lv0.x[:lv0.n_own]) else 0.0], dtype=torch.float64)
+    dist.all_reduce(same, op=dist.ReduceOp.MIN, group=host_group)
+    if same.item() < 0.5:
+        log("[bench] overlapped exchange disagreed with the plain one: disabled")
+        S.overlap = False
+    del xa
+    S.set_problem(np.asarray(b), None)
     r0 = S.residual_norm()
     warm = S.run_fixed(args.warmup, "V", x_zero=True)
     torch.cuda.synchronize(); dist.barrier(group=host_group); torch.cuda.synchronize()
@@ -178,6 +194,8 @@ def partitioned_main(args, rank, local_rank, world, torch, dist):
                        "parallelism": "rows of every level partitioned over %d GPUs, halo exchange + residual "
                                       "all-reduce over %s" % (world, transport),
                        "levels": shape_info, "halo_per_level_rank0": [lv_.n_halo for lv_ in S.lv],
+                       "replicated_from_level": S.first_rep,
+                       "exchange_overlapped_levels": [int(S.overlap and lv_.overlap) for lv_ in S.lv],
                        "setup_seconds": {"matrix": round(t_gen, 1), "hierarchy": round(t_setup, 1)},
                        "residuals": [r0, warm[-1] if warm else r0, timed[-1]]},
             "roofline": {"bound": "hbm", "kernel": "csr_stream_kernel (level-0 A-application on rank 0's row block)",

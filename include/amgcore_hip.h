@@ -229,6 +229,9 @@ long amg_mat_nnz(amg_mat *m);
  * xg is the gathered vector (owned entries followed by the halo) */
 int amg_mat_apply(amg_mat *m, int mode, const double *xg, const double *b, const double *v2, double *out,
                   double *out2, double c0, double gscale, void *stream);   /* products are a_ij*(gscale*xg_j); 0 = 1 */
+/* the same launch over rows [row_lo, row_hi) only (interior rows first, boundary rows after the halo arrived) */
+int amg_mat_apply_rows(amg_mat *m, int mode, int row_lo, int row_hi, const double *xg, const double *b,
+                       const double *v2, double *out, double *out2, double c0, double gscale, void *stream);
 /* Gauss-Seidel over the operator's own rows (order NULL: 0..nrows-1, else an index list as for
  * gauss_seidel_indexed); columns >= nrows (halo) stay frozen: GS inside a rank, Jacobi across */
 int amg_mat_build_gs(amg_mat *m, const int *order, int norder);

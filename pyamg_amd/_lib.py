@@ -89,6 +89,7 @@ def lib():
         "amg_hier_time_spmv": [V, I, I, I, I, c_dbl_p],
         "amg_hier_time_relax": [V, I, I, I, c_dbl_p],
         "amg_mat_apply": [V, I, V, V, V, V, V, D, D, V],
+        "amg_mat_apply_rows": [V, I, I, I, V, V, V, V, V, D, D, V],
         "amg_dev_axpy_scaled": [V, V, D, C.c_long, V],
         "amg_mat_build_gs": [V, c_int_p, I],
         "amg_mat_gs_sweep": [V, V, V, I, I, V],

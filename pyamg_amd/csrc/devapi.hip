@@ -110,6 +110,23 @@ int amg_mat_apply(amg_mat *m, int mode, const double *xg, const double *b, const
     return launch_stream((StreamMode)mode, a, (hipStream_t)stream);
 }
 
+// the same launch restricted to rows [row_lo, row_hi): lets a partitioned driver run the rows that
+// read no halo entry while the halo exchange is still in flight
+int amg_mat_apply_rows(amg_mat *m, int mode, int row_lo, int row_hi, const double *xg, const double *b,
+                       const double *v2, double *out, double *out2, double c0, double gscale, void *stream)
+{
+    if (!m) { set_error("null matrix"); return AMG_EINVAL; }
+    if (mode < 0 || mode > SM_JACOBI_BSR1) { set_error("bad mode"); return AMG_EINVAL; }
+    if (row_lo < 0 || row_hi > m->M.nrows || row_lo > row_hi) { set_error("bad row range"); return AMG_EINVAL; }
+    AMG_HIP(hipSetDevice(m->device));
+    StreamArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.Ap = m->M.Ap; a.Aj = m->M.Aj; a.Ax = m->M.Ax;
+    a.row_lo = row_lo; a.row_hi = row_hi; a.nnz_total = m->M.nnz; a.rows_per_wg = m->rpw;
+    a.xg = xg; a.b = b; a.v2 = v2; a.out = out; a.out2 = out2; a.c0 = c0; a.gscale = gscale;
+    return launch_stream((StreamMode)mode, a, (hipStream_t)stream);
+}
+
 int amg_dev_scale(double *out, const double *in, double c, long n, void *stream)
 { return launch_scale(out, in, c, n, (hipStream_t)stream); }
 int amg_dev_axpy(double *x, const double *h, long n, void *stream)

@@ -117,6 +117,12 @@ class HipBackend(object):
         self._lib.check(self.L.amg_mat_apply(m, mode, self._p(xg), self._p(b), self._p(v2), self._p(out),
                                              self._p(out2), float(c0), float(gscale), self.stream()))
 
+    def apply_rows(self, m, mode, lo, hi, xg, b, v2, out, out2, c0, gscale=1.0):
+        if hi > lo:
+            self._lib.check(self.L.amg_mat_apply_rows(m, mode, int(lo), int(hi), self._p(xg), self._p(b), self._p(v2),
+                                                      self._p(out), self._p(out2), float(c0), float(gscale),
+                                                      self.stream()))
+
     def axpy_scaled(self, x, r, c, n):
         self._lib.check(self.L.amg_dev_axpy_scaled(x.data_ptr(), r.data_ptr(), float(c), int(n), self.stream()))
 
@@ -187,6 +193,8 @@ class DistributedSolver(object):
         self.be = backend
         self.rank, self.world = rank, world
         self.group, self.host_group = group, host_group if host_group is not None else group
+        import os as _os
+        self.overlap = _os.environ.get("AMG_DIST_OVERLAP", "1") != "0"
         self.nlevels = len(levels)
         self.bounds = [split_rows(L["A"].shape[0], world) for L in levels]
         # Coarse levels at or below `replicate_below` unknowns are REPLICATED: every rank holds them
@@ -287,7 +295,23 @@ class DistributedSolver(object):
             lv = self.lv[l]
             n_ext = lv.n_own + lv.n_halo
             Ap, Aj, Ax = loc[l]["A"]
-            lv.A = self.be.mat(lv.n_own, n_ext, Ap, renum(Aj, l), Ax)
+            Ajl = renum(Aj, l)
+            lv.A = self.be.mat(lv.n_own, n_ext, Ap, Ajl, Ax)
+            # rows [i0, i1) read no halo entry: they can run while the halo exchange is in flight
+            lv.i0, lv.i1 = 0, lv.n_own
+            if lv.n_halo and lv.n_own:
+                touches = np.zeros(lv.n_own + 1, dtype=np.int64)
+                hal = np.nonzero(Ajl >= lv.n_own)[0]
+                rows_h = np.unique(np.searchsorted(Ap, hal, side="right") - 1)
+                if len(rows_h):
+                    # largest halo-free window: between the last boundary row of the leading run and the
+                    # first of the trailing run, taken at the biggest gap
+                    gaps = np.diff(np.concatenate(([-1], rows_h, [lv.n_own])))
+                    k = int(np.argmax(gaps))
+                    lv.i0 = int(rows_h[k - 1]) + 1 if k > 0 else 0
+                    lv.i1 = int(rows_h[k]) if k < len(rows_h) else lv.n_own
+                del touches
+            lv.overlap = (lv.i1 - lv.i0) >= 0.5 * max(lv.n_own, 1) and lv.n_halo > 0
             lv.A_bsr = loc[l]["bsr"]
             lv.nnzA = len(Ax)
             if l < nl - 1:
@@ -331,6 +355,23 @@ class DistributedSolver(object):
         self.acc = self.be.vec(1)
 
     # ------------------------------------------------------------------ communication
+    def xapply(self, l, mode, v, b, v2, out, out2, c0, gscale=1.0):
+        """exchange(l, v) followed by A_l applied with v as the gathered operand; when the level has a
+        large halo-free row window, that window runs while the halo is in flight"""
+        lv = self.lv[l]
+        if self.world == 1 or not lv.comm or not (self.overlap and lv.overlap):
+            self.exchange(l, v)
+            self.be.apply(lv.A, mode, v, b, v2, out, out2, c0, gscale)
+            return
+        if lv.n_send:
+            self.be.gather(lv.sendbuf, v, lv.send_idx, lv.n_send)
+        work = self.dist.all_to_all_single(v[lv.n_own:lv.n_own + lv.n_halo], lv.sendbuf[:lv.n_send],
+                                           lv.recv_counts, lv.send_counts, group=self.group, async_op=True)
+        self.be.apply_rows(lv.A, mode, lv.i0, lv.i1, v, b, v2, out, out2, c0, gscale)
+        work.wait()
+        self.be.apply_rows(lv.A, mode, 0, lv.i0, v, b, v2, out, out2, c0, gscale)
+        self.be.apply_rows(lv.A, mode, lv.i1, lv.n_own, v, b, v2, out, out2, c0, gscale)
+
     def exchange(self, l, v):
         """refresh the halo part of v (a V_l vector) from its owners"""
         lv = self.lv[l]
@@ -371,8 +412,7 @@ class DistributedSolver(object):
         if s["name"] == "jacobi":
             for _ in range(it):
                 x, xalt = getattr(lv, xname), lv.xalt
-                self.exchange(l, x)
-                self.be.apply(lv.A, JACOBI_BSR1 if lv.A_bsr else JACOBI, x, bvec, x, xalt, None, s["omega"])
+                self.xapply(l, JACOBI_BSR1 if lv.A_bsr else JACOBI, x, bvec, x, xalt, None, s["omega"])
                 setattr(lv, xname, xalt)
                 lv.xalt = x
             return
@@ -383,24 +423,20 @@ class DistributedSolver(object):
             if x_zero:
                 rvec = bvec
             else:
-                self.exchange(l, x)
-                self.be.apply(lv.A, RESIDUAL, x, bvec, None, lv.r, None, 0.0)
+                self.xapply(l, RESIDUAL, x, bvec, None, lv.r, None, 0.0)
                 rvec = lv.r
             if len(co) == 1:
                 self.be.axpy_scaled(x, rvec, co[0], n)
             else:
-                self.exchange(l, rvec)
                 if len(co) == 2:
-                    self.be.apply(lv.A, POLY_LAST, rvec, rvec, x, x, None, co[1], co[0])
+                    self.xapply(l, POLY_LAST, rvec, rvec, x, x, None, co[1], co[0])
                 else:
                     hh, hn = lv.h, lv.h2
-                    self.be.apply(lv.A, POLY_STEP, rvec, rvec, None, hh, None, co[1], co[0])
+                    self.xapply(l, POLY_STEP, rvec, rvec, None, hh, None, co[1], co[0])
                     for c in co[2:-1]:
-                        self.exchange(l, hh)
-                        self.be.apply(lv.A, POLY_STEP, hh, rvec, None, hn, None, c)
+                        self.xapply(l, POLY_STEP, hh, rvec, None, hn, None, c)
                         hh, hn = hn, hh
-                    self.exchange(l, hh)
-                    self.be.apply(lv.A, POLY_LAST, hh, rvec, x, x, None, co[-1])
+                    self.xapply(l, POLY_LAST, hh, rvec, x, x, None, co[-1])
             x_zero = False
 
     def coarse_solve(self):
@@ -434,8 +470,7 @@ class DistributedSolver(object):
     def cycle(self, l, cyc, x_zero):
         lv, nx = self.lv[l], self.lv[l + 1]
         self.relax(l, lv.pre, "x", lv.b, x_zero)
-        self.exchange(l, lv.x)
-        self.be.apply(lv.A, RESIDUAL, lv.x, lv.b, None, lv.r, None, 0.0)
+        self.xapply(l, RESIDUAL, lv.x, lv.b, None, lv.r, None, 0.0)
         self.exchange(l, lv.r)
         if lv.rslice is not None:
             # entering the replicated part: each rank restricts its slice of the coarse rows, then all gather
@@ -464,8 +499,7 @@ class DistributedSolver(object):
 
     def residual_norm(self):
         lv = self.lv[0]
-        self.exchange(0, lv.x)
-        self.be.apply(lv.A, RESIDUAL, lv.x, lv.b, None, lv.r, None, 0.0)
+        self.xapply(0, RESIDUAL, lv.x, lv.b, None, lv.r, None, 0.0)
         return self.global_norm(lv.r, lv.n_own)
 
     def set_problem(self, b_local, x0_local=None):
@@ -514,8 +548,7 @@ class DistributedSolver(object):
         for k in range(steps):
             self.iterate(cycle, x_zero)
             x_zero = False
-            self.exchange(0, lv.x)
-            self.be.apply(lv.A, RESIDUAL, lv.x, lv.b, None, lv.r, None, 0.0)
+            self.xapply(0, RESIDUAL, lv.x, lv.b, None, lv.r, None, 0.0)
             self.be.sumsq(lv.r, lv.n_own, hist[k:k + 1])
         if self.world > 1 and steps:
             self.dist.all_reduce(hist[:steps], group=self.group)

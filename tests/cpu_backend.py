@@ -89,6 +89,20 @@ class OracleBackend(object):
     def scale(self, out, inp, c, n):
         out[:n] = torch.from_numpy(c * inp.numpy()[:n])
 
+    def apply_rows(self, m, mode, lo, hi, xg, b, v2, out, out2, c0, gscale=1.0):
+        if hi <= lo:
+            return
+        n = m[0]
+        full = torch.zeros(max(n, 1), dtype=torch.float64)
+        full2 = torch.zeros(max(n, 1), dtype=torch.float64)
+        if mode in (MATVEC_ACC,):
+            full[:n] = out[:n]
+        v2c = None if v2 is None else v2.clone()      # in-place modes: read the old values
+        self.apply(m, mode, xg, b, v2c, full, full2, c0, gscale)
+        out[lo:hi] = full[lo:hi]
+        if out2 is not None:
+            out2[lo:hi] = full2[lo:hi]
+
     def axpy_scaled(self, x, r, c, n):
         x[:n] = torch.from_numpy(x.numpy()[:n] + c * r.numpy()[:n])
 

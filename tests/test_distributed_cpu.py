@@ -44,6 +44,7 @@ def _worker(rank, world, port, case, cycle, out_dir, replicate_below=0):
         if rank == 0:
             np.save(os.path.join(out_dir, "res.npy"), np.array(res))
             np.save(os.path.join(out_dir, "halo.npy"), np.array([lv.n_halo for lv in S.lv]))
+            np.save(os.path.join(out_dir, "overlap.npy"), np.array([int(S.overlap and lv.overlap) for lv in S.lv]))
     finally:
         dist.destroy_process_group()
 
@@ -74,6 +75,7 @@ def test_partitioned_cycle_equals_single_process(case, world, rep, tmp_path):
     tol = golden_io.history_tolerance(g["levels"][0]["A"], g["x"], g["b"], g["residuals"])
     assert np.all(np.abs(res - g["residuals"]) <= tol)
     assert np.load(tmp_path / "halo.npy")[0] > 0          # the ranks really exchanged halos
+    assert np.load(tmp_path / "overlap.npy")[0] == 1      # ... with the interior rows overlapped on level 0
 
 
 def test_split_rows_and_local_rows():
