@@ -69,6 +69,17 @@ def host_lib():
         L.amgsetup_greedy_coloring.argtypes = [C.c_int, ip, ip, ip]
         L.amgsetup_greedy_coloring.restype = C.c_int
         L.amgsetup_num_threads.restype = C.c_int
+        L.amgsetup_set_num_threads.argtypes = [C.c_int]
+        L.amgsetup_set_num_threads.restype = None
+        # Row-parallel setup kernels keep O(columns) scratch per thread: cap the team at the CPUs this
+        # process may use (launchers such as torchrun export OMP_NUM_THREADS=1; a bare run on a big
+        # host would otherwise start hundreds of threads).  AMG_SETUP_THREADS overrides.
+        try:
+            avail = len(os.sched_getaffinity(0))
+        except AttributeError:
+            avail = os.cpu_count() or 1
+        want = int(os.environ.get("AMG_SETUP_THREADS", min(32, avail)))
+        L.amgsetup_set_num_threads(max(1, want))
         _host = L
     return _host
 

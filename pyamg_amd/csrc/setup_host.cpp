@@ -532,6 +532,15 @@ int amgsetup_greedy_coloring(int n, const int *Ap, const int *Aj, int *colour)
     return ncol;
 }
 
+void amgsetup_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 int amgsetup_num_threads(void)
 {
 #ifdef _OPENMP
