@@ -389,3 +389,64 @@ def test_device_pcg_matches_reference_cg_semantics():
     assert np.linalg.norm(x - xr) <= 1e-9 * np.linalg.norm(xr)
     assert np.linalg.norm(b - A * x) <= 1e-8 * np.linalg.norm(b)
     assert len(res) < 0.5 * len(g["residuals"])          # CG needs far fewer cycles than the stand-alone iteration
+
+
+# --- mirrors of pyamg/tests/test_multilevel.py -------------------------------------------------
+def test_coarse_grid_solver_exact_on_small_systems():
+    # test_multilevel.py:19-45 (dense kinds; Krylov/callable coarse solvers are host code and refused)
+    cases = [sps.csr_matrix(np.diag(np.arange(1, 5, dtype=float))), poisson((4,)), poisson((4, 4))]
+    for A in cases:
+        for solver in ["splu", "pinv", "pinv2", "lu", "cholesky"]:
+            s = pyamg_amd.coarse_grid_solver(solver)
+            b = np.arange(A.shape[0], dtype=A.dtype)
+            x = s(A, b)
+            assert np.allclose(A * x, b, atol=1e-7)
+            x = s(A, b)                                   # subsequent calls use cached data
+            assert np.allclose(A * x, b, atol=1e-7)
+    # relaxation as coarse solver: 10 iterations by default (multilevel.py:662-680)
+    A = poisson((4, 4)); b = np.arange(16.0)
+    x = pyamg_amd.coarse_grid_solver("gauss_seidel")(A, b)
+    xo = np.zeros(16); 
+    for _ in range(10):
+        relaxation.gauss_seidel(A, xo, b)
+    assert np.array_equal(x, xo)
+    assert np.array_equal(pyamg_amd.coarse_grid_solver(None)(A, b), np.zeros(16))
+    with pytest.raises(NotImplementedError):
+        pyamg_amd.coarse_grid_solver("cg")(A, b)
+
+
+def test_aspreconditioner_and_accel_like_reference_tests():
+    # test_multilevel.py:47-98
+    from pyamg_amd.aggregation import poisson as native, smoothed_aggregation_solver
+    from scipy.sparse.linalg import cg
+    A = native((50, 50))
+    np.random.seed(0)
+    b = np.random.rand(A.shape[0])
+    ml = smoothed_aggregation_solver(A)          # defaults: symmetric GS smoother (exact, level-scheduled)
+
+    def precon_norm(v):
+        v = np.ravel(v)
+        return np.sqrt(np.inner(v, ml.psolve(v)))
+    for cycle in ["V", "W", "F"]:
+        M = ml.aspreconditioner(cycle=cycle)
+        x, info = cg(A, b, rtol=1e-8, maxiter=30, M=M)
+        assert np.linalg.norm(b - A * x) < 1e-6 * np.linalg.norm(b)
+    # cg halts based on the preconditioner norm; residuals[-1] is that norm
+    residuals = []
+    x = ml.solve(b, maxiter=30, tol=1e-8, residuals=residuals, accel="cg")
+    assert precon_norm(b - A * x) < 1e-8 * precon_norm(b) * 1.01
+    assert abs(precon_norm(b - A * x) - residuals[-1]) < 1e-6 * residuals[0]
+    # Euclidean-norm accelerators through scipy with the device cycle as M
+    for accel in ["bicgstab", "cgs"]:
+        residuals = []
+        x = ml.solve(b, maxiter=30, tol=1e-8, residuals=residuals, accel=accel)
+        assert np.linalg.norm(b - A * x) < 1e-7 * np.linalg.norm(b)
+    # SA defaults on 50x50 converge with average factor < 0.95 for every device smoother
+    # (pyamg/relaxation/tests/test_smoothing.py:33-51)
+    for sm in ["gauss_seidel", "jacobi", "block_gauss_seidel", "block_jacobi", "richardson", "sor", "chebyshev",
+               ("gauss_seidel", {"sweep": "symmetric"}), None]:
+        pyamg_amd.change_smoothers(ml, sm, "gauss_seidel" if sm is None else sm)
+        res = []
+        ml.solve(b, tol=1e-10, maxiter=40, residuals=res)
+        factor = (res[-1] / res[0]) ** (1.0 / (len(res) - 1))
+        assert factor < 0.95, (sm, factor)
