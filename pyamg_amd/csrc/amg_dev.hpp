@@ -80,7 +80,7 @@ struct StreamArgs {
 // variant: 0 = scalar (8 B / 4 B per lane) loads, 1 = 16-byte vector loads
 int launch_stream(StreamMode mode, const StreamArgs &a, hipStream_t st);
 int stream_blocks(const StreamArgs &a);   // workgroups launch_stream will use (partials of SM_RESIDUAL_SUMSQ)
-int launch_sum_sqrt(const double *partial, long np, double *result_dev, hipStream_t st);   // sqrt(sum) in fixed order
+int launch_sum_sqrt(const double *partial, long np, double *scratch512, double *result_dev, hipStream_t st);   // sqrt(sum), fixed order
 int launch_axpy_scaled(double *x, const double *r, double c, long n, hipStream_t st);        // x += c*r
 void set_stream_variant(int v);
 int stream_variant();

@@ -530,7 +530,7 @@ static int residual_norm_to(amg_hier *h, double *slot)
     const int nb = stream_blocks(a);
     if (nb > h->sumsq_cap) { set_error("sumsq partial buffer too small"); return AMG_ESTATE; }
     CHK(launch_stream(SM_RESIDUAL_SUMSQ, a, h->stream));
-    return launch_sum_sqrt(h->sumsq_partials, nb, slot, h->stream);
+    return launch_sum_sqrt(h->sumsq_partials, nb, h->sumsq_partials + h->sumsq_cap, slot, h->stream);
 }
 
 // One solve() iteration = cycle + residual norm into `slot`, replayed from a hipGraph once the
@@ -917,7 +917,7 @@ int amg_hier_finalize(amg_hier *h)
             if (h->sumsq_partials) hipFree(h->sumsq_partials);
     for (double *q : h->pcg) if (q) hipFree(q);
             h->sumsq_partials = nullptr;
-            CHK(dev_alloc(&h->sumsq_partials, need, &h->dev_bytes));
+            CHK(dev_alloc(&h->sumsq_partials, need + 512, &h->dev_bytes));   // + second-stage scratch
             h->sumsq_cap = need;
         }
     }

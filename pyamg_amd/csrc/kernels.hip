@@ -527,9 +527,24 @@ __global__ __launch_bounds__(256) void sum_sqrt_kernel(const double *partial, lo
     double r = block_reduce_sum(s, smem);
     if (threadIdx.x == 0) *result = sqrt(r);
 }
-int launch_sum_sqrt(const double *partial, long np, double *result_dev, hipStream_t st)
+__global__ __launch_bounds__(256) void sum_partials_kernel(const double *partial, long np, double *out)
 {
-    hipLaunchKernelGGL(sum_sqrt_kernel, dim3(1), dim3(256), 0, st, partial, np, result_dev);
+    // fixed assignment of partials to workgroups and threads: deterministic
+    __shared__ double smem[4];
+    double s = 0.0;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < np; i += (long)gridDim.x * blockDim.x) s += partial[i];
+    double r = block_reduce_sum(s, smem);
+    if (threadIdx.x == 0) out[blockIdx.x] = r;
+}
+int launch_sum_sqrt(const double *partial, long np, double *scratch512, double *result_dev, hipStream_t st)
+{
+    // np can be ~5e5 (one partial per workgroup of the 500^3 operator): reduce in two steps
+    if (np > 4096 && scratch512) {
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(512), dim3(256), 0, st, partial, np, scratch512);
+        hipLaunchKernelGGL(sum_sqrt_kernel, dim3(1), dim3(256), 0, st, scratch512, 512L, result_dev);
+    } else {
+        hipLaunchKernelGGL(sum_sqrt_kernel, dim3(1), dim3(256), 0, st, partial, np, result_dev);
+    }
     LAUNCH_CHECK("sum_sqrt");
 }
 __global__ void axpy_scaled_kernel(double *x, const double *r, double c, long n)

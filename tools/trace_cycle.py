@@ -7,7 +7,7 @@ nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 rows = list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 names = [r['Kernel_Name'] for r in rows]
-idx = [i for i, n in enumerate(names) if 'sumsq_stage2' in n]
+idx = [i for i, n in enumerate(names) if 'sum_sqrt_kernel' in n or 'sumsq_stage2' in n]
 # the timed solve = the last (nsteps + 2) norm kernels before the SpMV timing loops: norm(b), r0, then nsteps
 # find the run of nsteps+2 norms that ends last
 end = idx[-1]
