@@ -154,7 +154,7 @@ void amg_hier_destroy(amg_hier *h);
  * container (csr_matrix, or bsr_matrix with blocksize (R,C)); nrows/ncols are
  * scalar dimensions; Ax has nnz (CSR) or nblocks*R*C (BSR, blocks row-major)
  * entries.  Pointers are host pointers unless on_device != 0, in which case
- * the arrays are device pointers that the hierarchy ADOPTS (frees on destroy). */
+ * they are device pointers (CSR / BSR(1,1) only); the arrays are copied either way. */
 int amg_hier_set_matrix(amg_hier *h, int lvl, int which, int fmt, int nrows, int ncols,
                         int R, int C, const int *Ap, const int *Aj, const double *Ax,
                         int on_device);

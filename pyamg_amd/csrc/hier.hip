@@ -707,12 +707,20 @@ int amg_hier_set_matrix(amg_hier *h, int lvl, int which, int fmt, int nrows, int
     DevCsr &M = (which == AMG_MAT_A) ? L.A : (which == AMG_MAT_P ? L.P : L.Rm);
     free_csr(M);
     if (on_device) {
-        if (fmt != AMG_FMT_CSR) { set_error("device adoption supports CSR only"); return AMG_ENOTIMPL; }
+        // device-resident source (e.g. an operator assembled on the GPU): copied device-to-device
+        if (fmt != AMG_FMT_CSR && !(R == 1 && C == 1)) { set_error("device sources: CSR / BSR(1,1) only"); return AMG_ENOTIMPL; }
         int last = 0;
         AMG_HIP(hipMemcpy(&last, Ap + nrows, sizeof(int), hipMemcpyDeviceToHost));
+        if (last < 0) { set_error("bad device row pointer"); return AMG_EINVAL; }
         M.nrows = nrows; M.ncols = ncols; M.nnz = last;
-        M.Ap = const_cast<int *>(Ap); M.Aj = const_cast<int *>(Aj); M.Ax = const_cast<double *>(Ax);
-        h->dev_bytes += 4L * (nrows + 1) + 12L * last;
+        CHK(dev_alloc(&M.Ap, nrows + 1, &h->dev_bytes));
+        CHK(dev_alloc(&M.Aj, last, &h->dev_bytes));
+        CHK(dev_alloc(&M.Ax, last, &h->dev_bytes));
+        AMG_HIP(hipMemcpy(M.Ap, Ap, sizeof(int) * (size_t)(nrows + 1), hipMemcpyDeviceToDevice));
+        if (last) {
+            AMG_HIP(hipMemcpy(M.Aj, Aj, sizeof(int) * (size_t)last, hipMemcpyDeviceToDevice));
+            AMG_HIP(hipMemcpy(M.Ax, Ax, sizeof(double) * (size_t)last, hipMemcpyDeviceToDevice));
+        }
     } else if (fmt == AMG_FMT_CSR || (R == 1 && C == 1)) {
         CHK(upload_csr(M, nrows, ncols, Ap, Aj, Ax, &h->dev_bytes));
     } else {

@@ -450,3 +450,34 @@ def test_aspreconditioner_and_accel_like_reference_tests():
         ml.solve(b, tol=1e-10, maxiter=40, residuals=res)
         factor = (res[-1] / res[0]) ** (1.0 / (len(res) - 1))
         assert factor < 0.95, (sm, factor)
+
+
+def test_device_resident_operator_source_and_device_vectors():
+    """amg_hier_set_matrix(on_device=1) + AMG_SOLVE_DEVICE_VECTORS: a caller that already lives on the
+    GPU (torch tensors here) hands device pointers; results equal the host-pointer path bit for bit."""
+    import ctypes as C
+    import torch
+    from pyamg_amd import _lib
+    g = golden_io.load_hier("sa_jacobi_2d")
+    ml = golden_io.build_ml(g)
+    res = []
+    x_ref = ml.solve(g["b"], tol=0.0, maxiter=4, residuals=res)
+    L = _lib.lib()
+    dev = ml.device_hierarchy()
+    h = dev.h
+    # replace level-0 A by a device-resident copy of itself, then re-finalise
+    A = g["levels"][0]["A"]
+    tAp = torch.from_numpy(A.indptr.astype(np.int32)).cuda()
+    tAj = torch.from_numpy(A.indices.astype(np.int32)).cuda()
+    tAx = torch.from_numpy(A.data.astype(np.float64)).cuda()
+    _lib.check(L.amg_hier_set_matrix(h, 0, 0, 0, A.shape[0], A.shape[1], 1, 1, tAp.data_ptr(), tAj.data_ptr(),
+                                     tAx.data_ptr(), 1))
+    _lib.check(L.amg_hier_finalize(h))
+    tb = torch.from_numpy(g["b"].copy()).cuda()
+    tx = torch.zeros_like(tb)
+    torch.cuda.synchronize()
+    out = np.zeros(8); nres = C.c_int()
+    _lib.check(L.amg_hier_solve(h, tb.data_ptr(), tx.data_ptr(), 0.0, 4, 0, _lib.dp(out), C.byref(nres), 2 | 4))
+    assert nres.value == 5
+    assert np.array_equal(tx.cpu().numpy(), x_ref)
+    assert np.allclose(out[:5], res, rtol=1e-13)
