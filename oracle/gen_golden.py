@@ -227,6 +227,8 @@ def gen_hier(pyamg, name, A, build, pre, post, solve_kw, B=None, x0_random=False
             meta["levels"].append({
                 "pre": smoother_desc(out, "pre%d" % i, ps, lvl.presmoother, lvl),
                 "post": smoother_desc(out, "post%d" % i, qs, lvl.postsmoother, lvl)})
+    if B is not None:
+        out["B0"] = np.asarray(B, dtype=np.float64)          # near-null-space candidates handed to the setup
     out["coarse_pinv"] = np.asarray(ml.coarse_solver.P, dtype=np.float64)
     out["b"] = b
     out["x0"] = np.zeros(n) if x0 is None else x0

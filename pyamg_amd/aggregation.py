@@ -47,6 +47,8 @@ def host_lib():
         L.amgsetup_standard_aggregation.restype = C.c_int
         L.amgsetup_gauss_seidel.argtypes = [ip, ip, dp, dp, dp, C.c_int, C.c_int, C.c_int]
         L.amgsetup_gauss_seidel.restype = None
+        L.amgsetup_block_gauss_seidel.argtypes = [ip, ip, dp, dp, dp, dp, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.amgsetup_block_gauss_seidel.restype = None
         L.amgsetup_csr_matmat_count.argtypes = [C.c_int, C.c_int, lp, ip, lp, ip, lp]
         L.amgsetup_csr_matmat_count.restype = C.c_int64
         L.amgsetup_csr_matmat_fill.argtypes = [C.c_int, C.c_int, lp, ip, dp, lp, ip, dp, lp, ip, dp]
@@ -336,27 +338,47 @@ def _improve(method, A, B):
     lvl = multilevel_solver.level()
     lvl.A = A
     desc = getattr(smoothing, "setup_" + str(fn))(lvl, **kwargs).desc
-    if desc["name"] != "gauss_seidel" or (isspmatrix_bsr(A) and A.blocksize != (1, 1)):
-        raise NotImplementedError("improve_candidates=%r on this matrix is outside the restated setup" % (fn,))
-    Ac = A if isspmatrix_csr(A) else A.tocsr()
-    Ap = np.ascontiguousarray(Ac.indptr, dtype=np.intc)
-    Aj = np.ascontiguousarray(Ac.indices, dtype=np.intc)
-    Ax = np.ascontiguousarray(Ac.data, dtype=np.float64)
     n = A.shape[0]
     b = np.zeros(n)
     out = np.empty_like(B)
-    bsr1 = isspmatrix_bsr(A)
-    if bsr1:
-        raise NotImplementedError("candidate improvement on BSR(1,1) levels")
     L = host_lib()
+    its = int(desc.get("iterations", 1))
+    sw = desc.get("sweep", "forward")
+    if desc["name"] == "gauss_seidel" and (isspmatrix_csr(A) or A.blocksize == (1, 1)):
+        if isspmatrix_bsr(A):
+            raise NotImplementedError("candidate improvement on BSR(1,1) levels")
+        Ap = np.ascontiguousarray(A.indptr, dtype=np.intc)
+        Aj = np.ascontiguousarray(A.indices, dtype=np.intc)
+        Ax = np.ascontiguousarray(A.data, dtype=np.float64)
+
+        def sweep(x, reverse):
+            if reverse:
+                L.amgsetup_gauss_seidel(_ip(Ap), _ip(Aj), _dp(Ax), _dp(x), _dp(b), n - 1, -1, -1)
+            else:
+                L.amgsetup_gauss_seidel(_ip(Ap), _ip(Aj), _dp(Ax), _dp(x), _dp(b), 0, n, 1)
+    elif desc["name"] == "block_gauss_seidel":
+        bs = int(desc["blocksize"])
+        Ab = A.tobsr(blocksize=(bs, bs))                      # relaxation.py:563
+        Ap = np.ascontiguousarray(Ab.indptr, dtype=np.intc)
+        Aj = np.ascontiguousarray(Ab.indices, dtype=np.intc)
+        Ax = np.ascontiguousarray(np.ravel(Ab.data), dtype=np.float64)
+        Dinv = np.ascontiguousarray(np.ravel(desc["Dinv"]), dtype=np.float64)
+        nb = n // bs
+
+        def sweep(x, reverse):
+            if reverse:
+                L.amgsetup_block_gauss_seidel(_ip(Ap), _ip(Aj), _dp(Ax), _dp(x), _dp(b), _dp(Dinv), nb - 1, -1, -1, bs)
+            else:
+                L.amgsetup_block_gauss_seidel(_ip(Ap), _ip(Aj), _dp(Ax), _dp(x), _dp(b), _dp(Dinv), 0, nb, 1, bs)
+    else:
+        raise NotImplementedError("improve_candidates=%r on this matrix is outside the restated setup" % (fn,))
     for j in range(B.shape[1]):
         x = np.ascontiguousarray(B[:, j], dtype=np.float64).copy()
-        for it in range(int(desc.get("iterations", 1))):
-            sw = desc.get("sweep", "forward")
+        for it in range(its):
             if sw in ("forward", "symmetric"):
-                L.amgsetup_gauss_seidel(_ip(Ap), _ip(Aj), _dp(Ax), _dp(x), _dp(b), 0, n, 1)
+                sweep(x, False)
             if sw in ("backward", "symmetric"):
-                L.amgsetup_gauss_seidel(_ip(Ap), _ip(Aj), _dp(Ax), _dp(x), _dp(b), n - 1, -1, -1)
+                sweep(x, True)
         out[:, j] = x
     return out
 

@@ -83,6 +83,37 @@ void amgsetup_gauss_seidel(const int *Ap, const int *Aj, const double *Ax, doubl
     }
 }
 
+// pyamg/amg_core/relaxation.h:756-810 on the host (candidate improvement on BSR operators at setup)
+void amgsetup_block_gauss_seidel(const int *Ap, const int *Aj, const double *Ax, double *x, const double *b,
+                                 const double *Dinv, int row_start, int row_stop, int row_step, int bs)
+{
+    const int B2 = bs * bs;
+    std::vector<double> rsum((size_t)bs), v((size_t)bs);
+    for (int i = row_start; i != row_stop; i += row_step) {
+        std::fill(rsum.begin(), rsum.end(), 0.0);
+        for (int jj = Ap[i]; jj < Ap[i + 1]; jj++) {
+            int j = Aj[jj];
+            if (i == j) continue;
+            const double *blk = Ax + (int64_t)jj * B2;
+            const double *xj = x + (int64_t)j * bs;
+            for (int r = 0; r < bs; r++) {
+                double sacc = 0.0;
+                for (int c = 0; c < bs; c++) sacc += blk[r * bs + c] * xj[c];
+                v[r] = sacc;
+            }
+            for (int k = 0; k < bs; k++) rsum[k] += v[k];
+        }
+        const int64_t ib = (int64_t)i * bs;
+        for (int k = 0; k < bs; k++) rsum[k] = b[ib + k] - rsum[k];
+        const double *D = Dinv + (int64_t)i * B2;
+        for (int r = 0; r < bs; r++) {
+            double sacc = 0.0;
+            for (int c = 0; c < bs; c++) sacc += D[r * bs + c] * rsum[c];
+            x[ib + r] = sacc;
+        }
+    }
+}
+
 // C = A * B for CSR operands, row-parallel restatement of scipy's SMMP
 // (scipy.sparse._sparsetools csr_matmat): per output row the products are
 // accumulated in the order of A's row entries, the output columns come out in

@@ -103,8 +103,12 @@ def get_block_diag(A, blocksize, inv_flag=True):
 def scale_rows(A, v, copy=True):
     """util/utils.py:133-200 (CSR/BSR(1,1))"""
     v = np.ravel(v)
-    if isspmatrix_bsr(A) and A.blocksize != (1, 1):
-        A = A.tocsr()
+    if isspmatrix_bsr(A):
+        R, C = A.blocksize
+        A = bsr_matrix(A, copy=copy)
+        per_block = np.repeat(v.reshape(-1, R), np.diff(A.indptr), axis=0)      # (nblocks, R)
+        A.data = A.data * per_block[:, :, None]
+        return A
     A = csr_matrix(A, copy=copy)
     A.data = A.data * np.repeat(v, np.diff(A.indptr))
     return A

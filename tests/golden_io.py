@@ -59,6 +59,8 @@ def load_hier(name):
     out = dict(meta=meta, levels=levels, coarse_pinv=z["coarse_pinv"])
     for k in ("b", "x0", "x", "residuals", "x_iter1", "x_iter2"):
         out[k] = z[k]
+    if "B0" in z.files:
+        out["B0"] = z["B0"]
     return out
 
 

@@ -141,3 +141,27 @@ def test_rs_setup_reproduces_reference_hierarchy_and_readme():
     assert sizes[:4] == [(250000, 1248000), (125000, 1121002), (31252, 280662), (7825, 70657)]
     assert sizes[4:] == [(1937, 17971), (483, 4725)]          # reference run in this container
     assert abs(ml.operator_complexity() - 2.198) < 1e-3 and abs(ml.grid_complexity() - 1.666) < 1e-3
+
+
+@pytest.mark.parametrize("case,sm", [
+    ("elas_bgs_2d", ("block_gauss_seidel", {"sweep": "symmetric"})),
+    ("bs3_bgs_2d", ("block_gauss_seidel", {"sweep": "symmetric", "blocksize": 3})),
+])
+def test_block_sa_setup_reproduces_reference_hierarchy(case, sm):
+    """BSR operators with several near-null-space candidates (2D elasticity: blocks 2x2 -> 3x3 with the
+    three rigid-body modes; a 3-unknowns-per-node diffusion system): block candidate improvement,
+    block strength pattern, per-aggregate QR (fit_candidates), BSR Jacobi smoothing and Galerkin product."""
+    g = golden_io.load_hier(case)
+    np.random.seed(0)
+    ml = smoothed_aggregation_solver(g["levels"][0]["A"].copy(), B=g["B0"], presmoother=sm, postsmoother=sm,
+                                     max_coarse=10)
+    assert len(ml.levels) == g["meta"]["nlevels"]
+    for lvl, G in zip(ml.levels, g["levels"]):
+        assert type(lvl.A) is type(G["A"]) and lvl.A.blocksize == G["A"].blocksize
+        same(lvl.A, G["A"], 1e-12)
+        if "P" in G:
+            assert lvl.P.blocksize == G["P"].blocksize and lvl.R.blocksize == G["R"].blocksize
+            same(lvl.P, G["P"], 1e-12)
+            same(lvl.R, G["R"], 1e-12)
+            assert lvl.presmoother.desc["name"] == G["pre"]["name"]
+            assert np.allclose(np.ravel(lvl.presmoother.desc["Dinv"]), np.ravel(G["pre"]["Dinv"]), rtol=1e-10, atol=1e-14)
