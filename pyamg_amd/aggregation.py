@@ -229,33 +229,39 @@ def fit_candidates(AggOp, B, tol=1e-10):
         R[:, 0, 0] = Rv
         Qx = q.reshape(-1, 1, 1)
     else:
-        for j in range(N_coarse):
-            s, e = Ap[j], Ap[j + 1]
-            blk = Qx[s:e].reshape(-1, K2)            # ((e-s)*K1, K2) rows in storage order
+        # general case: modified Gram-Schmidt per aggregate, batched over the aggregates that have the
+        # same number of members; every sum runs over the rows in storage order, one row at a time,
+        # exactly as the reference's scalar loops do (smoothed_aggregation.h:367-452)
+        counts = np.diff(Ap)
+        for m in np.unique(counts):
+            if m == 0:
+                continue
+            aggs = np.nonzero(counts == m)[0]
+            pos = (Ap[aggs][:, None] + np.arange(m)[None, :]).astype(np.int64)      # (ng, m)
+            blk = Qx[pos].reshape(len(aggs), m * K1, K2).copy()
+            nrow = m * K1
             for bj in range(K2):
-                norm_j = 0.0
-                for v in blk[:, bj]:
-                    norm_j += v * v
+                norm_j = np.zeros(len(aggs))
+                for rr in range(nrow):
+                    norm_j = norm_j + blk[:, rr, bj] * blk[:, rr, bj]
                 norm_j = np.sqrt(norm_j)
                 threshold_j = tol * norm_j
                 for bi in range(bj):
-                    dot_prod = 0.0
-                    for a, c in zip(blk[:, bj], blk[:, bi]):
-                        dot_prod += c * a
-                    blk[:, bj] -= dot_prod * blk[:, bi]
-                    R[j, bi, bj] = dot_prod
-                norm_j = 0.0
-                for v in blk[:, bj]:
-                    norm_j += v * v
+                    dot_prod = np.zeros(len(aggs))
+                    for rr in range(nrow):
+                        dot_prod = dot_prod + blk[:, rr, bi] * blk[:, rr, bj]
+                    blk[:, :, bj] = blk[:, :, bj] - dot_prod[:, None] * blk[:, :, bi]
+                    R[aggs, bi, bj] = dot_prod
+                norm_j = np.zeros(len(aggs))
+                for rr in range(nrow):
+                    norm_j = norm_j + blk[:, rr, bj] * blk[:, rr, bj]
                 norm_j = np.sqrt(norm_j)
-                if norm_j > threshold_j:
-                    scale = 1.0 / norm_j
-                    R[j, bj, bj] = norm_j
-                else:
-                    scale = 0.0
-                    R[j, bj, bj] = 0.0
-                blk[:, bj] *= scale
-            Qx[s:e] = blk.reshape(-1, K1, K2)
+                ok = norm_j > threshold_j
+                scale = np.zeros(len(aggs))
+                scale[ok] = 1.0 / norm_j[ok]
+                R[aggs, bj, bj] = np.where(ok, norm_j, 0.0)
+                blk[:, :, bj] = blk[:, :, bj] * scale[:, None]
+            Qx[pos] = blk.reshape(len(aggs), m, K1, K2)
     Q = bsr_matrix((Qx.swapaxes(1, 2).copy(), Ai, Ap), shape=(K2 * N_coarse, K1 * N_fine))
     Q = Q.T.tobsr()
     R = R.reshape(-1, K2)
