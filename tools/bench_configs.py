@@ -61,10 +61,16 @@ if "C2" in which:
     sm = ("jacobi", {"omega": 4.0 / 3.0})
     run("C2: 2D Poisson 2000x2000, SA, weighted Jacobi omega=4/3", smoothed_aggregation_solver(A, presmoother=sm, postsmoother=sm), A)
 if "C5" in which:
-    m = int(os.environ.get("C5_GRID", "32"))
-    M3 = np.array([[4.0, -1.0, 0.5], [-1.0, 3.0, -0.5], [0.5, -0.5, 2.0]])
-    A = sps.kron(poisson((m, m, m)), M3).tobsr((3, 3)); A.sort_indices()
-    B = np.kron(np.ones((m ** 3, 1)), np.eye(3)); np.random.seed(0)
+    from pyamg_amd.gallery import tet_diffusion
+    m = int(os.environ.get("C5_GRID", "72"))
+    t0 = time.time()
+    A = tet_diffusion(m, blocksize=3)
+    np.random.seed(0)
     sm = ("block_gauss_seidel", {"sweep": "symmetric", "blocksize": 3})
-    ml = smoothed_aggregation_solver(A, B=B, presmoother=sm, postsmoother=sm, improve_candidates=None, max_coarse=100)
-    run("C5-shaped (reduced): 3 coupled unknowns per node on a %d^3 grid, BSR bs=3, SA, block Gauss-Seidel" % m, ml, A)
+    ml = smoothed_aggregation_solver(A, presmoother=sm, postsmoother=sm, max_coarse=300)
+    sys.stderr.write("C5 build+setup %.1fs\n" % (time.time() - t0))
+    run("C5-shaped (reduced): anisotropic diffusion, P1 on a jittered Kuhn tetrahedral mesh, %d^3 = %d unknowns, "
+        "BSR bs=3, SA, symmetric block Gauss-Seidel" % (m, A.shape[0]), ml, A)
+    sm = ("block_jacobi", {"omega": 4.0 / 3.0, "blocksize": 3})
+    ml2 = smoothed_aggregation_solver(A, presmoother=sm, postsmoother=sm, max_coarse=300)
+    run("C5 variant: same problem, block Jacobi (omega = 4/3 / rho)", ml2, A)
