@@ -339,7 +339,8 @@ def main():
             rn = H.lib.oracle_norm2(dp(b - Ah), n)
             t_cpu = time.perf_counter() - t0
             log("[bench] CPU oracle: 1 step in %.2fs, residual %.6e (GPU first step: %.6e)" % (t_cpu, rn, warm_res[1]))
-            cpu = {"value": round(1.0 / t_cpu, 5), "unit": "V-cycle iterations/s", "cores": 1, "kind": "port",
+            first_step_agrees = bool(abs(rn - warm_res[1]) <= 1e-12 * abs(rn))
+            cpu = {"value": round(1.0 / t_cpu, 5), "first_step_residual_equals_gpu": first_step_agrees, "unit": "V-cycle iterations/s", "cores": 1, "kind": "port",
                    "sample": "1 V-cycle of the same hierarchy and RHS from x0=0 with the C oracle "
                              "(oracle/amg_oracle.c, -O3, 1 thread; includes the reference's discarded "
                              "second P*coarse_x per level, multilevel.py:548)",

@@ -146,6 +146,14 @@ __global__ __launch_bounds__(WG) void csr_stream_kernel(StreamArgs a, int xcd_ch
     }
     double acc = 0.0;
     if (MT::sub && t < nr) acc = a.b[row];
+    // Gauss-Seidel levels are latency-bound (a few thousand rows per launch): fetch the diagonal
+    // and the right-hand side now, so that their latency overlaps the matrix stream instead of
+    // following it
+    double gs_d = 0.0, gs_b = 0.0;
+    if (MT::gs && t < nr) {
+        gs_d = (dpos >= 0) ? a.Ax[dpos] : 0.0;
+        if (!MT::sub) gs_b = a.b[row];
+    }
 
     // tile origin aligned to 4 entries so that 16-byte loads are aligned
     const int abeg = VEC ? (kbeg & ~3) : kbeg;
@@ -301,11 +309,9 @@ __global__ __launch_bounds__(WG) void csr_stream_kernel(StreamArgs a, int xcd_ch
             a.out[i] = told;
         }
     } else if (MODE == SM_GS) {
-        double d = (dpos >= 0) ? a.Ax[dpos] : 0.0;
-        if (d != 0.0) a.out[row] = (a.b[row] - acc) / d;
+        if (gs_d != 0.0) a.out[row] = (gs_b - acc) / gs_d;
     } else if (MODE == SM_GS_BSR1) {
-        double d = (dpos >= 0) ? a.Ax[dpos] : 0.0;
-        if (d != 0.0) a.out[row] = acc / d;
+        if (gs_d != 0.0) a.out[row] = acc / gs_d;
     }
 }
 
