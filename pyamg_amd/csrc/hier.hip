@@ -61,6 +61,7 @@ int upload_csr(DevCsr &M, int nrows, int ncols, const int *Ap, const int *Aj, co
                long *acct)
 {
     long nnz = Ap[nrows];
+    if (nnz < 0 || nrows < 0) { set_error("row pointer overflows int32 (more than 2^31-1 stored entries)"); return AMG_EINVAL; }
     M.nrows = nrows; M.ncols = ncols; M.nnz = nnz;
     CHK(dev_alloc(&M.Ap, nrows + 1, acct));
     CHK(dev_alloc(&M.Aj, nnz, acct));
