@@ -160,6 +160,59 @@ def gen_kernels(core):
     print("kernels.npz: %d cases" % len(cases))
 
 
+# --------------------------------------------------------------------------- setup kernels
+def gen_setup_kernels(core):
+    """inputs/outputs of the reference's native SETUP kernels (amg_core) on seeded random graphs:
+    standard_aggregation, classical_strength_of_connection, rs_cf_splitting,
+    rs_direct_interpolation_pass1/2, fit_candidates"""
+    out = {}
+    cases = []
+
+    def rec(name, **arrs):
+        cases.append(name)
+        for k, v in arrs.items():
+            out["%s__%s" % (name, k)] = np.asarray(v)
+
+    for tag, n, dens, seed in (("g40", 40, 0.08, 1), ("g300", 300, 0.012, 2), ("g1000", 1000, 0.004, 3),
+                                ("path", 9, None, 0), ("iso", 12, 0.05, 5)):
+        if dens is None:
+            A = sps.diags([-np.ones(n - 1), 2 * np.ones(n), -np.ones(n - 1)], [-1, 0, 1], format="csr")
+        else:
+            A = random_system(n, dens, seed=seed)
+        A = sps.csr_matrix(A); A.sort_indices()
+        Ap, Aj, Ax = A.indptr.astype(np.intc), A.indices.astype(np.intc), A.data.astype(np.float64)
+        # aggregation on the pattern of A
+        x = np.empty(n, dtype=np.intc); y = np.empty(n, dtype=np.intc)
+        na = core.standard_aggregation(n, Ap, Aj, x, y)
+        rec("standard_aggregation_" + tag, Ap=Ap, Aj=Aj, n=[n], agg=x, roots=y[:na], count=[na])
+        # classical strength
+        for theta in (0.0, 0.25, 0.6):
+            Sp = np.empty_like(Ap); Sj = np.empty_like(Aj); Sx = np.empty_like(Ax)
+            core.classical_strength_of_connection(n, theta, Ap, Aj, Ax, Sp, Sj, Sx)
+            nnz = Sp[-1]
+            rec("classical_strength_%s_%g" % (tag, theta), Ap=Ap, Aj=Aj, Ax=Ax, theta=[theta], Sp=Sp, Sj=Sj[:nnz], Sx=Sx[:nnz])
+        # RS splitting + direct interpolation on the theta = 0.25 strength graph
+        S = sps.csr_matrix((Sx[:nnz], Sj[:nnz], Sp), shape=A.shape)    # theta = 0.6 from the loop above
+        Sc = S.tocoo(); m = Sc.row != Sc.col
+        S0 = sps.coo_matrix((Sc.data[m], (Sc.row[m], Sc.col[m])), shape=S.shape).tocsr()
+        T = S0.T.tocsr()
+        spl = np.empty(n, dtype=np.intc)
+        core.rs_cf_splitting(n, S0.indptr.astype(np.intc), S0.indices.astype(np.intc), T.indptr.astype(np.intc),
+                             T.indices.astype(np.intc), spl)
+        rec("rs_cf_splitting_" + tag, Sp=S0.indptr.astype(np.intc), Sj=S0.indices.astype(np.intc),
+            Tp=T.indptr.astype(np.intc), Tj=T.indices.astype(np.intc), splitting=spl)
+        C = S.copy(); C.data[:] = 1.0; C = sps.csr_matrix(C.multiply(A)); C.sort_indices()
+        Cp, Cj, Cx = C.indptr.astype(np.intc), C.indices.astype(np.intc), C.data.astype(np.float64)
+        Pp = np.empty(n + 1, dtype=np.intc)
+        core.rs_direct_interpolation_pass1(n, Cp, Cj, spl, Pp)
+        Pj = np.empty(Pp[-1], dtype=np.intc); Px = np.empty(Pp[-1], dtype=np.float64)
+        core.rs_direct_interpolation_pass2(n, Ap, Aj, Ax, Cp, Cj, Cx, spl, Pp, Pj, Px)
+        rec("rs_direct_interpolation_" + tag, Ap=Ap, Aj=Aj, Ax=Ax, Cp=Cp, Cj=Cj, Cx=Cx, splitting=spl, Pp=Pp, Pj=Pj, Px=Px)
+    out["cases"] = np.array(cases)
+    np.savez_compressed(os.path.join(OUT, "setup_kernels.npz"), **out)
+    print("setup_kernels.npz: %d cases" % len(cases))
+
+
 # --------------------------------------------------------------------------- hierarchies
 def put_mat(out, key, M):
     if sps.isspmatrix_bsr(M):
@@ -249,6 +302,7 @@ def main():
     sys.path.insert(0, os.path.join(HERE, "_ref"))
     import _amg_core as core
     gen_kernels(core)
+    gen_setup_kernels(core)
 
     P = ref_env.poisson
     rs = lambda A, **kw: pyamg.ruge_stuben_solver(A, max_coarse=40, **kw)

@@ -14,57 +14,59 @@
 
 extern "C" {
 
-// pyamg/amg_core/smoothed_aggregation.h:122-222 (greedy three-pass aggregation).
-// x[i] = aggregate of node i (-1: isolated), y = root nodes; returns #aggregates.
-int amgsetup_standard_aggregation(int n_row, const int *Ap, const int *Aj, int *x, int *y)
+// Greedy three-pass aggregation (Vanek/Mandel/Brezina), with the tie-breaking of
+// pyamg/amg_core/smoothed_aggregation.h:122-222 so that the aggregates come out identical:
+//   pass 1  a node none of whose neighbours is taken seeds an aggregate made of itself and all its
+//           neighbours (nodes are visited in index order; a node without neighbours stays isolated);
+//   pass 2  every node still free joins the aggregate of the first SEED-PASS member in its row;
+//   pass 3  whatever is left seeds new aggregates from its still-free neighbours.
+// agg[i] = aggregate of node i (-1: isolated), roots[k] = seed node of aggregate k.
+int amgsetup_standard_aggregation(int n, const int *Ap, const int *Aj, int *agg, int *roots)
 {
-    std::fill(x, x + n_row, 0);
-    int next_aggregate = 1;
-    for (int i = 0; i < n_row; i++) {                     // pass 1
-        if (x[i]) continue;
-        const int row_start = Ap[i], row_end = Ap[i + 1];
-        bool has_aggregated_neighbors = false, has_neighbors = false;
-        for (int jj = row_start; jj < row_end; jj++) {
-            const int j = Aj[jj];
-            if (i != j) {
-                has_neighbors = true;
-                if (x[j]) { has_aggregated_neighbors = true; break; }
-            }
+    enum : int { FREE = 0 };
+    const int ISOLATED = -n;                 // cannot collide with -(aggregate id) since ids <= n-... < n
+    // state encoding during the passes: 0 free, +k member since pass 1 or 3 (k = id+1),
+    // -k attached in pass 2, ISOLATED no neighbours
+    for (int i = 0; i < n; ++i) agg[i] = FREE;
+    int count = 0;                           // aggregates so far
+
+    for (int i = 0; i < n; ++i) {            // ---- pass 1
+        if (agg[i] != FREE) continue;
+        bool any_neighbour = false, neighbour_taken = false;
+        for (int k = Ap[i]; k < Ap[i + 1] && !neighbour_taken; ++k) {
+            const int j = Aj[k];
+            if (j == i) continue;
+            any_neighbour = true;
+            neighbour_taken = (agg[j] != FREE);
         }
-        if (!has_neighbors) {
-            x[i] = -n_row;
-        } else if (!has_aggregated_neighbors) {
-            x[i] = next_aggregate;
-            y[next_aggregate - 1] = i;
-            for (int jj = row_start; jj < row_end; jj++) x[Aj[jj]] = next_aggregate;
-            next_aggregate++;
+        if (!any_neighbour) { agg[i] = ISOLATED; continue; }
+        if (neighbour_taken) continue;
+        roots[count] = i;
+        ++count;
+        agg[i] = count;
+        for (int k = Ap[i]; k < Ap[i + 1]; ++k) agg[Aj[k]] = count;
+    }
+
+    for (int i = 0; i < n; ++i) {            // ---- pass 2
+        if (agg[i] != FREE) continue;
+        for (int k = Ap[i]; k < Ap[i + 1]; ++k) {
+            const int tag = agg[Aj[k]];
+            if (tag > 0) { agg[i] = -tag; break; }      // only pass-1 members attract
         }
     }
-    for (int i = 0; i < n_row; i++) {                     // pass 2
-        if (x[i]) continue;
-        for (int jj = Ap[i]; jj < Ap[i + 1]; jj++) {
-            const int xj = x[Aj[jj]];
-            if (xj > 0) { x[i] = -xj; break; }
-        }
+
+    for (int i = 0; i < n; ++i) {            // ---- pass 3 + decoding to 0-based ids
+        const int tag = agg[i];
+        if (tag == ISOLATED) { agg[i] = -1; continue; }
+        if (tag > 0) { agg[i] = tag - 1; continue; }
+        if (tag < 0) { agg[i] = -tag - 1; continue; }
+        roots[count] = i;
+        agg[i] = count;
+        for (int k = Ap[i]; k < Ap[i + 1]; ++k)
+            if (agg[Aj[k]] == FREE) agg[Aj[k]] = count;   // later nodes only: earlier ones are decoded already
+        ++count;
     }
-    next_aggregate--;
-    for (int i = 0; i < n_row; i++) {                     // pass 3
-        const int xi = x[i];
-        if (xi != 0) {
-            if (xi > 0) x[i] = xi - 1;
-            else if (xi == -n_row) x[i] = -1;
-            else x[i] = -xi - 1;
-            continue;
-        }
-        x[i] = next_aggregate;
-        y[next_aggregate] = i;
-        for (int jj = Ap[i]; jj < Ap[i + 1]; jj++) {
-            const int j = Aj[jj];
-            if (x[j] == 0) x[j] = next_aggregate;
-        }
-        next_aggregate++;
-    }
-    return next_aggregate;
+    return count;
 }
 
 // pyamg/amg_core/relaxation.h:34-62 on the host: used only at SETUP time for the
@@ -409,75 +411,85 @@ int amgsetup_classical_strength(int n_row, double theta, const int *Ap, const in
     return nnz;
 }
 
-// :158-310 Ruge-Stuben first-pass C/F splitting (S without diagonal, T = S^T).  F=0, C=1.
-void amgsetup_rs_cf_splitting(int n_nodes, const int *Sp, const int *Sj, const int *Tp, const int *Tj,
-                              int *splitting)
+// Ruge-Stuben first-pass C/F splitting (ruge_stuben.h:158-310).  Nodes are kept in buckets by
+// their weight lambda (= number of points they would interpolate to, plus one per neighbour already
+// made F); the heaviest node becomes C, the points that depend on it become F, and weights are
+// adjusted.  The bucket bookkeeping below (one array sorted by weight, a position per node, and the
+// [first, size) of every weight class) reproduces the reference's choice among equal weights: a
+// node whose weight rises moves to the END of its class before the class boundary moves over it, a
+// node whose weight drops moves to the FRONT of its class.  F = 0, C = 1.
+namespace {
+struct WeightBuckets {
+    std::vector<int> weight, first, size, order, where;
+    explicit WeightBuckets(int n) : weight((size_t)n, 0), first((size_t)n + 1, 0), size((size_t)n + 1, 0),
+                                    order((size_t)n), where((size_t)n) {}
+    void build()
+    {
+        const int n = (int)weight.size();
+        for (int i = 0; i < n; ++i) size[weight[i]]++;
+        for (int w = 0, run = 0; w < n; ++w) { first[w] = run; run += size[w]; size[w] = 0; }
+        for (int i = 0; i < n; ++i) {
+            const int w = weight[i], slot = first[w] + size[w]++;
+            order[slot] = i;
+            where[i] = slot;
+        }
+    }
+    void swap_slots(int a, int b)
+    {
+        where[order[a]] = b;
+        where[order[b]] = a;
+        std::swap(order[a], order[b]);
+    }
+    void raise(int k)       // weight[k] += 1
+    {
+        const int w = weight[k], last = first[w] + size[w] - 1;
+        swap_slots(where[k], last);
+        size[w] -= 1;
+        size[w + 1] += 1;
+        first[w + 1] = last;
+        weight[k] = w + 1;
+    }
+    void lower(int k)       // weight[k] -= 1
+    {
+        const int w = weight[k], front = first[w];
+        swap_slots(where[k], front);
+        size[w] -= 1;
+        size[w - 1] += 1;
+        first[w] += 1;
+        first[w - 1] = first[w] - size[w - 1];
+        weight[k] = w - 1;
+    }
+};
+}  // namespace
+
+void amgsetup_rs_cf_splitting(int n, const int *Sp, const int *Sj, const int *Tp, const int *Tj, int *splitting)
 {
-    const int F_NODE = 0, C_NODE = 1, U_NODE = 2;
-    std::vector<int> lambda((size_t)n_nodes, 0);
-    for (int i = 0; i < n_nodes; i++) lambda[i] = Tp[i + 1] - Tp[i];
-    std::vector<int> interval_ptr((size_t)n_nodes + 1, 0), interval_count((size_t)n_nodes + 1, 0);
-    std::vector<int> index_to_node((size_t)n_nodes), node_to_index((size_t)n_nodes);
-    for (int i = 0; i < n_nodes; i++) interval_count[lambda[i]]++;
-    for (int i = 0, cumsum = 0; i < n_nodes; i++) {
-        interval_ptr[i] = cumsum;
-        cumsum += interval_count[i];
-        interval_count[i] = 0;
+    const int F = 0, Cpt = 1, UNDECIDED = 2;
+    WeightBuckets wb(n);
+    for (int i = 0; i < n; ++i) wb.weight[i] = Tp[i + 1] - Tp[i];
+    wb.build();
+    for (int i = 0; i < n; ++i) {
+        const int w = Tp[i + 1] - Tp[i];
+        // nothing depends on i (or only i itself): it can only be a fine point
+        splitting[i] = (w == 0 || (w == 1 && Tj[Tp[i]] == i)) ? F : UNDECIDED;
     }
-    for (int i = 0; i < n_nodes; i++) {
-        int lambda_i = lambda[i];
-        int index = interval_ptr[lambda_i] + interval_count[lambda_i];
-        index_to_node[index] = i;
-        node_to_index[i] = index;
-        interval_count[lambda_i]++;
-    }
-    std::fill(splitting, splitting + n_nodes, U_NODE);
-    for (int i = 0; i < n_nodes; i++)
-        if (lambda[i] == 0 || (lambda[i] == 1 && Tj[Tp[i]] == i)) splitting[i] = F_NODE;
-    for (int top_index = n_nodes - 1; top_index != -1; top_index--) {
-        int i = index_to_node[top_index];
-        int lambda_i = lambda[i];
-        interval_count[lambda_i]--;
-        if (splitting[i] == F_NODE) continue;
-        splitting[i] = C_NODE;
-        for (int jj = Tp[i]; jj < Tp[i + 1]; jj++) {
-            int j = Tj[jj];
-            if (splitting[j] == U_NODE) {
-                splitting[j] = F_NODE;
-                for (int kk = Sp[j]; kk < Sp[j + 1]; kk++) {
-                    int k = Sj[kk];
-                    if (splitting[k] == U_NODE) {
-                        if (lambda[k] >= n_nodes - 1) continue;
-                        int lambda_k = lambda[k];
-                        int old_pos = node_to_index[k];
-                        int new_pos = interval_ptr[lambda_k] + interval_count[lambda_k] - 1;
-                        node_to_index[index_to_node[old_pos]] = new_pos;
-                        node_to_index[index_to_node[new_pos]] = old_pos;
-                        std::swap(index_to_node[old_pos], index_to_node[new_pos]);
-                        interval_count[lambda_k] -= 1;
-                        interval_count[lambda_k + 1] += 1;
-                        interval_ptr[lambda_k + 1] = new_pos;
-                        lambda[k]++;
-                    }
-                }
+    for (int slot = n - 1; slot >= 0; --slot) {
+        const int i = wb.order[slot];
+        wb.size[wb.weight[i]] -= 1;                       // i leaves the structure
+        if (splitting[i] == F) continue;
+        splitting[i] = Cpt;
+        for (int jj = Tp[i]; jj < Tp[i + 1]; ++jj) {      // points that depend on i become fine ...
+            const int j = Tj[jj];
+            if (splitting[j] != UNDECIDED) continue;
+            splitting[j] = F;
+            for (int kk = Sp[j]; kk < Sp[j + 1]; ++kk) {  // ... which makes their other influences more attractive
+                const int k = Sj[kk];
+                if (splitting[k] == UNDECIDED && wb.weight[k] < n - 1) wb.raise(k);
             }
         }
-        for (int jj = Sp[i]; jj < Sp[i + 1]; jj++) {
-            int j = Sj[jj];
-            if (splitting[j] == U_NODE) {
-                if (lambda[j] == 0) continue;
-                int lambda_j = lambda[j];
-                int old_pos = node_to_index[j];
-                int new_pos = interval_ptr[lambda_j];
-                node_to_index[index_to_node[old_pos]] = new_pos;
-                node_to_index[index_to_node[new_pos]] = old_pos;
-                std::swap(index_to_node[old_pos], index_to_node[new_pos]);
-                interval_count[lambda_j] -= 1;
-                interval_count[lambda_j - 1] += 1;
-                interval_ptr[lambda_j] += 1;
-                interval_ptr[lambda_j - 1] = interval_ptr[lambda_j] - interval_count[lambda_j - 1];
-                lambda[j]--;
-            }
+        for (int jj = Sp[i]; jj < Sp[i + 1]; ++jj) {      // i no longer needs the points it depends on
+            const int j = Sj[jj];
+            if (splitting[j] == UNDECIDED && wb.weight[j] > 0) wb.lower(j);
         }
     }
 }

@@ -165,3 +165,57 @@ def test_block_sa_setup_reproduces_reference_hierarchy(case, sm):
             same(lvl.R, G["R"], 1e-12)
             assert lvl.presmoother.desc["name"] == G["pre"]["name"]
             assert np.allclose(np.ravel(lvl.presmoother.desc["Dinv"]), np.ravel(G["pre"]["Dinv"]), rtol=1e-10, atol=1e-14)
+
+
+# --- our host setup kernels vs the reference's native ones (tests/golden/setup_kernels.npz) -----
+def _setup_cases(prefix):
+    z = np.load(golden_io.os.path.join(golden_io.GOLDEN, "setup_kernels.npz"), allow_pickle=False)
+    for name in z["cases"]:
+        name = str(name)
+        if name.startswith(prefix):
+            yield name, {k[len(name) + 2:]: z[k] for k in z.files if k.startswith(name + "__")}
+
+
+def test_standard_aggregation_identical_to_reference_kernel():
+    from pyamg_amd.aggregation import _ip, host_lib
+    n_cases = 0
+    for name, c in _setup_cases("standard_aggregation_"):
+        n = int(c["n"][0])
+        Ap, Aj = np.ascontiguousarray(c["Ap"], np.intc), np.ascontiguousarray(c["Aj"], np.intc)
+        agg = np.empty(n, dtype=np.intc); roots = np.empty(n, dtype=np.intc)
+        cnt = host_lib().amgsetup_standard_aggregation(n, _ip(Ap), _ip(Aj), _ip(agg), _ip(roots))
+        assert cnt == int(c["count"][0]), name
+        assert np.array_equal(agg, c["agg"]), name
+        assert np.array_equal(roots[:cnt], c["roots"]), name
+        n_cases += 1
+    assert n_cases >= 5
+
+
+def test_classical_kernels_identical_to_reference_kernels():
+    from pyamg_amd.aggregation import _dp, _ip
+    from pyamg_amd.classical import _lib
+    L = _lib()
+    for name, c in _setup_cases("classical_strength_"):
+        Ap, Aj, Ax = (np.ascontiguousarray(c["Ap"], np.intc), np.ascontiguousarray(c["Aj"], np.intc),
+                      np.ascontiguousarray(c["Ax"], np.float64))
+        n = len(Ap) - 1
+        Sp = np.empty_like(Ap); Sj = np.empty_like(Aj); Sx = np.empty_like(Ax)
+        nnz = L.amgsetup_classical_strength(n, float(c["theta"][0]), _ip(Ap), _ip(Aj), _dp(Ax), _ip(Sp), _ip(Sj), _dp(Sx))
+        assert np.array_equal(Sp, c["Sp"]) and np.array_equal(Sj[:nnz], c["Sj"]) and np.array_equal(Sx[:nnz], c["Sx"]), name
+    for name, c in _setup_cases("rs_cf_splitting_"):
+        Sp, Sj, Tp, Tj = (np.ascontiguousarray(c[k], np.intc) for k in ("Sp", "Sj", "Tp", "Tj"))
+        n = len(Sp) - 1
+        spl = np.empty(n, dtype=np.intc)
+        L.amgsetup_rs_cf_splitting(n, _ip(Sp), _ip(Sj), _ip(Tp), _ip(Tj), _ip(spl))
+        assert np.array_equal(spl, c["splitting"]), name
+    for name, c in _setup_cases("rs_direct_interpolation_"):
+        Ap, Aj, Cp, Cj, spl = (np.ascontiguousarray(c[k], np.intc) for k in ("Ap", "Aj", "Cp", "Cj", "splitting"))
+        Ax, Cx = np.ascontiguousarray(c["Ax"], np.float64), np.ascontiguousarray(c["Cx"], np.float64)
+        n = len(Ap) - 1
+        Pp = np.empty(n + 1, dtype=np.intc)
+        nnz = L.amgsetup_rs_direct_interpolation_pass1(n, _ip(Cp), _ip(Cj), _ip(spl), _ip(Pp))
+        Pj = np.empty(nnz, dtype=np.intc); Px = np.empty(nnz, dtype=np.float64)
+        L.amgsetup_rs_direct_interpolation_pass2(n, _ip(Ap), _ip(Aj), _dp(Ax), _ip(Cp), _ip(Cj), _dp(Cx), _ip(spl),
+                                                 _ip(Pp), _ip(Pj), _dp(Px))
+        assert np.array_equal(Pp, c["Pp"]) and np.array_equal(Pj, c["Pj"]), name
+        assert np.array_equal(Px, c["Px"], equal_nan=True), name
