@@ -303,12 +303,19 @@ def main():
         A0 = ml.levels[0].A
         spmv_bytes = 12.0 * A0.nnz + 4.0 * (n + 1) + 8.0 * n + 8.0 * n + 8.0 * n   # bytes_spmv(A0) + 8 n
         reps = 20
-        ms_resid = dev.time_spmv(0, 0, mode=1, reps=reps)     # r = b - A x  (csr_stream_kernel<SM_RESIDUAL>)
+        ms_resid = dev.time_spmv(0, 0, mode=1, reps=reps)     # r = b - A x as the cycle runs it
+        ms_resid_csr = dev.time_spmv(0, 0, mode=3, reps=reps) # the same through the plain CSR stream kernel
         ms_matvec = dev.time_spmv(0, 0, mode=0, reps=reps)
         ms_P = dev.time_spmv(0, 1, mode=0, reps=reps)
         ms_R = dev.time_spmv(0, 2, mode=0, reps=reps)
         ach = spmv_bytes / (ms_resid * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": "csr_stream_kernel (level-0 A-application, r = b - A x)",
+        pattern = abs(ms_resid - ms_resid_csr) > 0.02 * ms_resid_csr
+        moved = (8.0 * A0.nnz + 4.0 * n + 4.0 * (n + 1) + 24.0 * n) if pattern else spmv_bytes
+        roofline = {"bound": "hbm",
+                    "kernel": ("csr_pattern_kernel" if pattern else "csr_stream_kernel") +
+                              " (level-0 A-application, r = b - A x)",
+                    "bytes_moved_per_launch": moved, "moved_GBs": round(moved / (ms_resid * 1e-3) / 1e9, 1),
+                    "plain_csr_stream_ms_per_launch": round(ms_resid_csr, 4),
                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                     "bytes_per_launch": spmv_bytes, "ms_per_launch": round(ms_resid, 4),

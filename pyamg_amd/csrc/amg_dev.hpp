@@ -29,7 +29,18 @@ struct DevCsr {
     int *Aj = nullptr;
     double *Ax = nullptr;
     bool owned = true;
+    // Offset-pattern form of the column indices (square operators on structured grids): row i's
+    // columns are i + dict_off[dict_ptr[pat[i]] .. ], with a dictionary of a few distinct offset
+    // tuples.  When present, the pattern kernel streams 8 B per entry + 4 B per row instead of
+    // 12 B per entry; results are identical (same entries, same order).
+    int *pat = nullptr;        // [nrows] pattern id of every row
+    int *dict_ptr = nullptr;   // [npat+1]
+    int *dict_off = nullptr;   // [ndict]
+    int npat = 0, ndict = 0;
 };
+
+constexpr int PAT_MAX = 255;       // distinct row patterns kept in LDS
+constexpr int PAT_DICT_MAX = 2048; // total offsets in the dictionary
 
 struct DevBsr {   // block rows, for the block / point-BSR relaxation kernels
     int nbrows = 0, bs = 1;
@@ -79,6 +90,9 @@ struct StreamArgs {
 
 // variant: 0 = scalar (8 B / 4 B per lane) loads, 1 = 16-byte vector loads
 int launch_stream(StreamMode mode, const StreamArgs &a, hipStream_t st);
+// same modes (except the GS ones) through the offset-pattern form of M's column indices
+int launch_pattern(StreamMode mode, const StreamArgs &a, const DevCsr &M, hipStream_t st);
+bool pattern_supports(StreamMode mode);
 int stream_blocks(const StreamArgs &a);   // workgroups launch_stream will use (partials of SM_RESIDUAL_SUMSQ)
 int launch_sum_sqrt(const double *partial, long np, double *scratch512, double *result_dev, hipStream_t st);   // sqrt(sum), fixed order
 int launch_axpy_scaled(double *x, const double *r, double c, long n, hipStream_t st);        // x += c*r

@@ -47,6 +47,9 @@ static void free_csr(DevCsr &M)
     if (M.Ap) hipFree(M.Ap);
     if (M.Aj) hipFree(M.Aj);
     if (M.Ax) hipFree(M.Ax);
+    if (M.pat) hipFree(M.pat);
+    if (M.dict_ptr) hipFree(M.dict_ptr);
+    if (M.dict_off) hipFree(M.dict_off);
     M = DevCsr();
 }
 static void free_bsr(DevBsr &M)
@@ -71,6 +74,55 @@ int upload_csr(DevCsr &M, int nrows, int ncols, const int *Ap, const int *Aj, co
         AMG_HIP(hipMemcpy(M.Aj, Aj, sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice));
         AMG_HIP(hipMemcpy(M.Ax, Ax, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice));
     }
+    return 0;
+}
+
+// Offset-pattern analysis of a square operator (host, O(nnz)): succeeds when the rows use at most
+// PAT_MAX distinct tuples of (column - row) with PAT_DICT_MAX offsets in total -- i.e. stencil
+// operators.  On success the pattern ids and the dictionary go to HBM next to the CSR arrays.
+int try_patterns(DevCsr &M, const int *Ap, const int *Aj, long *acct)
+{
+    const char *env = getenv("AMG_PATTERN");
+    if (env && atoi(env) == 0) return 0;
+    const int n = M.nrows;
+    if (n != M.ncols || n < 1024) return 0;
+    std::vector<int> pat((size_t)n), dptr(1, 0), doff;
+    // open-addressing table: hash of the offset tuple -> pattern id
+    const int TBL = 1024;
+    std::vector<int> tbl((size_t)TBL, -1);
+    std::vector<uint64_t> thash((size_t)TBL, 0);
+    for (int i = 0; i < n; ++i) {
+        const int s = Ap[i], e = Ap[i + 1], len = e - s;
+        uint64_t hsh = 1469598103934665603ULL ^ (uint64_t)len;
+        for (int k = s; k < e; ++k) { hsh ^= (uint64_t)(uint32_t)(Aj[k] - i); hsh *= 1099511628211ULL; }
+        int slot = (int)(hsh & (TBL - 1)), id = -1;
+        for (int probe = 0; probe < TBL; ++probe, slot = (slot + 1) & (TBL - 1)) {
+            if (tbl[slot] < 0) break;
+            if (thash[slot] != hsh) continue;
+            const int c = tbl[slot];
+            if (dptr[c + 1] - dptr[c] != len) continue;
+            bool same = true;
+            for (int q = 0; q < len && same; ++q) same = (doff[dptr[c] + q] == Aj[s + q] - i);
+            if (same) { id = c; break; }
+        }
+        if (id < 0) {
+            id = (int)dptr.size() - 1;
+            if (id >= PAT_MAX || (int)doff.size() + len > PAT_DICT_MAX) return 0;   // not a stencil operator
+            for (int k = s; k < e; ++k) doff.push_back(Aj[k] - i);
+            dptr.push_back((int)doff.size());
+            tbl[slot] = id;
+            thash[slot] = hsh;
+        }
+        pat[i] = id;
+    }
+    M.npat = (int)dptr.size() - 1;
+    M.ndict = (int)doff.size();
+    CHK(dev_alloc(&M.pat, n, acct));
+    CHK(dev_alloc(&M.dict_ptr, M.npat + 1, acct));
+    CHK(dev_alloc(&M.dict_off, M.ndict, acct));
+    AMG_HIP(hipMemcpy(M.pat, pat.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
+    AMG_HIP(hipMemcpy(M.dict_ptr, dptr.data(), sizeof(int) * dptr.size(), hipMemcpyHostToDevice));
+    if (M.ndict) AMG_HIP(hipMemcpy(M.dict_off, doff.data(), sizeof(int) * doff.size(), hipMemcpyHostToDevice));
     return 0;
 }
 
@@ -248,6 +300,7 @@ int spmv(const DevCsr &M, StreamMode mode, const double *xg, const double *b, co
 {
     StreamArgs a = base_args(M);
     a.xg = xg; a.b = b; a.v2 = v2; a.out = out; a.out2 = out2; a.c0 = c0;
+    if (M.pat && pattern_supports(mode)) return launch_pattern(mode, a, M, st);
     return launch_stream(mode, a, st);
 }
 
@@ -257,6 +310,7 @@ static int spmv_scaled(const DevCsr &M, StreamMode mode, const double *xg, doubl
 {
     StreamArgs a = base_args(M);
     a.xg = xg; a.b = b; a.v2 = v2; a.out = out; a.c0 = c0; a.gscale = gscale;
+    if (M.pat && pattern_supports(mode)) return launch_pattern(mode, a, M, st);
     return launch_stream(mode, a, st);
 }
 
@@ -530,7 +584,8 @@ static int residual_norm_to(amg_hier *h, double *slot)
     a.xg = L0.x; a.b = L0.b; a.out2 = h->sumsq_partials;
     const int nb = stream_blocks(a);
     if (nb > h->sumsq_cap) { set_error("sumsq partial buffer too small"); return AMG_ESTATE; }
-    CHK(launch_stream(SM_RESIDUAL_SUMSQ, a, h->stream));
+    if (L0.A.pat) CHK(launch_pattern(SM_RESIDUAL_SUMSQ, a, L0.A, h->stream));
+    else CHK(launch_stream(SM_RESIDUAL_SUMSQ, a, h->stream));
     return launch_sum_sqrt(h->sumsq_partials, nb, h->sumsq_partials + h->sumsq_cap, slot, h->stream);
 }
 
@@ -724,6 +779,7 @@ int amg_hier_set_matrix(amg_hier *h, int lvl, int which, int fmt, int nrows, int
         }
     } else if (fmt == AMG_FMT_CSR || (R == 1 && C == 1)) {
         CHK(upload_csr(M, nrows, ncols, Ap, Aj, Ax, &h->dev_bytes));
+        if (which == AMG_MAT_A) CHK(try_patterns(M, Ap, Aj, &h->dev_bytes));
     } else {
         std::vector<int> cp, cj;
         std::vector<double> cx;
@@ -1218,10 +1274,13 @@ int amg_hier_time_spmv(amg_hier *h, int lvl, int which, int mode, int reps, doub
     if (which == AMG_MAT_A) { in = L.x; out = L.r; }
     else if (which == AMG_MAT_P) { in = h->lv[lvl + 1].x; out = L.h; }
     else { in = L.r; out = h->lv[lvl + 1].b; }
-    StreamMode sm = (mode == 1 && which == AMG_MAT_A) ? SM_RESIDUAL : SM_MATVEC;
-    CHK(spmv(M, sm, in, L.b, nullptr, out, nullptr, 0.0, h->stream));   // warm-up
+    StreamMode sm = ((mode & 1) && which == AMG_MAT_A) ? SM_RESIDUAL : SM_MATVEC;
+    DevCsr Mplain = M;                     // mode bit 1 (value 2): time the plain CSR kernel even if
+    if (mode & 2) Mplain.pat = nullptr;    // the operator also has the offset-pattern form
+    const DevCsr &Mu = (mode & 2) ? Mplain : M;
+    CHK(spmv(Mu, sm, in, L.b, nullptr, out, nullptr, 0.0, h->stream));   // warm-up
     AMG_HIP(hipEventRecord(h->ev0, h->stream));
-    for (int r = 0; r < reps; ++r) CHK(spmv(M, sm, in, L.b, nullptr, out, nullptr, 0.0, h->stream));
+    for (int r = 0; r < reps; ++r) CHK(spmv(Mu, sm, in, L.b, nullptr, out, nullptr, 0.0, h->stream));
     AMG_HIP(hipEventRecord(h->ev1, h->stream));
     AMG_HIP(hipStreamSynchronize(h->stream));
     float t = 0.f;

@@ -315,6 +315,191 @@ __global__ __launch_bounds__(WG) void csr_stream_kernel(StreamArgs a, int xcd_ch
     }
 }
 
+// ---------------------------------------------------------------------------
+// csr_pattern: the same operator application for matrices whose rows repeat a few column-offset
+// patterns (stencil operators: 27 patterns for a 7-point grid operator with boundaries).  Only the
+// values are streamed (8 B per entry, 16-byte loads through the same LDS tile); a row's columns
+// come from its pattern id (4 B per row) and the dictionary held in LDS.  Thread t gathers
+// x[i + off_j] for ITS row -- neighbouring lanes read neighbouring addresses, so the gather is
+// coalesced -- and accumulates in storage order: bit-identical to csr_stream, 21 % fewer bytes
+// on the 7-point level.
+// ---------------------------------------------------------------------------
+struct PatternArgs {
+    const int *pat;
+    const int *dict_ptr;
+    const int *dict_off;
+    int npat, ndict;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(WG) void csr_pattern_kernel(StreamArgs a, PatternArgs P, int xcd_chunk, int rpb)
+{
+    using MT = ModeTraits<MODE>;
+    __shared__ double sp[TILE];
+    __shared__ int sAp[WG + 1];
+    __shared__ int sDptr[PAT_MAX + 2];
+    __shared__ int sDict[PAT_DICT_MAX];
+
+    const int t = threadIdx.x;
+    const int blk = remap_block(blockIdx.x, gridDim.x, xcd_chunk);
+    const int r0 = a.row_lo + blk * rpb;
+    const int nr = min(rpb, a.row_hi - r0);
+    const double gscale = a.gscale;
+    const long nnz_total = a.nnz_total;
+
+    for (int i = t; i <= nr; i += WG) sAp[i] = a.Ap[r0 + i];
+    for (int i = t; i <= P.npat; i += WG) sDptr[i] = P.dict_ptr[i];
+    for (int i = t; i < P.ndict; i += WG) sDict[i] = P.dict_off[i];
+    __syncthreads();
+
+    const int kbeg = sAp[0], kend = sAp[nr];
+    const int my_s = (t < nr) ? sAp[t] : kend;
+    const int my_e = (t < nr) ? sAp[t + 1] : kend;
+    const int i = r0 + t;
+    const int *offs = sDict;
+    if (t < nr) offs = &sDict[sDptr[P.pat[i]]];
+    double acc = 0.0, diag = 0.0;
+    if (MT::sub && t < nr) acc = a.b[i];
+
+    const int abeg = kbeg & ~3;
+    for (int tile_lo = abeg; tile_lo < kend; tile_lo += TILE) {
+        const int tile_hi = min(tile_lo + TILE, kend);
+        constexpr int NQ = TILE / (4 * WG);
+#pragma unroll
+        for (int p = 0; p < NQ; ++p) {
+            const int e = tile_lo + p * (4 * WG) + 4 * t;
+            if (e < tile_hi) {
+                v2d v0, v1;
+                if ((long)e + 4 <= nnz_total) {
+                    v0 = load_v2d(a.Ax + e);
+                    v1 = load_v2d(a.Ax + e + 2);
+                } else {
+                    double v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) v[u] = ((long)e + u < nnz_total) ? a.Ax[e + u] : 0.0;
+                    v0 = v2d{v[0], v[1]};
+                    v1 = v2d{v[2], v[3]};
+                }
+                const int q = e - tile_lo;
+                *reinterpret_cast<v2d *>(&sp[q]) = v0;
+                *reinterpret_cast<v2d *>(&sp[q + 2]) = v1;
+            }
+        }
+        __syncthreads();
+        {
+            const int s = max(my_s, tile_lo), e2 = min(my_e, tile_hi);
+            // batches of 8 entries: all gathers of a batch are in flight together
+            for (int k0 = s; k0 < e2; k0 += 8) {
+                double xv[8];
+                int off[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int k = k0 + u;
+                    off[u] = (k < e2) ? offs[k - my_s] : 0;
+                    xv[u] = (k < e2) ? a.xg[i + off[u]] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int k = k0 + u;
+                    if (k < e2) {
+                        const double av = sp[k - tile_lo];
+                        if (MT::jac && off[u] == 0) { diag = av; continue; }
+                        const double pr = av * (gscale * xv[u]);
+                        acc = MT::sub ? (acc - pr) : (acc + pr);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    if (MODE == SM_RESIDUAL_SUMSQ) {
+        double sq = 0.0;
+        if (t < nr) { double rr = a.b[i] - acc; sq = rr * rr; }
+        __syncthreads();
+        double tot = block_reduce_sum(sq, sp);
+        if (t == 0) a.out2[blk] = tot;
+        return;
+    }
+    if (t >= nr) return;
+    if (MODE == SM_MATVEC) {
+        store_out(&a.out[i], acc);
+    } else if (MODE == SM_MATVEC_ACC) {
+        store_out(&a.out[i], a.out[i] + acc);
+    } else if (MODE == SM_RESIDUAL) {
+        store_out(&a.out[i], a.b[i] - acc);
+    } else if (MODE == SM_POLY_STEP) {
+        double cr = a.c0 * a.b[i];
+        a.out[i] = cr + acc;
+    } else if (MODE == SM_POLY_LAST) {
+        double cr = a.c0 * a.b[i];
+        double h = cr + acc;
+        store_out(&a.out[i], a.v2[i] + h);
+    } else if (MODE == SM_JACOBI) {
+        double told = a.v2[i];
+        if (diag != 0.0) {
+            double q = (a.b[i] - acc) / diag;
+            double t1 = (1.0 - a.c0) * told;
+            double t2 = a.c0 * q;
+            a.out[i] = t1 + t2;
+        } else {
+            a.out[i] = told;
+        }
+    } else if (MODE == SM_JACOBI_BSR1) {
+        double told = a.v2[i];
+        if (diag != 0.0) {
+            double t1 = (1.0 - a.c0) * told;
+            double t2 = (a.c0 * acc) / diag;
+            a.out[i] = t1 + t2;
+        } else {
+            a.out[i] = told;
+        }
+    }
+}
+
+bool pattern_supports(StreamMode mode)
+{
+    switch (mode) {
+    case SM_MATVEC: case SM_MATVEC_ACC: case SM_RESIDUAL: case SM_POLY_STEP: case SM_POLY_LAST:
+    case SM_JACOBI: case SM_JACOBI_BSR1: case SM_RESIDUAL_SUMSQ: return true;
+    default: return false;
+    }
+}
+
+template <int MODE>
+static int launch_pattern_mode(const StreamArgs &a, const PatternArgs &P, hipStream_t st)
+{
+    int rows = a.row_hi - a.row_lo;
+    if (rows <= 0) return 0;
+    int rpb = a.rows_per_wg;
+    if (rpb < 1 || rpb > WG) rpb = WG;
+    int nb = (rows + rpb - 1) / rpb;
+    StreamArgs b = a;
+    if (b.gscale == 0.0) b.gscale = 1.0;
+    hipLaunchKernelGGL((csr_pattern_kernel<MODE>), dim3(nb), dim3(WG), 0, st, b, P, g_xcd_chunk, rpb);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "csr_pattern launch", __FILE__, __LINE__);
+    return 0;
+}
+
+int launch_pattern(StreamMode mode, const StreamArgs &a, const DevCsr &M, hipStream_t st)
+{
+    PatternArgs P{M.pat, M.dict_ptr, M.dict_off, M.npat, M.ndict};
+    switch (mode) {
+    case SM_MATVEC: return launch_pattern_mode<SM_MATVEC>(a, P, st);
+    case SM_MATVEC_ACC: return launch_pattern_mode<SM_MATVEC_ACC>(a, P, st);
+    case SM_RESIDUAL: return launch_pattern_mode<SM_RESIDUAL>(a, P, st);
+    case SM_POLY_STEP: return launch_pattern_mode<SM_POLY_STEP>(a, P, st);
+    case SM_POLY_LAST: return launch_pattern_mode<SM_POLY_LAST>(a, P, st);
+    case SM_JACOBI: return launch_pattern_mode<SM_JACOBI>(a, P, st);
+    case SM_JACOBI_BSR1: return launch_pattern_mode<SM_JACOBI_BSR1>(a, P, st);
+    case SM_RESIDUAL_SUMSQ: return launch_pattern_mode<SM_RESIDUAL_SUMSQ>(a, P, st);
+    default: break;
+    }
+    set_error("launch_pattern: mode not supported");
+    return -1;
+}
+
 template <int MODE>
 static int launch_stream_mode(const StreamArgs &a, hipStream_t st)
 {
