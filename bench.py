@@ -305,28 +305,36 @@ def main():
         reps = 20
         ms_resid = dev.time_spmv(0, 0, mode=1, reps=reps)     # r = b - A x as the cycle runs it
         ms_resid_csr = dev.time_spmv(0, 0, mode=3, reps=reps) # the same through the plain CSR stream kernel
+        ms_resid_pat = dev.time_spmv(0, 0, mode=5, reps=reps) # ... and through the offset-pattern kernel
         ms_matvec = dev.time_spmv(0, 0, mode=0, reps=reps)
         ms_P = dev.time_spmv(0, 1, mode=0, reps=reps)
         ms_R = dev.time_spmv(0, 2, mode=0, reps=reps)
         ach = spmv_bytes / (ms_resid * 1e-3) / 1e9
-        pattern = abs(ms_resid - ms_resid_csr) > 0.02 * ms_resid_csr
-        moved = (8.0 * A0.nnz + 4.0 * n + 4.0 * (n + 1) + 24.0 * n) if pattern else spmv_bytes
+        form = L.amg_hier_operator_form(h, 0)
+        moved = L.amg_hier_operator_bytes(h, 0, 1)
+        kname = {0: "csr_stream_kernel", 1: "csr_pattern_kernel", 2: "stencil_kernel"}[form]
+        # `achieved` prices the launch at the CSR bytes of SURVEY.md 8(d) (12 B per stored entry), the figure
+        # the reference's csr_matvec would have to stream; `moved_GBs` prices it at what this kernel's
+        # storage form actually streams -- that one is bounded by the HBM peak.
         roofline = {"bound": "hbm",
-                    "kernel": ("csr_pattern_kernel" if pattern else "csr_stream_kernel") +
-                              " (level-0 A-application, r = b - A x)",
+                    "kernel": kname + " (level-0 A-application, r = b - A x)",
                     "bytes_moved_per_launch": moved, "moved_GBs": round(moved / (ms_resid * 1e-3) / 1e9, 1),
+                    "moved_frac": round(moved / (ms_resid * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                     "plain_csr_stream_ms_per_launch": round(ms_resid_csr, 4),
+                    "pattern_kernel_ms_per_launch": round(ms_resid_pat, 4),
                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                     "bytes_per_launch": spmv_bytes, "ms_per_launch": round(ms_resid, 4),
                     "cycle_bytes": cycle_bytes,
                     "cycle_achieved_GBs": round(cycle_bytes * (args.steps / (ev_ms * 1e-3)) / 1e9, 1),
+                    "cycle_bytes_moved": dev.cycle_bytes_moved("V"),
+                    "cycle_moved_GBs": round(dev.cycle_bytes_moved("V") * (args.steps / (ev_ms * 1e-3)) / 1e9, 1),
                     "other_kernels_ms": {"A0_matvec": round(ms_matvec, 4), "P0_matvec": round(ms_P, 4),
                                          "R0_matvec": round(ms_R, 4)}}
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
         if os.path.exists(pmc):
             pj = json.load(open(pmc))
-            if pj.get("grid") == args.grid:
+            if pj.get("grid") == args.grid and pj.get("form") == form:
                 # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel (profiles/README.md);
                 # FETCH_SIZE doubled per MI355X_MICROARCH.md (calibrated on a known 1e9-byte read)
                 roofline["traffic"] = pj["traffic_bytes"]

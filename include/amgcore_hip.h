@@ -196,6 +196,13 @@ int amg_hier_matvec(amg_hier *h, int lvl, int which, const double *x, double *y)
 /* bookkeeping for measurement */
 /* algorithmic bytes of one cycle per SURVEY.md section 8(d) */
 double amg_hier_cycle_bytes(amg_hier *h, int cycle);
+/* storage form level lvl's A is applied from: 0 CSR, 1 offset-pattern, 2 stencil */
+int amg_hier_operator_form(amg_hier *h, int lvl);
+/* bytes of one r = b - A x on level lvl: moved = 0 the CSR figure of SURVEY.md 8(d), 1 what the form in use streams */
+double amg_hier_operator_bytes(amg_hier *h, int lvl, int moved);
+/* bytes one solve() iteration needs as this library runs it: offset-pattern operators without
+ * their column indices, and one level-0 application less when the outer residual is kept */
+double amg_hier_cycle_bytes_moved(amg_hier *h, int cycle);
 /* device time of the timed part of the last amg_hier_solve, ms (hipEvents on the solve stream) */
 double amg_hier_last_solve_ms(amg_hier *h);
 long amg_hier_device_bytes(amg_hier *h);
@@ -258,11 +265,21 @@ void amg_arnoldi_free(amg_hier *h);
 /* replay each iteration (cycle + residual norm) from a hipGraph once its launch sequence has
  * been seen (default on; env AMG_HIP_GRAPHS=0 disables).  Speed only: same kernels, same order. */
 void amg_hier_use_graphs(amg_hier *h, int on);
+/* on (default): amg_hier_solve keeps the residual vector b - A x it forms for the convergence test
+ * (multilevel.py:461) and a polynomial pre-smoother on level 0 starts from it instead of forming
+ * the same b - A x again (relaxation.py:655).  Same bits either way; off restores the two passes. */
+void amg_hier_keep_residual(amg_hier *h, int on);
 
 /* tuning knobs (speed only): 0 = scalar loads, 1 = 16-byte loads in the CSR stream kernel;
  * XCD chunk: consecutive row blocks given to one XCD (0 = round-robin dispatch order) */
 void amg_set_stream_variant(int v);
 void amg_set_xcd_chunk(int c);
+/* 1 (default): operators in offset-pattern form map row blocks to XCDs periodically in the slowest
+ * grid axis, so one XCD's L2 serves a row's neighbours in the planes above and below; 0: chunked */
+void amg_set_xcd_period(int on);
+/* 1 (default): operators whose rows are subsets of one stencil of <= 32 offsets are applied from
+ * the stencil form (padded values + row masks, no indices); 0: from the pattern / CSR forms */
+void amg_set_stencil_form(int on);
 /* products per workgroup aimed at when choosing rows per workgroup (default 2048 = one LDS tile) */
 void amg_set_tile_target(int t);
 

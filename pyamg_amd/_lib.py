@@ -116,6 +116,12 @@ def lib():
     L.amg_hier_destroy.restype = None
     L.amg_hier_cycle_bytes.argtypes = [V, I]
     L.amg_hier_cycle_bytes.restype = D
+    L.amg_hier_operator_form.argtypes = [V, I]
+    L.amg_hier_operator_form.restype = I
+    L.amg_hier_operator_bytes.argtypes = [V, I, I]
+    L.amg_hier_operator_bytes.restype = D
+    L.amg_hier_cycle_bytes_moved.argtypes = [V, I]
+    L.amg_hier_cycle_bytes_moved.restype = D
     L.amg_hier_last_solve_ms.argtypes = [V]
     L.amg_hier_last_solve_ms.restype = D
     L.amg_hier_device_bytes.argtypes = [V]
@@ -140,8 +146,14 @@ def lib():
     L.amg_set_stream_variant.restype = None
     L.amg_hier_use_graphs.argtypes = [V, I]
     L.amg_hier_use_graphs.restype = None
+    L.amg_hier_keep_residual.argtypes = [V, I]
+    L.amg_hier_keep_residual.restype = None
     L.amg_set_tile_target.argtypes = [I]
     L.amg_set_tile_target.restype = None
+    L.amg_set_stencil_form.argtypes = [I]
+    L.amg_set_stencil_form.restype = None
+    L.amg_set_xcd_period.argtypes = [I]
+    L.amg_set_xcd_period.restype = None
     L.amg_set_xcd_chunk.argtypes = [I]
     L.amg_set_xcd_chunk.restype = None
     _lib = L

@@ -37,7 +37,19 @@ struct DevCsr {
     int *dict_ptr = nullptr;   // [npat+1]
     int *dict_off = nullptr;   // [ndict]
     int npat = 0, ndict = 0;
+    int period_rows = 0;       // largest |column - row| of the dictionary: the stride of the slowest grid axis
+    // Stencil form (a second copy of the values, built on the device when every row's offsets are
+    // an increasing subset of one union stencil U of at most STENCIL_MAX offsets): slot u of row i
+    // holds a(i, i+U[u]) if bit u of mask[i] is set.  Values are laid out [block][slot][256 rows],
+    // so every load of the kernel is issued up front, coalesced, with no row pointer, no column
+    // index and no LDS staging; x[i+U[u]] is gathered speculatively and masked.
+    double *st_vals = nullptr;     // [nblocks256 * st_nu * 256]
+    void *st_mask = nullptr;       // [nrows] uint8 when |U| <= 8, else uint32
+    int st_nu = 0;                 // |U|
+    int st_u0 = -1;                // slot of offset 0 (the diagonal), -1 if absent
+    int st_off[32] = {0};          // U, increasing
 };
+constexpr int STENCIL_MAX = 32;
 
 constexpr int PAT_MAX = 255;       // distinct row patterns kept in LDS
 constexpr int PAT_DICT_MAX = 2048; // total offsets in the dictionary
@@ -65,7 +77,7 @@ enum StreamMode {
     SM_JACOBI_BSR1,     // rs=b[i]; rs-=p..; out[i] = (1-w)*v2[i] + w*rs/d   (relaxation.h:268-360, bs=1)
     SM_GS,              // out[row] = (b[row]-s)/d                      (relaxation.h:34-62, one level)
     SM_GS_BSR1,         // rs=b[row]; rs-=p..; out[row] = rs/d          (relaxation.h:90-173, bs=1)
-    SM_RESIDUAL_SUMSQ,  // out2[block] = sum over the block's rows of (b[i]-s)^2; r is not stored
+    SM_RESIDUAL_SUMSQ,  // out2[block] = sum over the block's rows of (b[i]-s)^2; r stored only if out != nullptr
                         // (the outer residual norm, multilevel.py:461, without the 16n vector round trip)
 };
 
@@ -93,6 +105,12 @@ int launch_stream(StreamMode mode, const StreamArgs &a, hipStream_t st);
 // same modes (except the GS ones) through the offset-pattern form of M's column indices
 int launch_pattern(StreamMode mode, const StreamArgs &a, const DevCsr &M, hipStream_t st);
 bool pattern_supports(StreamMode mode);
+int launch_stencil(StreamMode mode, const StreamArgs &a, const DevCsr &M, hipStream_t st);
+int stencil_blocks(const StreamArgs &a);   // workgroups (= SM_RESIDUAL_SUMSQ partials) of launch_stencil
+int launch_stencil_build(const DevCsr &M, const int *dict_slot, const unsigned *pat_mask, hipStream_t st);
+bool stencil_enabled();
+void set_stencil_form(int on);           // 0: dispatch pattern operators to csr_pattern_kernel instead
+void set_xcd_period(int on);             // plane-periodic block->XCD mapping of pattern operators (default on)
 int stream_blocks(const StreamArgs &a);   // workgroups launch_stream will use (partials of SM_RESIDUAL_SUMSQ)
 int launch_sum_sqrt(const double *partial, long np, double *scratch512, double *result_dev, hipStream_t st);   // sqrt(sum), fixed order
 int launch_axpy_scaled(double *x, const double *r, double c, long n, hipStream_t st);        // x += c*r

@@ -50,6 +50,8 @@ static void free_csr(DevCsr &M)
     if (M.pat) hipFree(M.pat);
     if (M.dict_ptr) hipFree(M.dict_ptr);
     if (M.dict_off) hipFree(M.dict_off);
+    if (M.st_vals) hipFree(M.st_vals);
+    if (M.st_mask) hipFree(M.st_mask);
     M = DevCsr();
 }
 static void free_bsr(DevBsr &M)
@@ -75,6 +77,53 @@ int upload_csr(DevCsr &M, int nrows, int ncols, const int *Ap, const int *Aj, co
         AMG_HIP(hipMemcpy(M.Ax, Ax, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice));
     }
     return 0;
+}
+
+// Stencil form on top of the pattern dictionary: possible when the union U of all offsets has at
+// most STENCIL_MAX members, every pattern lists its offsets in increasing order (then slot order
+// = stored order) and the padding (rows that lack some of U) costs less than a fifth of the
+// values.  The value copy is built on the device from the CSR arrays already there.
+static int try_stencil(DevCsr &M, const std::vector<int> &dptr, const std::vector<int> &doff, long *acct)
+{
+    const char *env = getenv("AMG_STENCIL");
+    if (env && atoi(env) == 0) return 0;
+    std::vector<int> U(doff);
+    std::sort(U.begin(), U.end());
+    U.erase(std::unique(U.begin(), U.end()), U.end());
+    const int nu = (int)U.size();
+    if (nu < 1 || nu > STENCIL_MAX) return 0;
+    if ((double)M.nnz < 0.8 * (double)M.nrows * nu) return 0;
+    const int npat = (int)dptr.size() - 1;
+    std::vector<int> slot(doff.size());
+    std::vector<unsigned> pmask((size_t)npat, 0u);
+    for (int p = 0; p < npat; ++p) {
+        for (int q = dptr[p]; q < dptr[p + 1]; ++q) {
+            if (q > dptr[p] && doff[q] <= doff[q - 1]) return 0;           // stored order is not by column
+            slot[q] = (int)(std::lower_bound(U.begin(), U.end(), doff[q]) - U.begin());
+            pmask[p] |= 1u << slot[q];
+        }
+    }
+    M.st_nu = nu;
+    M.st_u0 = -1;
+    for (int u = 0; u < nu; ++u) { M.st_off[u] = U[u]; if (U[u] == 0) M.st_u0 = u; }
+    const size_t nblk = ((size_t)M.nrows + 255) / 256;
+    int *dslot = nullptr;
+    unsigned *dmask = nullptr;
+    CHK(dev_alloc(&M.st_vals, nblk * nu * 256, acct));
+    {
+        unsigned char *mb = nullptr;             // 1 byte per row for |U| <= 8, 4 otherwise
+        CHK(dev_alloc(&mb, (size_t)M.nrows * (nu <= 8 ? 1 : 4) + 16, acct));
+        M.st_mask = mb;
+    }
+    CHK(dev_alloc(&dslot, slot.size(), nullptr));
+    CHK(dev_alloc(&dmask, npat, nullptr));
+    AMG_HIP(hipMemcpy(dslot, slot.data(), sizeof(int) * slot.size(), hipMemcpyHostToDevice));
+    AMG_HIP(hipMemcpy(dmask, pmask.data(), sizeof(unsigned) * pmask.size(), hipMemcpyHostToDevice));
+    int rc = launch_stencil_build(M, dslot, dmask, 0);
+    AMG_HIP(hipDeviceSynchronize());
+    hipFree(dslot);
+    hipFree(dmask);
+    return rc;
 }
 
 // Offset-pattern analysis of a square operator (host, O(nnz)): succeeds when the rows use at most
@@ -117,13 +166,15 @@ int try_patterns(DevCsr &M, const int *Ap, const int *Aj, long *acct)
     }
     M.npat = (int)dptr.size() - 1;
     M.ndict = (int)doff.size();
+    M.period_rows = 0;
+    for (int o : doff) M.period_rows = std::max(M.period_rows, std::abs(o));
     CHK(dev_alloc(&M.pat, n, acct));
     CHK(dev_alloc(&M.dict_ptr, M.npat + 1, acct));
     CHK(dev_alloc(&M.dict_off, M.ndict, acct));
     AMG_HIP(hipMemcpy(M.pat, pat.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
     AMG_HIP(hipMemcpy(M.dict_ptr, dptr.data(), sizeof(int) * dptr.size(), hipMemcpyHostToDevice));
     if (M.ndict) AMG_HIP(hipMemcpy(M.dict_off, doff.data(), sizeof(int) * doff.size(), hipMemcpyHostToDevice));
-    return 0;
+    return try_stencil(M, dptr, doff, acct);
 }
 
 int upload_bsr(DevBsr &M, int nbrows, int bs, const int *Ap, const int *Aj, const double *Ax,
@@ -300,6 +351,7 @@ int spmv(const DevCsr &M, StreamMode mode, const double *xg, const double *b, co
 {
     StreamArgs a = base_args(M);
     a.xg = xg; a.b = b; a.v2 = v2; a.out = out; a.out2 = out2; a.c0 = c0;
+    if (M.st_vals && stencil_enabled() && pattern_supports(mode)) return launch_stencil(mode, a, M, st);
     if (M.pat && pattern_supports(mode)) return launch_pattern(mode, a, M, st);
     return launch_stream(mode, a, st);
 }
@@ -310,6 +362,7 @@ static int spmv_scaled(const DevCsr &M, StreamMode mode, const double *xg, doubl
 {
     StreamArgs a = base_args(M);
     a.xg = xg; a.b = b; a.v2 = v2; a.out = out; a.c0 = c0; a.gscale = gscale;
+    if (M.st_vals && stencil_enabled() && pattern_supports(mode)) return launch_stencil(mode, a, M, st);
     if (M.pat && pattern_supports(mode)) return launch_pattern(mode, a, M, st);
     return launch_stream(mode, a, st);
 }
@@ -380,7 +433,7 @@ using namespace amg;
 // ------------------------------------------------------------------ relaxation on a level
 // x may be swapped with the level's alternate buffer (Jacobi writes out of place).
 static int relax(amg_hier *h, Level &L, Smoother &s, double *&x, double *&xalt, const double *b,
-                 bool x_zero)
+                 bool x_zero, bool r_ready = false)
 {
     hipStream_t st = h->stream;
     const int n = L.A.nrows;
@@ -437,6 +490,8 @@ static int relax(amg_hier *h, Level &L, Smoother &s, double *&x, double *&xalt, 
             const double *r;
             if (x_zero) {
                 r = b;
+            } else if (r_ready && it == 0) {
+                r = L.r;                       // b - A x of this very x, left there by residual_norm_to
             } else {
                 CHK(spmv(L.A, SM_RESIDUAL, x, b, nullptr, L.r, nullptr, 0.0, st));
                 r = L.r;
@@ -499,14 +554,15 @@ static int coarse_solve(amg_hier *h, const double *b, double *&x, double *&xalt)
 }
 
 // multilevel_solver.__solve (multilevel.py:473-548)
-static int cycle(amg_hier *h, int lvl, double *&x, double *&xalt, const double *b, int cyc, bool x_zero)
+static int cycle(amg_hier *h, int lvl, double *&x, double *&xalt, const double *b, int cyc, bool x_zero,
+                 bool r_ready = false)
 {
     Level &L = h->lv[lvl];
     Level &Lc = h->lv[lvl + 1];
     hipStream_t st = h->stream;
     const int nc = Lc.A.nrows;
 
-    CHK(relax(h, L, L.sm[AMG_PRE], x, xalt, b, x_zero));                                   // :494
+    CHK(relax(h, L, L.sm[AMG_PRE], x, xalt, b, x_zero, r_ready));                          // :494
     CHK(spmv(L.A, SM_RESIDUAL, x, b, nullptr, L.r, nullptr, 0.0, st));                     // :496
     CHK(spmv(L.Rm, SM_MATVEC, L.r, nullptr, nullptr, Lc.b, nullptr, 0.0, st));             // :498
     AMG_HIP(hipMemsetAsync(Lc.x, 0, sizeof(double) * (size_t)nc, st));                     // :499
@@ -568,23 +624,32 @@ static int cycle(amg_hier *h, int lvl, double *&x, double *&xalt, const double *
     return 0;
 }
 
-static int one_iteration(amg_hier *h, int cyc, bool x_zero)
+static int one_iteration(amg_hier *h, int cyc, bool x_zero, bool r_ready = false)
 {
     Level &L0 = h->lv[0];
     if (h->nlevels == 1) return coarse_solve(h, L0.b, L0.x, L0.xalt);                      // :455-457
-    return cycle(h, 0, L0.x, L0.xalt, L0.b, cyc, x_zero);                                  // :459
+    return cycle(h, 0, L0.x, L0.xalt, L0.b, cyc, x_zero, r_ready);                         // :459
 }
 
 static int residual_norm_to(amg_hier *h, double *slot)
 {
-    // util/linalg.py:109-112: ||b - A x||.  The residual is not stored: every workgroup of the
-    // operator application reduces its rows' squares, a second kernel adds the partials in order.
+    // util/linalg.py:109-112: ||b - A x||.  Every workgroup of the operator application reduces its
+    // rows' squares, a second kernel adds the partials in order.  The residual vector itself is
+    // stored only when the next cycle's pre-smoother starts by forming exactly this b - A x (the
+    // polynomial smoother, relaxation.py:655): it then reads it from L0.r instead of applying A
+    // a second time to the same x -- the same kernel on the same operands, hence the same bits.
     Level &L0 = h->lv[0];
     StreamArgs a = base_args(L0.A);
     a.xg = L0.x; a.b = L0.b; a.out2 = h->sumsq_partials;
-    const int nb = stream_blocks(a);
+    const bool keep = h->keep_residual && h->nlevels > 1 && L0.sm[AMG_PRE].kind == AMG_SM_POLYNOMIAL &&
+                      L0.sm[AMG_PRE].iterations >= 1;
+    a.out = keep ? L0.r : nullptr;
+    h->r_kept = keep;
+    const bool stencil = L0.A.st_vals && stencil_enabled();
+    const int nb = stencil ? stencil_blocks(a) : stream_blocks(a);
     if (nb > h->sumsq_cap) { set_error("sumsq partial buffer too small"); return AMG_ESTATE; }
-    if (L0.A.pat) CHK(launch_pattern(SM_RESIDUAL_SUMSQ, a, L0.A, h->stream));
+    if (stencil) CHK(launch_stencil(SM_RESIDUAL_SUMSQ, a, L0.A, h->stream));
+    else if (L0.A.pat) CHK(launch_pattern(SM_RESIDUAL_SUMSQ, a, L0.A, h->stream));
     else CHK(launch_stream(SM_RESIDUAL_SUMSQ, a, h->stream));
     return launch_sum_sqrt(h->sumsq_partials, nb, h->sumsq_partials + h->sumsq_cap, slot, h->stream);
 }
@@ -602,7 +667,9 @@ static std::vector<double *> buffer_state(amg_hier *h)
 
 static int iteration_with_norm(amg_hier *h, int cyc, bool x_zero, double *slot)
 {
-    CHK(one_iteration(h, cyc, x_zero));
+    const bool r_ready = h->r_kept;
+    h->r_kept = false;
+    CHK(one_iteration(h, cyc, x_zero, r_ready));
     return residual_norm_to(h, slot);
 }
 
@@ -614,11 +681,11 @@ static int graph_iteration(amg_hier *h, int cyc, bool x_zero, double *dst)
     std::vector<double *> state = buffer_state(h);
     GraphEntry *ge = nullptr;
     for (auto &g : h->graphs)
-        if (g.cyc == cyc && g.x_zero == x_zero && g.state_in == state) { ge = &g; break; }
+        if (g.cyc == cyc && g.x_zero == x_zero && g.kept_in == h->r_kept && g.state_in == state) { ge = &g; break; }
     if (!ge) {
         h->graphs.emplace_back();
         ge = &h->graphs.back();
-        ge->cyc = cyc; ge->x_zero = x_zero; ge->state_in = state;
+        ge->cyc = cyc; ge->x_zero = x_zero; ge->kept_in = h->r_kept; ge->state_in = state;
     }
     if (!ge->exec && ge->seen < 1) {           // first encounter: eager
         ge->seen++;
@@ -649,8 +716,10 @@ static int graph_iteration(amg_hier *h, int cyc, bool x_zero, double *dst)
         }
         ge->graph = graph; ge->exec = exec;
         ge->state_out = buffer_state(h);
+        ge->kept_out = h->r_kept;
     } else {
         for (size_t l = 0; l < h->lv.size(); ++l) { h->lv[l].x = ge->state_out[2 * l]; h->lv[l].xalt = ge->state_out[2 * l + 1]; }
+        h->r_kept = ge->kept_out;
     }
     AMG_HIP(hipGraphLaunch(ge->exec, st));
     AMG_HIP(hipMemcpyAsync(dst, slot, sizeof(double), hipMemcpyDeviceToDevice, st));
@@ -977,10 +1046,9 @@ int amg_hier_finalize(amg_hier *h)
     if (!h->norm_scratch) CHK(dev_alloc(&h->norm_scratch, 1024 + 8, &h->dev_bytes));
     {
         StreamArgs a0 = base_args(h->lv[0].A);
-        long need = stream_blocks(a0) + 8;
+        long need = std::max(stream_blocks(a0), stencil_blocks(a0)) + 8;
         if (need > h->sumsq_cap) {
             if (h->sumsq_partials) hipFree(h->sumsq_partials);
-    for (double *q : h->pcg) if (q) hipFree(q);
             h->sumsq_partials = nullptr;
             CHK(dev_alloc(&h->sumsq_partials, need + 512, &h->dev_bytes));   // + second-stage scratch
             h->sumsq_cap = need;
@@ -1227,12 +1295,22 @@ static double smoother_apps(const Smoother &s, bool x_zero)
     }
 }
 
-double amg_hier_cycle_bytes(amg_hier *h, int cyc)
+// Bytes of one operator application as THIS library stores the operator: the offset-pattern form
+// streams the values, one pattern id per row and the row pointer; the column indices are implied.
+static double bytes_spmv_moved(const DevCsr &M)
+{
+    if (M.st_vals && stencil_enabled())     // padded values + one mask word per row; no row pointer
+        return 8.0 * (double)M.st_nu * 256.0 * (double)((M.nrows + 255) / 256) + (M.st_nu <= 8 ? 1.0 : 4.0) * M.nrows +
+               8.0 * M.ncols + 8.0 * M.nrows;
+    if (!M.pat) return bytes_spmv(M);
+    return 8.0 * (double)M.nnz + 4.0 * M.nrows + 4.0 * (M.nrows + 1.0) + 8.0 * M.ncols + 8.0 * M.nrows;
+}
+
+static double cycle_bytes_impl(amg_hier *h, int cyc, bool moved)
 {
     if (!h) return 0.0;
     // visits per level for V/W/F
     std::vector<double> visits((size_t)h->nlevels, 0.0);
-    std::vector<double> first((size_t)h->nlevels, 0.0);
     visits[0] = 1.0;
     for (int l = 1; l < h->nlevels; ++l) {
         if (cyc == AMG_CYCLE_W) visits[l] = 2.0 * visits[l - 1];
@@ -1243,17 +1321,40 @@ double amg_hier_cycle_bytes(amg_hier *h, int cyc)
     for (int l = 0; l < h->nlevels - 1; ++l) {
         Level &L = h->lv[l];
         double n = L.A.nrows;
-        double app = bytes_spmv(L.A) + 8.0 * n;
+        double app = (moved ? bytes_spmv_moved(L.A) : bytes_spmv(L.A)) + 8.0 * n;
         // every visit: pre + residual + post; coarse levels enter with x == 0 on first of
         // each pair of visits -- counted as zero-start for all coarse presmooths of a V cycle
         double k = smoother_apps(L.sm[0], l > 0) + 1.0 + smoother_apps(L.sm[1], false);
-        if (l == 0) k += 1.0;   // outer residual norm (multilevel.py:461)
-        total += visits[l] * (k * app + bytes_spmv(L.Rm) + bytes_spmv(L.P) + 8.0 * n);
+        double extra = 0.0;
+        if (l == 0) {
+            k += 1.0;   // outer residual norm (multilevel.py:461)
+            if (moved && h->keep_residual && L.sm[0].kind == AMG_SM_POLYNOMIAL && L.sm[0].iterations >= 1) {
+                k -= 1.0;            // the pre-smoother starts from the kept residual ...
+                extra = 8.0 * n;     // ... which the norm pass wrote
+            }
+        }
+        total += visits[l] * (k * app + extra + bytes_spmv(L.Rm) + bytes_spmv(L.P) + 8.0 * n);
     }
     double ncs = h->lv[h->nlevels - 1].A.nrows;
     total += visits[h->nlevels - 1] * (8.0 * ncs * ncs + 16.0 * ncs);
     return total;
 }
+
+int amg_hier_operator_form(amg_hier *h, int lvl)
+{
+    if (!h || lvl < 0 || lvl >= h->nlevels) return -1;
+    const DevCsr &M = h->lv[lvl].A;
+    if (M.st_vals && stencil_enabled()) return 2;
+    return M.pat ? 1 : 0;
+}
+double amg_hier_operator_bytes(amg_hier *h, int lvl, int moved)
+{
+    if (!h || lvl < 0 || lvl >= h->nlevels) return 0.0;
+    const DevCsr &M = h->lv[lvl].A;
+    return (moved ? bytes_spmv_moved(M) : bytes_spmv(M)) + 8.0 * M.nrows;     // + the right-hand side of r = b - A x
+}
+double amg_hier_cycle_bytes(amg_hier *h, int cyc) { return cycle_bytes_impl(h, cyc, false); }
+double amg_hier_cycle_bytes_moved(amg_hier *h, int cyc) { return cycle_bytes_impl(h, cyc, true); }
 
 double amg_hier_last_solve_ms(amg_hier *h) { return h ? h->last_ms : 0.0; }
 long amg_hier_device_bytes(amg_hier *h) { return h ? h->dev_bytes : 0; }
@@ -1276,8 +1377,9 @@ int amg_hier_time_spmv(amg_hier *h, int lvl, int which, int mode, int reps, doub
     else { in = L.r; out = h->lv[lvl + 1].b; }
     StreamMode sm = ((mode & 1) && which == AMG_MAT_A) ? SM_RESIDUAL : SM_MATVEC;
     DevCsr Mplain = M;                     // mode bit 1 (value 2): time the plain CSR kernel even if
-    if (mode & 2) Mplain.pat = nullptr;    // the operator also has the offset-pattern form
-    const DevCsr &Mu = (mode & 2) ? Mplain : M;
+    if (mode & 2) { Mplain.pat = nullptr; Mplain.st_vals = nullptr; }   // the operator has derived forms;
+    if (mode & 4) Mplain.st_vals = nullptr;                             // bit 2 (value 4): the pattern kernel
+    const DevCsr &Mu = (mode & 6) ? Mplain : M;
     CHK(spmv(Mu, sm, in, L.b, nullptr, out, nullptr, 0.0, h->stream));   // warm-up
     AMG_HIP(hipEventRecord(h->ev0, h->stream));
     for (int r = 0; r < reps; ++r) CHK(spmv(Mu, sm, in, L.b, nullptr, out, nullptr, 0.0, h->stream));
@@ -1411,7 +1513,10 @@ int amg_hier_time_relax(amg_hier *h, int lvl, int which, int reps, double *ms)
 
 void amg_set_stream_variant(int v) { amg::set_stream_variant(v); }
 void amg_set_xcd_chunk(int c) { amg::set_xcd_chunk(c); }
+void amg_set_xcd_period(int on) { amg::set_xcd_period(on); }
+void amg_set_stencil_form(int on) { amg::set_stencil_form(on); }
 void amg_set_tile_target(int t) { amg::set_tile_target(t); }
 void amg_hier_use_graphs(amg_hier *h, int on) { if (h) { h->use_graphs = on; if (!on) drop_graphs(h); } }
+void amg_hier_keep_residual(amg_hier *h, int on) { if (h) { h->keep_residual = on; h->r_kept = false; drop_graphs(h); } }
 
 }  // extern "C"

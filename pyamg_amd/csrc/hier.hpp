@@ -70,6 +70,7 @@ struct GraphEntry {
     std::vector<double *> state_in, state_out;   // (x, xalt) of every level before / after
     int cyc = 0;
     bool x_zero = false;
+    bool kept_in = false, kept_out = false;     // amg_hier::r_kept before / after
     int seen = 0;                                // times this state was run eagerly
     hipGraphExec_t exec = nullptr;
     hipGraph_t graph = nullptr;
@@ -103,6 +104,8 @@ struct amg_hier {
     // hipGraph replay of the iteration (launch-bound hierarchies: small levels, level-scheduled GS)
     std::vector<amg::GraphEntry> graphs;
     int use_graphs = 1;
+    int keep_residual = 1;                       // hand the outer residual to the next pre-smoother
+    bool r_kept = false;                         // lv[0].r == lv[0].b - A*lv[0].x right now (solve loop only)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double last_ms = 0.0;
     long dev_bytes = 0;

@@ -65,6 +65,8 @@ int rows_per_wg_for(long nnz, long rows)
 void set_stream_variant(int v) { g_stream_variant = v; }
 int stream_variant() { return g_stream_variant; }
 void set_xcd_chunk(int c) { g_xcd_chunk = c; }
+static int g_xcd_period = 1;
+void set_xcd_period(int on) { g_xcd_period = on; }
 
 // Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2).
 // With chunk > 0, each group of 8*chunk consecutive logical blocks is laid out
@@ -262,7 +264,11 @@ __global__ __launch_bounds__(WG) void csr_stream_kernel(StreamArgs a, int xcd_ch
     if (MODE == SM_RESIDUAL_SUMSQ) {
         // per-workgroup partial of ||b - A x||^2 (fixed order: lanes by shuffle tree, waves in order)
         double sq = 0.0;
-        if (t < nr) { double rr = a.b[r0 + t] - acc; sq = rr * rr; }
+        if (t < nr) {
+            double rr = a.b[r0 + t] - acc;
+            sq = rr * rr;
+            if (a.out) store_out(&a.out[r0 + t], rr);     // kept for the next pre-smoother (hier.hip)
+        }
         __syncthreads();
         double tot = block_reduce_sum(sq, sp);
         if (t == 0) a.out2[blk] = tot;
@@ -329,6 +335,12 @@ struct PatternArgs {
     const int *dict_ptr;
     const int *dict_off;
     int npat, ndict;
+    // plane-periodic block -> XCD mapping (0 = off): the operator's slowest axis has a stride of
+    // about period_blocks row blocks; each period is cut into 8 segments of seg_blocks and XCD k
+    // (= blockIdx % 8, the hardware's round-robin dispatch) sweeps segment k of every period in
+    // turn.  A row's neighbours one plane up and down are then gathered by the SAME XCD, a few
+    // hundred blocks earlier or later, i.e. out of its own L2 instead of over the fabric again.
+    int period_blocks, seg_blocks, nblocks;
 };
 
 template <int MODE>
@@ -341,7 +353,16 @@ __global__ __launch_bounds__(WG) void csr_pattern_kernel(StreamArgs a, PatternAr
     __shared__ int sDict[PAT_DICT_MAX];
 
     const int t = threadIdx.x;
-    const int blk = remap_block(blockIdx.x, gridDim.x, xcd_chunk);
+    int blk;
+    if (P.period_blocks > 0) {
+        const int k = blockIdx.x & 7, s = blockIdx.x >> 3;
+        const int p = s / P.seg_blocks, j = s - p * P.seg_blocks;
+        const int q = k * P.seg_blocks + j;
+        blk = p * P.period_blocks + q;
+        if (q >= P.period_blocks || blk >= P.nblocks) return;       // padding of the last segment / period
+    } else {
+        blk = remap_block(blockIdx.x, gridDim.x, xcd_chunk);
+    }
     const int r0 = a.row_lo + blk * rpb;
     const int nr = min(rpb, a.row_hi - r0);
     const double gscale = a.gscale;
@@ -359,7 +380,27 @@ __global__ __launch_bounds__(WG) void csr_pattern_kernel(StreamArgs a, PatternAr
     const int *offs = sDict;
     if (t < nr) offs = &sDict[sDptr[P.pat[i]]];
     double acc = 0.0, diag = 0.0;
-    if (MT::sub && t < nr) acc = a.b[i];
+    // The operands of a row's first 8 entries do not depend on the matrix values: gather them (and
+    // the right-hand side) NOW, so that their latency overlaps the value stream instead of
+    // following it -- one dependent memory round trip less per workgroup.
+    const int my_len = my_e - my_s;
+    double xv0[8];
+    int off0[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        off0[u] = (u < my_len) ? offs[u] : 0;
+        xv0[u] = (u < my_len) ? a.xg[i + off0[u]] : 0.0;
+    }
+    double bval = 0.0;
+    if (t < nr && (MT::sub || MODE == SM_RESIDUAL || MODE == SM_RESIDUAL_SUMSQ || MODE == SM_POLY_STEP ||
+                   MODE == SM_POLY_LAST || MODE == SM_JACOBI))
+        bval = a.b[i];
+    if (MT::sub && t < nr) acc = bval;
+    double pre2 = 0.0;                                  // second epilogue operand, same reasoning
+    if (t < nr) {
+        if (MODE == SM_MATVEC_ACC) pre2 = a.out[i];
+        else if (MODE == SM_POLY_LAST || MODE == SM_JACOBI || MODE == SM_JACOBI_BSR1) pre2 = a.v2[i];
+    }
 
     const int abeg = kbeg & ~3;
     for (int tile_lo = abeg; tile_lo < kend; tile_lo += TILE) {
@@ -388,15 +429,18 @@ __global__ __launch_bounds__(WG) void csr_pattern_kernel(StreamArgs a, PatternAr
         __syncthreads();
         {
             const int s = max(my_s, tile_lo), e2 = min(my_e, tile_hi);
-            // batches of 8 entries: all gathers of a batch are in flight together
             for (int k0 = s; k0 < e2; k0 += 8) {
                 double xv[8];
                 int off[8];
+                const bool first = (k0 == my_s);       // the pre-gathered batch
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int k = k0 + u;
-                    off[u] = (k < e2) ? offs[k - my_s] : 0;
-                    xv[u] = (k < e2) ? a.xg[i + off[u]] : 0.0;
+                    if (first) { off[u] = off0[u]; xv[u] = xv0[u]; }
+                    else {
+                        off[u] = (k < e2) ? offs[k - my_s] : 0;
+                        xv[u] = (k < e2) ? a.xg[i + off[u]] : 0.0;
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
@@ -415,7 +459,11 @@ __global__ __launch_bounds__(WG) void csr_pattern_kernel(StreamArgs a, PatternAr
 
     if (MODE == SM_RESIDUAL_SUMSQ) {
         double sq = 0.0;
-        if (t < nr) { double rr = a.b[i] - acc; sq = rr * rr; }
+        if (t < nr) {
+            double rr = bval - acc;
+            sq = rr * rr;
+            if (a.out) store_out(&a.out[i], rr);
+        }
         __syncthreads();
         double tot = block_reduce_sum(sq, sp);
         if (t == 0) a.out2[blk] = tot;
@@ -425,20 +473,20 @@ __global__ __launch_bounds__(WG) void csr_pattern_kernel(StreamArgs a, PatternAr
     if (MODE == SM_MATVEC) {
         store_out(&a.out[i], acc);
     } else if (MODE == SM_MATVEC_ACC) {
-        store_out(&a.out[i], a.out[i] + acc);
+        store_out(&a.out[i], pre2 + acc);
     } else if (MODE == SM_RESIDUAL) {
-        store_out(&a.out[i], a.b[i] - acc);
+        store_out(&a.out[i], bval - acc);
     } else if (MODE == SM_POLY_STEP) {
-        double cr = a.c0 * a.b[i];
+        double cr = a.c0 * bval;
         a.out[i] = cr + acc;
     } else if (MODE == SM_POLY_LAST) {
-        double cr = a.c0 * a.b[i];
+        double cr = a.c0 * bval;
         double h = cr + acc;
-        store_out(&a.out[i], a.v2[i] + h);
+        store_out(&a.out[i], pre2 + h);
     } else if (MODE == SM_JACOBI) {
-        double told = a.v2[i];
+        double told = pre2;
         if (diag != 0.0) {
-            double q = (a.b[i] - acc) / diag;
+            double q = (bval - acc) / diag;
             double t1 = (1.0 - a.c0) * told;
             double t2 = a.c0 * q;
             a.out[i] = t1 + t2;
@@ -446,7 +494,7 @@ __global__ __launch_bounds__(WG) void csr_pattern_kernel(StreamArgs a, PatternAr
             a.out[i] = told;
         }
     } else if (MODE == SM_JACOBI_BSR1) {
-        double told = a.v2[i];
+        double told = pre2;
         if (diag != 0.0) {
             double t1 = (1.0 - a.c0) * told;
             double t2 = (a.c0 * acc) / diag;
@@ -467,7 +515,7 @@ bool pattern_supports(StreamMode mode)
 }
 
 template <int MODE>
-static int launch_pattern_mode(const StreamArgs &a, const PatternArgs &P, hipStream_t st)
+static int launch_pattern_mode(const StreamArgs &a, const PatternArgs &P, int period_rows, hipStream_t st)
 {
     int rows = a.row_hi - a.row_lo;
     if (rows <= 0) return 0;
@@ -476,7 +524,21 @@ static int launch_pattern_mode(const StreamArgs &a, const PatternArgs &P, hipStr
     int nb = (rows + rpb - 1) / rpb;
     StreamArgs b = a;
     if (b.gscale == 0.0) b.gscale = 1.0;
-    hipLaunchKernelGGL((csr_pattern_kernel<MODE>), dim3(nb), dim3(WG), 0, st, b, P, g_xcd_chunk, rpb);
+    PatternArgs Q = P;
+    Q.nblocks = nb;
+    Q.period_blocks = Q.seg_blocks = 0;
+    int grid = nb;
+    if (g_xcd_period && period_rows > 0) {
+        const int S = (period_rows + rpb / 2) / rpb;            // blocks per plane (rounded; drift is harmless)
+        const int G = (S + 7) / 8;
+        // worth it when a plane spans many blocks and three segments of x fit an XCD's 4 MB L2
+        if (S >= 64 && nb >= 4 * S && 3.0 * G * rpb * 8.0 <= 2.0e6) {
+            Q.period_blocks = S;
+            Q.seg_blocks = G;
+            grid = 8 * G * ((nb + S - 1) / S);
+        }
+    }
+    hipLaunchKernelGGL((csr_pattern_kernel<MODE>), dim3(grid), dim3(WG), 0, st, b, Q, g_xcd_chunk, rpb);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "csr_pattern launch", __FILE__, __LINE__);
     return 0;
@@ -484,19 +546,222 @@ static int launch_pattern_mode(const StreamArgs &a, const PatternArgs &P, hipStr
 
 int launch_pattern(StreamMode mode, const StreamArgs &a, const DevCsr &M, hipStream_t st)
 {
-    PatternArgs P{M.pat, M.dict_ptr, M.dict_off, M.npat, M.ndict};
+    PatternArgs P{M.pat, M.dict_ptr, M.dict_off, M.npat, M.ndict, 0, 0, 0};
+    const int period_rows = M.period_rows;
     switch (mode) {
-    case SM_MATVEC: return launch_pattern_mode<SM_MATVEC>(a, P, st);
-    case SM_MATVEC_ACC: return launch_pattern_mode<SM_MATVEC_ACC>(a, P, st);
-    case SM_RESIDUAL: return launch_pattern_mode<SM_RESIDUAL>(a, P, st);
-    case SM_POLY_STEP: return launch_pattern_mode<SM_POLY_STEP>(a, P, st);
-    case SM_POLY_LAST: return launch_pattern_mode<SM_POLY_LAST>(a, P, st);
-    case SM_JACOBI: return launch_pattern_mode<SM_JACOBI>(a, P, st);
-    case SM_JACOBI_BSR1: return launch_pattern_mode<SM_JACOBI_BSR1>(a, P, st);
-    case SM_RESIDUAL_SUMSQ: return launch_pattern_mode<SM_RESIDUAL_SUMSQ>(a, P, st);
+    case SM_MATVEC: return launch_pattern_mode<SM_MATVEC>(a, P, period_rows, st);
+    case SM_MATVEC_ACC: return launch_pattern_mode<SM_MATVEC_ACC>(a, P, period_rows, st);
+    case SM_RESIDUAL: return launch_pattern_mode<SM_RESIDUAL>(a, P, period_rows, st);
+    case SM_POLY_STEP: return launch_pattern_mode<SM_POLY_STEP>(a, P, period_rows, st);
+    case SM_POLY_LAST: return launch_pattern_mode<SM_POLY_LAST>(a, P, period_rows, st);
+    case SM_JACOBI: return launch_pattern_mode<SM_JACOBI>(a, P, period_rows, st);
+    case SM_JACOBI_BSR1: return launch_pattern_mode<SM_JACOBI_BSR1>(a, P, period_rows, st);
+    case SM_RESIDUAL_SUMSQ: return launch_pattern_mode<SM_RESIDUAL_SUMSQ>(a, P, period_rows, st);
     default: break;
     }
     set_error("launch_pattern: mode not supported");
+    return -1;
+}
+
+// ---------------------------------------------------------------------------
+// Stencil form (DevCsr::st_*): one thread per row, every operand requested before anything is
+// consumed -- NU coalesced value loads (slot-major inside a 256-row block), NU speculative gathers
+// x[i + U[u]] (bounds-checked, masked later), the row mask and the epilogue operands.  One memory
+// round trip per workgroup, no LDS, no barrier (except the SM_RESIDUAL_SUMSQ reduction).  The row
+// sum runs over the slots whose mask bit is set, in increasing slot order = increasing column =
+// the CSR's stored order, so the result is bit-identical to csr_stream_kernel's.
+// ---------------------------------------------------------------------------
+struct StencilArgs {
+    const double *vals;
+    const void *mask;                    // uint8 per row in the NUB == 8 instantiation, else uint32
+    int nu, u0;
+    int blk_lo, nblocks;                 // blocks [blk_lo, blk_lo + nblocks) cover the row range
+    int period_blocks, seg_blocks;       // plane-periodic block -> XCD mapping, see PatternArgs
+    int ncols;
+    int off[STENCIL_MAX];
+};
+
+template <int MODE, int NUB>
+__global__ __launch_bounds__(WG) void stencil_kernel(StreamArgs a, StencilArgs E, int xcd_chunk)
+{
+    using MT = ModeTraits<MODE>;
+    __shared__ double red[8];
+    const int t = threadIdx.x;
+    int blk;
+    if (E.period_blocks > 0) {
+        const int k = blockIdx.x & 7, s = blockIdx.x >> 3;
+        const int p = s / E.seg_blocks, j = s - p * E.seg_blocks;
+        const int q = k * E.seg_blocks + j;
+        blk = p * E.period_blocks + q;
+        if (q >= E.period_blocks || blk >= E.nblocks) return;
+    } else {
+        blk = remap_block(blockIdx.x, gridDim.x, xcd_chunk);
+    }
+    blk += E.blk_lo;
+    const int i = blk * WG + t;
+    const bool live = (i >= a.row_lo && i < a.row_hi);
+    const double *vp = E.vals + ((size_t)blk * E.nu) * WG + t;
+
+    double v[NUB], xv[NUB];
+#pragma unroll
+    for (int u = 0; u < NUB; ++u) {
+        v[u] = 0.0; xv[u] = 0.0;
+        if (u < E.nu && live) {
+            v[u] = vp[(size_t)u * WG];
+            const long j = (long)i + E.off[u];
+            if (j >= 0 && j < E.ncols) xv[u] = a.xg[j];
+        }
+    }
+    unsigned m = 0;
+    double bval = 0.0, pre2 = 0.0;
+    if (live) {
+        m = (NUB == 8) ? (unsigned)static_cast<const unsigned char *>(E.mask)[i] : static_cast<const unsigned *>(E.mask)[i];
+        if (MT::sub || MODE == SM_RESIDUAL || MODE == SM_RESIDUAL_SUMSQ || MODE == SM_POLY_STEP ||
+            MODE == SM_POLY_LAST || MODE == SM_JACOBI)
+            bval = a.b[i];
+        if (MODE == SM_MATVEC_ACC) pre2 = a.out[i];
+        else if (MODE == SM_POLY_LAST || MODE == SM_JACOBI || MODE == SM_JACOBI_BSR1) pre2 = a.v2[i];
+    }
+    const double gscale = a.gscale;
+    double acc = MT::sub ? bval : 0.0, diag = 0.0;
+#pragma unroll
+    for (int u = 0; u < NUB; ++u) {
+        if (u < E.nu && ((m >> u) & 1u)) {
+            if (MT::jac && u == E.u0) { diag = v[u]; continue; }
+            const double pr = v[u] * (gscale * xv[u]);
+            acc = MT::sub ? (acc - pr) : (acc + pr);
+        }
+    }
+
+    if (MODE == SM_RESIDUAL_SUMSQ) {
+        double sq = 0.0;
+        if (live) {
+            double rr = bval - acc;
+            sq = rr * rr;
+            if (a.out) store_out(&a.out[i], rr);
+        }
+        double tot = block_reduce_sum(sq, red);
+        if (t == 0) a.out2[blk - E.blk_lo] = tot;
+        return;
+    }
+    if (!live) return;
+    if (MODE == SM_MATVEC) {
+        store_out(&a.out[i], acc);
+    } else if (MODE == SM_MATVEC_ACC) {
+        store_out(&a.out[i], pre2 + acc);
+    } else if (MODE == SM_RESIDUAL) {
+        store_out(&a.out[i], bval - acc);
+    } else if (MODE == SM_POLY_STEP) {
+        double cr = a.c0 * bval;
+        a.out[i] = cr + acc;
+    } else if (MODE == SM_POLY_LAST) {
+        double cr = a.c0 * bval;
+        double h = cr + acc;
+        store_out(&a.out[i], pre2 + h);
+    } else if (MODE == SM_JACOBI) {
+        double told = pre2;
+        if (diag != 0.0) {
+            double q = (bval - acc) / diag;
+            double t1 = (1.0 - a.c0) * told;
+            double t2 = a.c0 * q;
+            a.out[i] = t1 + t2;
+        } else {
+            a.out[i] = told;
+        }
+    } else if (MODE == SM_JACOBI_BSR1) {
+        double told = pre2;
+        if (diag != 0.0) {
+            double t1 = (1.0 - a.c0) * told;
+            double t2 = (a.c0 * acc) / diag;
+            a.out[i] = t1 + t2;
+        } else {
+            a.out[i] = told;
+        }
+    }
+}
+
+// values of the CSR -> stencil layout; one thread per row
+__global__ void stencil_build_kernel(int n, const int *Ap, const double *Ax, const int *pat, const int *dict_ptr,
+                                     const int *dict_slot, const unsigned *pat_mask, int nu, double *vals,
+                                     void *mask)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int p = pat[i];
+    if (nu <= 8) static_cast<unsigned char *>(mask)[i] = (unsigned char)pat_mask[p];
+    else static_cast<unsigned *>(mask)[i] = pat_mask[p];
+    const int s = Ap[i], e = Ap[i + 1], d = dict_ptr[p];
+    double *vp = vals + ((size_t)(i / WG) * nu) * WG + (i % WG);
+    for (int k = s; k < e; ++k) vp[(size_t)dict_slot[d + (k - s)] * WG] = Ax[k];
+}
+
+int launch_stencil_build(const DevCsr &M, const int *dict_slot, const unsigned *pat_mask, hipStream_t st)
+{
+    const int n = M.nrows;
+    hipLaunchKernelGGL(stencil_build_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, M.Ap, M.Ax, M.pat,
+                       M.dict_ptr, dict_slot, pat_mask, M.st_nu, M.st_vals, M.st_mask);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "stencil build launch", __FILE__, __LINE__);
+    return 0;
+}
+
+static int g_stencil_form = 1;
+void set_stencil_form(int on) { g_stencil_form = on; }
+bool stencil_enabled() { return g_stencil_form != 0; }
+
+int stencil_blocks(const StreamArgs &a)
+{
+    if (a.row_hi <= a.row_lo) return 0;
+    return (a.row_hi - 1) / WG - a.row_lo / WG + 1;
+}
+
+template <int MODE>
+static int launch_stencil_mode(const StreamArgs &a, const DevCsr &M, hipStream_t st)
+{
+    const int nb = stencil_blocks(a);
+    if (nb <= 0) return 0;
+    StreamArgs b = a;
+    if (b.gscale == 0.0) b.gscale = 1.0;
+    StencilArgs E;
+    E.vals = M.st_vals; E.mask = M.st_mask; E.nu = M.st_nu; E.u0 = M.st_u0;
+    E.blk_lo = a.row_lo / WG; E.nblocks = nb; E.ncols = M.ncols;
+    E.period_blocks = E.seg_blocks = 0;
+    for (int u = 0; u < STENCIL_MAX; ++u) E.off[u] = M.st_off[u];
+    int grid = nb;
+    if (g_xcd_period && M.period_rows > 0) {
+        const int S = (M.period_rows + WG / 2) / WG;
+        const int G = (S + 7) / 8;
+        if (S >= 64 && nb >= 4 * S && 3.0 * G * WG * 8.0 <= 2.0e6) {
+            E.period_blocks = S;
+            E.seg_blocks = G;
+            grid = 8 * G * ((nb + S - 1) / S);
+        }
+    }
+    if (M.st_nu <= 8)
+        hipLaunchKernelGGL((stencil_kernel<MODE, 8>), dim3(grid), dim3(WG), 0, st, b, E, g_xcd_chunk);
+    else if (M.st_nu <= 16)
+        hipLaunchKernelGGL((stencil_kernel<MODE, 16>), dim3(grid), dim3(WG), 0, st, b, E, g_xcd_chunk);
+    else
+        hipLaunchKernelGGL((stencil_kernel<MODE, 32>), dim3(grid), dim3(WG), 0, st, b, E, g_xcd_chunk);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "stencil launch", __FILE__, __LINE__);
+    return 0;
+}
+
+int launch_stencil(StreamMode mode, const StreamArgs &a, const DevCsr &M, hipStream_t st)
+{
+    switch (mode) {
+    case SM_MATVEC: return launch_stencil_mode<SM_MATVEC>(a, M, st);
+    case SM_MATVEC_ACC: return launch_stencil_mode<SM_MATVEC_ACC>(a, M, st);
+    case SM_RESIDUAL: return launch_stencil_mode<SM_RESIDUAL>(a, M, st);
+    case SM_POLY_STEP: return launch_stencil_mode<SM_POLY_STEP>(a, M, st);
+    case SM_POLY_LAST: return launch_stencil_mode<SM_POLY_LAST>(a, M, st);
+    case SM_JACOBI: return launch_stencil_mode<SM_JACOBI>(a, M, st);
+    case SM_JACOBI_BSR1: return launch_stencil_mode<SM_JACOBI_BSR1>(a, M, st);
+    case SM_RESIDUAL_SUMSQ: return launch_stencil_mode<SM_RESIDUAL_SUMSQ>(a, M, st);
+    default: break;
+    }
+    set_error("launch_stencil: mode not supported");
     return -1;
 }
 

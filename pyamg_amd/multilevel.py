@@ -174,6 +174,9 @@ class _DeviceHierarchy(object):
     def cycle_bytes(self, cycle="V"):
         return self.L.amg_hier_cycle_bytes(self.h, _CYCLE[cycle])
 
+    def cycle_bytes_moved(self, cycle="V"):
+        return self.L.amg_hier_cycle_bytes_moved(self.h, _CYCLE[cycle])
+
     def last_solve_ms(self):
         return self.L.amg_hier_last_solve_ms(self.h)
 

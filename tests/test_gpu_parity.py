@@ -362,6 +362,77 @@ def test_full_cycle_at_scale_vs_oracle(smoother):
     assert np.linalg.norm(y - xs) <= 1e-10 * np.linalg.norm(xs)
 
 
+@pytest.mark.parametrize("degree", [1, 2, 3])
+def test_kept_residual_equals_two_pass_form(degree):
+    """amg_hier_solve hands the residual of the convergence test to the next polynomial
+    pre-smoother (amg_hier_keep_residual): histories and iterates must be bit-identical to the form
+    that applies A twice, with and without graph replay, from zero and nonzero initial guesses."""
+    from pyamg_amd.aggregation import poisson as native, smoothed_aggregation_solver
+    from pyamg_amd import _lib
+    A = native((40, 41, 42))
+    np.random.seed(0)
+    sm = ("chebyshev", {"degree": degree, "iterations": 2 if degree == 1 else 1})
+    ml = smoothed_aggregation_solver(A, presmoother=sm, postsmoother=sm)
+    rng = np.random.RandomState(3)
+    b = rng.rand(A.shape[0])
+    x0 = rng.rand(A.shape[0])
+    dev = ml.device_hierarchy()
+    out = {}
+    for keep in (1, 0):
+        for graphs in (1, 0):
+            _lib.lib().amg_hier_keep_residual(dev.h, keep)
+            _lib.lib().amg_hier_use_graphs(dev.h, graphs)
+            for guess in (None, x0):
+                for cyc in ("V", "W"):
+                    res = []
+                    x = ml.solve(b, x0=guess, tol=0.0, maxiter=6, cycle=cyc, residuals=res)
+                    out[(keep, graphs, guess is None, cyc)] = (x, np.array(res))
+    _lib.lib().amg_hier_keep_residual(dev.h, 1)
+    _lib.lib().amg_hier_use_graphs(dev.h, 1)
+    for (keep, graphs, zero, cyc), (x, res) in out.items():
+        xr, rr = out[(0, 0, zero, cyc)]
+        assert np.array_equal(x, xr), (keep, graphs, zero, cyc)
+        assert np.array_equal(res, rr), (keep, graphs, zero, cyc)
+
+
+def test_plane_periodic_xcd_mapping_is_only_a_schedule():
+    """Offset-pattern operators whose slowest axis spans >= 64 row blocks are launched with the
+    plane-periodic block->XCD mapping (padded grid, early-exit blocks).  Same rows, same bits:
+    compare with the chunked mapping and with the oracle on a grid where the mapping applies
+    (plane = 130*130 rows = 66 blocks) and whose last period / last segment are ragged."""
+    from pyamg_amd.aggregation import poisson as native, smoothed_aggregation_solver
+    from pyamg_amd import _lib
+    A = native((9, 130, 130))
+    np.random.seed(0)
+    sm = ("chebyshev", {"degree": 3})
+    ml = smoothed_aggregation_solver(A, presmoother=sm, postsmoother=sm)
+    rng = np.random.RandomState(5)
+    b = rng.rand(A.shape[0])
+    got = {}
+    for stencil in (1, 0):                      # stencil form / offset-pattern form of level 0
+        _lib.lib().amg_set_stencil_form(stencil)
+        for period in (1, 0):
+            _lib.lib().amg_set_xcd_period(period)
+            res = []
+            x = ml.solve(b, tol=0.0, maxiter=4, residuals=res)
+            got[(stencil, period)] = (x, np.array(res))
+    _lib.lib().amg_set_xcd_period(1)
+    _lib.lib().amg_set_stencil_form(1)
+    for key, (x, res) in got.items():
+        assert np.array_equal(x, got[(0, 0)][0]) and np.array_equal(res, got[(0, 0)][1]), key
+    got = {1: got[(1, 1)]}
+    levels = []
+    for lvl in ml.levels:
+        L = {"A": lvl.A}
+        if hasattr(lvl, "P"):
+            L.update(P=lvl.P, R=lvl.R, pre=dict(lvl.presmoother.desc), post=dict(lvl.postsmoother.desc))
+        levels.append(L)
+    kind, M = ml.coarse_solver.device_form(ml.levels[-1].A)
+    xo, reso = oracle_lib.Hierarchy(levels, M).solve(b, tol=0.0, maxiter=4)
+    assert np.array_equal(got[1][0], xo)
+    assert np.allclose(got[1][1], reso, rtol=1e-12)
+
+
 def test_device_pcg_matches_reference_cg_semantics():
     """solve(accel='cg') on the device vs a host restatement of pyamg/krylov/_cg.py:84-179 whose
     preconditioner is the oracle's cycle from zero; dots are BLAS / tree / numpy sums, so the bar is
