@@ -231,6 +231,8 @@ typedef struct amg_mat amg_mat;
 amg_mat *amg_mat_create(int device, int nrows, int ncols, const int *Ap, const int *Aj, const double *Ax);
 void amg_mat_destroy(amg_mat *m);
 long amg_mat_nnz(amg_mat *m);
+/* storage form the operator is applied from: 0 CSR, 1 offset-pattern, 2 stencil */
+int amg_mat_form(amg_mat *m);
 /* one csr_stream launch.  mode: 0 out=Mx  1 out+=Mx  2 out=b-Mx  3 out=b-Mx,out2=c0*out
  * 4 out=c0*b+Mx  5 out=v2+(c0*b+Mx)  6 Jacobi (CSR rounding)  7 Jacobi (BSR(1,1) rounding);
  * xg is the gathered vector (owned entries followed by the halo) */

@@ -138,6 +138,8 @@ def lib():
     L.amg_mat_destroy.restype = None
     L.amg_mat_gs_levels.argtypes = [V]
     L.amg_mat_gs_levels.restype = I
+    L.amg_mat_form.argtypes = [V]
+    L.amg_mat_form.restype = I
     L.amg_mat_nnz.argtypes = [V]
     L.amg_mat_nnz.restype = C.c_long
     L.amg_arnoldi_free.argtypes = [V]

@@ -44,12 +44,18 @@ struct DevCsr {
     // so every load of the kernel is issued up front, coalesced, with no row pointer, no column
     // index and no LDS staging; x[i+U[u]] is gathered speculatively and masked.
     double *st_vals = nullptr;     // [nblocks256 * st_nu * 256]
-    void *st_mask = nullptr;       // [nrows] uint8 when |U| <= 8, else uint32
+    void *st_mask = nullptr;       // [nrows] uint8 when |U| <= 7, else uint32; top bit = row not covered
     int st_nu = 0;                 // |U|
+    // Rows that use a rare offset (halo columns of a rank-local operator, a few irregular rows) are
+    // left out of the stencil form instead of widening U for everybody: up to STENCIL_RANGES
+    // contiguous row ranges that the offset-pattern kernel applies after the stencil launch.
+    int st_nranges = 0;
+    int st_range[8][2] = {{0}};
     int st_u0 = -1;                // slot of offset 0 (the diagonal), -1 if absent
     int st_off[32] = {0};          // U, increasing
 };
-constexpr int STENCIL_MAX = 32;
+constexpr int STENCIL_MAX = 31;
+constexpr int STENCIL_RANGES = 8;
 
 constexpr int PAT_MAX = 255;       // distinct row patterns kept in LDS
 constexpr int PAT_DICT_MAX = 2048; // total offsets in the dictionary
@@ -106,7 +112,7 @@ int launch_stream(StreamMode mode, const StreamArgs &a, hipStream_t st);
 int launch_pattern(StreamMode mode, const StreamArgs &a, const DevCsr &M, hipStream_t st);
 bool pattern_supports(StreamMode mode);
 int launch_stencil(StreamMode mode, const StreamArgs &a, const DevCsr &M, hipStream_t st);
-int stencil_blocks(const StreamArgs &a);   // workgroups (= SM_RESIDUAL_SUMSQ partials) of launch_stencil
+int stencil_blocks(const StreamArgs &a, const DevCsr &M);   // workgroups (= SM_RESIDUAL_SUMSQ partials) of launch_stencil
 int launch_stencil_build(const DevCsr &M, const int *dict_slot, const unsigned *pat_mask, hipStream_t st);
 bool stencil_enabled();
 void set_stencil_form(int on);           // 0: dispatch pattern operators to csr_pattern_kernel instead

@@ -9,6 +9,9 @@
 namespace amg {
 int upload_csr(DevCsr &M, int nrows, int ncols, const int *Ap, const int *Aj, const double *Ax, long *acct);
 int gs_sweep_csr(const Schedule &S, bool bsr1, double *x, const double *b, bool reverse, hipStream_t st);
+int try_patterns(DevCsr &M, const int *Ap, const int *Aj, long *acct);
+int apply_operator(const DevCsr &M, StreamMode mode, const StreamArgs &a, hipStream_t st);
+void free_csr(DevCsr &M);
 }
 using namespace amg;
 
@@ -45,17 +48,24 @@ amg_mat *amg_mat_create(int device, int nrows, int ncols, const int *Ap, const i
     amg_mat *m = new amg_mat();
     m->device = device;
     if (upload_csr(m->M, nrows, ncols, Ap, Aj, Ax, nullptr) != 0) { delete m; return nullptr; }
+    // structured-grid operators (also rank-local ones with a halo) get the pattern / stencil forms
+    if (Aj && try_patterns(m->M, Ap, Aj, nullptr) != 0) { free_csr(m->M); delete m; return nullptr; }
     m->rpw = rows_per_wg_for(m->M.nnz, m->M.nrows);
     return m;
+}
+
+int amg_mat_form(amg_mat *m)
+{
+    if (!m) return -1;
+    if (m->M.st_vals && stencil_enabled()) return 2;
+    return m->M.pat ? 1 : 0;
 }
 
 void amg_mat_destroy(amg_mat *m)
 {
     if (!m) return;
     hipSetDevice(m->device);
-    if (m->M.Ap) hipFree(m->M.Ap);
-    if (m->M.Aj) hipFree(m->M.Aj);
-    if (m->M.Ax) hipFree(m->M.Ax);
+    free_csr(m->M);
     if (m->sched) { m->sched->release(); delete m->sched; }
     delete m;
 }
@@ -107,7 +117,7 @@ int amg_mat_apply(amg_mat *m, int mode, const double *xg, const double *b, const
     a.Ap = m->M.Ap; a.Aj = m->M.Aj; a.Ax = m->M.Ax;
     a.row_lo = 0; a.row_hi = m->M.nrows; a.nnz_total = m->M.nnz; a.rows_per_wg = m->rpw;
     a.xg = xg; a.b = b; a.v2 = v2; a.out = out; a.out2 = out2; a.c0 = c0; a.gscale = gscale;
-    return launch_stream((StreamMode)mode, a, (hipStream_t)stream);
+    return apply_operator(m->M, (StreamMode)mode, a, (hipStream_t)stream);
 }
 
 // the same launch restricted to rows [row_lo, row_hi): lets a partitioned driver run the rows that
@@ -124,7 +134,7 @@ int amg_mat_apply_rows(amg_mat *m, int mode, int row_lo, int row_hi, const doubl
     a.Ap = m->M.Ap; a.Aj = m->M.Aj; a.Ax = m->M.Ax;
     a.row_lo = row_lo; a.row_hi = row_hi; a.nnz_total = m->M.nnz; a.rows_per_wg = m->rpw;
     a.xg = xg; a.b = b; a.v2 = v2; a.out = out; a.out2 = out2; a.c0 = c0; a.gscale = gscale;
-    return launch_stream((StreamMode)mode, a, (hipStream_t)stream);
+    return apply_operator(m->M, (StreamMode)mode, a, (hipStream_t)stream);
 }
 
 int amg_dev_scale(double *out, const double *in, double c, long n, void *stream)

@@ -42,7 +42,7 @@ template <class T> static int dev_alloc(T **p, long count, long *acct)
     return 0;
 }
 
-static void free_csr(DevCsr &M)
+void free_csr(DevCsr &M)
 {
     if (M.Ap) hipFree(M.Ap);
     if (M.Aj) hipFree(M.Aj);
@@ -79,40 +79,110 @@ int upload_csr(DevCsr &M, int nrows, int ncols, const int *Ap, const int *Aj, co
     return 0;
 }
 
-// Stencil form on top of the pattern dictionary: possible when the union U of all offsets has at
-// most STENCIL_MAX members, every pattern lists its offsets in increasing order (then slot order
-// = stored order) and the padding (rows that lack some of U) costs less than a fifth of the
-// values.  The value copy is built on the device from the CSR arrays already there.
-static int try_stencil(DevCsr &M, const std::vector<int> &dptr, const std::vector<int> &doff, long *acct)
+// Stencil form on top of the pattern dictionary.  U = the offsets that at least 1/32 of the rows
+// use (all of them when that keeps the padding small); rows with a rarer offset -- the halo columns
+// of a rank-local operator, an irregular corner of a mostly structured grid -- stay with the
+// offset-pattern kernel as up to STENCIL_RANGES contiguous row ranges.  Slot order is a topological
+// order of "precedes in some row's stored sequence", so that the slots with their mask bit set, in
+// slot order, are exactly the row's stored order (the increasing order when rows are sorted).
+// The value copy is built on the device from the CSR arrays already there.
+static int try_stencil(DevCsr &M, const std::vector<int> &dptr, const std::vector<int> &doff,
+                       const std::vector<long> &pcount, const std::vector<int> &pat, long *acct)
 {
     const char *env = getenv("AMG_STENCIL");
     if (env && atoi(env) == 0) return 0;
-    std::vector<int> U(doff);
-    std::sort(U.begin(), U.end());
-    U.erase(std::unique(U.begin(), U.end()), U.end());
-    const int nu = (int)U.size();
-    if (nu < 1 || nu > STENCIL_MAX) return 0;
-    if ((double)M.nnz < 0.8 * (double)M.nrows * nu) return 0;
     const int npat = (int)dptr.size() - 1;
-    std::vector<int> slot(doff.size());
+    const long n = M.nrows;
+    std::vector<int> V(doff);                       // distinct offsets
+    std::sort(V.begin(), V.end());
+    V.erase(std::unique(V.begin(), V.end()), V.end());
+    auto id_in = [](const std::vector<int> &W, int o) {
+        auto it = std::lower_bound(W.begin(), W.end(), o);
+        return (it != W.end() && *it == o) ? (int)(it - W.begin()) : -1;
+    };
+    // drop the least-used offset until U fits and the padding is small; the rows that lose an
+    // offset leave the stencil form
+    std::vector<long> use(V.size(), 0);
+    for (int p = 0; p < npat; ++p)
+        for (int q = dptr[p]; q < dptr[p + 1]; ++q) use[(size_t)id_in(V, doff[q])] += pcount[p];
+    std::vector<char> covered((size_t)npat, 1);
+    long rows_cov = 0, nnz_cov = 0;
+    for (;;) {
+        rows_cov = nnz_cov = 0;
+        for (int p = 0; p < npat; ++p) {
+            covered[p] = 1;
+            for (int q = dptr[p]; q < dptr[p + 1]; ++q) if (id_in(V, doff[q]) < 0) covered[p] = 0;
+            if (covered[p]) { rows_cov += pcount[p]; nnz_cov += pcount[p] * (dptr[p + 1] - dptr[p]); }
+        }
+        if (rows_cov * 4 < n * 3 || V.empty()) return 0;                     // less than 3/4 of the rows fit
+        if ((int)V.size() <= STENCIL_MAX && (double)nnz_cov >= 0.8 * (double)rows_cov * (double)V.size()) break;
+        size_t least = 0;
+        for (size_t c = 1; c < V.size(); ++c) if (use[c] < use[least]) least = c;
+        V.erase(V.begin() + (long)least);
+        use.erase(use.begin() + (long)least);
+    }
+    const int nu = (int)V.size();
+    // uncovered rows as contiguous ranges; runs separated by fewer than 4096 covered rows are
+    // merged (the rows in between then go with their range: cheaper than another launch)
+    int nr = 0, ranges[STENCIL_RANGES][2];
+    if (rows_cov < n) {
+        std::vector<std::pair<long, long>> runs;
+        for (long i = 0; i < n;) {
+            if (covered[pat[i]]) { ++i; continue; }
+            long j = i;
+            while (j < n && !covered[pat[j]]) ++j;
+            if (!runs.empty() && i - runs.back().second < 4096) runs.back().second = j;
+            else runs.emplace_back(i, j);
+            i = j;
+        }
+        if ((int)runs.size() > STENCIL_RANGES) return 0;
+        for (auto &r : runs) { ranges[nr][0] = (int)r.first; ranges[nr][1] = (int)r.second; ++nr; }
+    }
+    // topological slot order over the covered patterns
+    std::vector<unsigned> succ((size_t)nu, 0u);
+    std::vector<int> indeg((size_t)nu, 0);
+    for (int p = 0; p < npat; ++p) {
+        if (!covered[p]) continue;
+        for (int q = dptr[p] + 1; q < dptr[p + 1]; ++q) {
+            const int a = id_in(V, doff[q - 1]), b = id_in(V, doff[q]);
+            if (a == b) return 0;                                           // duplicate column in a row
+            if (!((succ[a] >> b) & 1u)) { succ[a] |= 1u << b; ++indeg[b]; }
+        }
+    }
+    std::vector<int> U;                             // offsets in slot order
+    std::vector<int> slot_of((size_t)nu, -1);
+    std::vector<char> done((size_t)nu, 0);
+    for (int step = 0; step < nu; ++step) {
+        int pick = -1;
+        for (int c = 0; c < nu; ++c) if (!done[c] && indeg[c] == 0) { pick = c; break; }   // smallest offset first
+        if (pick < 0) return 0;                                              // patterns disagree on the order
+        done[pick] = 1;
+        slot_of[pick] = (int)U.size();
+        U.push_back(V[pick]);
+        for (int c = 0; c < nu; ++c) if ((succ[pick] >> c) & 1u) --indeg[c];
+    }
+    std::vector<int> slot(doff.size(), -1);
     std::vector<unsigned> pmask((size_t)npat, 0u);
     for (int p = 0; p < npat; ++p) {
+        if (!covered[p]) { pmask[p] = 0x80000000u; continue; }
         for (int q = dptr[p]; q < dptr[p + 1]; ++q) {
-            if (q > dptr[p] && doff[q] <= doff[q - 1]) return 0;           // stored order is not by column
-            slot[q] = (int)(std::lower_bound(U.begin(), U.end(), doff[q]) - U.begin());
+            slot[q] = slot_of[id_in(V, doff[q])];
+            if (q > dptr[p] && slot[q] <= slot[q - 1]) return 0;
             pmask[p] |= 1u << slot[q];
         }
     }
     M.st_nu = nu;
     M.st_u0 = -1;
     for (int u = 0; u < nu; ++u) { M.st_off[u] = U[u]; if (U[u] == 0) M.st_u0 = u; }
+    M.st_nranges = nr;
+    for (int r = 0; r < nr; ++r) { M.st_range[r][0] = ranges[r][0]; M.st_range[r][1] = ranges[r][1]; }
     const size_t nblk = ((size_t)M.nrows + 255) / 256;
     int *dslot = nullptr;
     unsigned *dmask = nullptr;
     CHK(dev_alloc(&M.st_vals, nblk * nu * 256, acct));
     {
-        unsigned char *mb = nullptr;             // 1 byte per row for |U| <= 8, 4 otherwise
-        CHK(dev_alloc(&mb, (size_t)M.nrows * (nu <= 8 ? 1 : 4) + 16, acct));
+        unsigned char *mb = nullptr;             // 1 byte per row for |U| <= 7, 4 otherwise
+        CHK(dev_alloc(&mb, (size_t)M.nrows * (nu <= 7 ? 1 : 4) + 16, acct));
         M.st_mask = mb;
     }
     CHK(dev_alloc(&dslot, slot.size(), nullptr));
@@ -134,8 +204,9 @@ int try_patterns(DevCsr &M, const int *Ap, const int *Aj, long *acct)
     const char *env = getenv("AMG_PATTERN");
     if (env && atoi(env) == 0) return 0;
     const int n = M.nrows;
-    if (n != M.ncols || n < 1024) return 0;
+    if (n > M.ncols || n < 1024) return 0;      // square, or a rank-local [owned | halo] operator
     std::vector<int> pat((size_t)n), dptr(1, 0), doff;
+    std::vector<long> pcount;
     // open-addressing table: hash of the offset tuple -> pattern id
     const int TBL = 1024;
     std::vector<int> tbl((size_t)TBL, -1);
@@ -161,20 +232,27 @@ int try_patterns(DevCsr &M, const int *Ap, const int *Aj, long *acct)
             dptr.push_back((int)doff.size());
             tbl[slot] = id;
             thash[slot] = hsh;
+            pcount.push_back(0);
         }
         pat[i] = id;
+        ++pcount[id];
     }
     M.npat = (int)dptr.size() - 1;
     M.ndict = (int)doff.size();
+    // stride of the slowest grid axis = the widest offset of the pattern most rows share (halo
+    // offsets of a rank-local operator are larger but belong to boundary rows only)
     M.period_rows = 0;
-    for (int o : doff) M.period_rows = std::max(M.period_rows, std::abs(o));
+    {
+        const int top = (int)(std::max_element(pcount.begin(), pcount.end()) - pcount.begin());
+        for (int q = dptr[top]; q < dptr[top + 1]; ++q) M.period_rows = std::max(M.period_rows, std::abs(doff[q]));
+    }
     CHK(dev_alloc(&M.pat, n, acct));
     CHK(dev_alloc(&M.dict_ptr, M.npat + 1, acct));
     CHK(dev_alloc(&M.dict_off, M.ndict, acct));
     AMG_HIP(hipMemcpy(M.pat, pat.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
     AMG_HIP(hipMemcpy(M.dict_ptr, dptr.data(), sizeof(int) * dptr.size(), hipMemcpyHostToDevice));
     if (M.ndict) AMG_HIP(hipMemcpy(M.dict_off, doff.data(), sizeof(int) * doff.size(), hipMemcpyHostToDevice));
-    return try_stencil(M, dptr, doff, acct);
+    return try_stencil(M, dptr, doff, pcount, pat, acct);
 }
 
 int upload_bsr(DevBsr &M, int nbrows, int bs, const int *Ap, const int *Aj, const double *Ax,
@@ -346,14 +424,20 @@ static StreamArgs base_args(const DevCsr &M)
     return a;
 }
 
+// the storage form an operator application runs from: stencil, offset-pattern or plain CSR
+int apply_operator(const DevCsr &M, StreamMode mode, const StreamArgs &a, hipStream_t st)
+{
+    if (M.st_vals && stencil_enabled() && pattern_supports(mode)) return launch_stencil(mode, a, M, st);
+    if (M.pat && pattern_supports(mode)) return launch_pattern(mode, a, M, st);
+    return launch_stream(mode, a, st);
+}
+
 int spmv(const DevCsr &M, StreamMode mode, const double *xg, const double *b, const double *v2,
          double *out, double *out2, double c0, hipStream_t st)
 {
     StreamArgs a = base_args(M);
     a.xg = xg; a.b = b; a.v2 = v2; a.out = out; a.out2 = out2; a.c0 = c0;
-    if (M.st_vals && stencil_enabled() && pattern_supports(mode)) return launch_stencil(mode, a, M, st);
-    if (M.pat && pattern_supports(mode)) return launch_pattern(mode, a, M, st);
-    return launch_stream(mode, a, st);
+    return apply_operator(M, mode, a, st);
 }
 
 // products a_ij * (gscale * xg_j): the polynomial smoother gathers h = c0*r straight from r
@@ -362,9 +446,7 @@ static int spmv_scaled(const DevCsr &M, StreamMode mode, const double *xg, doubl
 {
     StreamArgs a = base_args(M);
     a.xg = xg; a.b = b; a.v2 = v2; a.out = out; a.c0 = c0; a.gscale = gscale;
-    if (M.st_vals && stencil_enabled() && pattern_supports(mode)) return launch_stencil(mode, a, M, st);
-    if (M.pat && pattern_supports(mode)) return launch_pattern(mode, a, M, st);
-    return launch_stream(mode, a, st);
+    return apply_operator(M, mode, a, st);
 }
 
 // one directional sweep of a scheduled (CSR flavour) Gauss-Seidel
@@ -646,7 +728,7 @@ static int residual_norm_to(amg_hier *h, double *slot)
     a.out = keep ? L0.r : nullptr;
     h->r_kept = keep;
     const bool stencil = L0.A.st_vals && stencil_enabled();
-    const int nb = stencil ? stencil_blocks(a) : stream_blocks(a);
+    const int nb = stencil ? stencil_blocks(a, L0.A) : stream_blocks(a);
     if (nb > h->sumsq_cap) { set_error("sumsq partial buffer too small"); return AMG_ESTATE; }
     if (stencil) CHK(launch_stencil(SM_RESIDUAL_SUMSQ, a, L0.A, h->stream));
     else if (L0.A.pat) CHK(launch_pattern(SM_RESIDUAL_SUMSQ, a, L0.A, h->stream));
@@ -1046,7 +1128,7 @@ int amg_hier_finalize(amg_hier *h)
     if (!h->norm_scratch) CHK(dev_alloc(&h->norm_scratch, 1024 + 8, &h->dev_bytes));
     {
         StreamArgs a0 = base_args(h->lv[0].A);
-        long need = std::max(stream_blocks(a0), stencil_blocks(a0)) + 8;
+        long need = std::max(stream_blocks(a0), stencil_blocks(a0, h->lv[0].A)) + 8;
         if (need > h->sumsq_cap) {
             if (h->sumsq_partials) hipFree(h->sumsq_partials);
             h->sumsq_partials = nullptr;
@@ -1300,7 +1382,7 @@ static double smoother_apps(const Smoother &s, bool x_zero)
 static double bytes_spmv_moved(const DevCsr &M)
 {
     if (M.st_vals && stencil_enabled())     // padded values + one mask word per row; no row pointer
-        return 8.0 * (double)M.st_nu * 256.0 * (double)((M.nrows + 255) / 256) + (M.st_nu <= 8 ? 1.0 : 4.0) * M.nrows +
+        return 8.0 * (double)M.st_nu * 256.0 * (double)((M.nrows + 255) / 256) + (M.st_nu <= 7 ? 1.0 : 4.0) * M.nrows +
                8.0 * M.ncols + 8.0 * M.nrows;
     if (!M.pat) return bytes_spmv(M);
     return 8.0 * (double)M.nnz + 4.0 * M.nrows + 4.0 * (M.nrows + 1.0) + 8.0 * M.ncols + 8.0 * M.nrows;

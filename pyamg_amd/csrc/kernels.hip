@@ -573,7 +573,8 @@ int launch_pattern(StreamMode mode, const StreamArgs &a, const DevCsr &M, hipStr
 // ---------------------------------------------------------------------------
 struct StencilArgs {
     const double *vals;
-    const void *mask;                    // uint8 per row in the NUB == 8 instantiation, else uint32
+    const void *mask;                    // uint8 per row in the NUB == 8 instantiation (|U| <= 7), else uint32;
+                                         // top bit set = the row is applied by the pattern kernel instead
     int nu, u0;
     int blk_lo, nblocks;                 // blocks [blk_lo, blk_lo + nblocks) cover the row range
     int period_blocks, seg_blocks;       // plane-periodic block -> XCD mapping, see PatternArgs
@@ -616,12 +617,15 @@ __global__ __launch_bounds__(WG) void stencil_kernel(StreamArgs a, StencilArgs E
     double bval = 0.0, pre2 = 0.0;
     if (live) {
         m = (NUB == 8) ? (unsigned)static_cast<const unsigned char *>(E.mask)[i] : static_cast<const unsigned *>(E.mask)[i];
+        if (m & ((NUB == 8) ? 0x80u : 0x80000000u)) m = 0xFFFFFFFFu;          // not covered
         if (MT::sub || MODE == SM_RESIDUAL || MODE == SM_RESIDUAL_SUMSQ || MODE == SM_POLY_STEP ||
             MODE == SM_POLY_LAST || MODE == SM_JACOBI)
             bval = a.b[i];
         if (MODE == SM_MATVEC_ACC) pre2 = a.out[i];
         else if (MODE == SM_POLY_LAST || MODE == SM_JACOBI || MODE == SM_JACOBI_BSR1) pre2 = a.v2[i];
     }
+    const bool covered = live && m != 0xFFFFFFFFu;
+    if (!covered) m = 0;
     const double gscale = a.gscale;
     double acc = MT::sub ? bval : 0.0, diag = 0.0;
 #pragma unroll
@@ -635,7 +639,7 @@ __global__ __launch_bounds__(WG) void stencil_kernel(StreamArgs a, StencilArgs E
 
     if (MODE == SM_RESIDUAL_SUMSQ) {
         double sq = 0.0;
-        if (live) {
+        if (covered) {
             double rr = bval - acc;
             sq = rr * rr;
             if (a.out) store_out(&a.out[i], rr);
@@ -644,7 +648,7 @@ __global__ __launch_bounds__(WG) void stencil_kernel(StreamArgs a, StencilArgs E
         if (t == 0) a.out2[blk - E.blk_lo] = tot;
         return;
     }
-    if (!live) return;
+    if (!covered) return;
     if (MODE == SM_MATVEC) {
         store_out(&a.out[i], acc);
     } else if (MODE == SM_MATVEC_ACC) {
@@ -680,16 +684,22 @@ __global__ __launch_bounds__(WG) void stencil_kernel(StreamArgs a, StencilArgs E
     }
 }
 
+struct StencilRanges { int n; int range[STENCIL_RANGES][2]; };
+
 // values of the CSR -> stencil layout; one thread per row
 __global__ void stencil_build_kernel(int n, const int *Ap, const double *Ax, const int *pat, const int *dict_ptr,
                                      const int *dict_slot, const unsigned *pat_mask, int nu, double *vals,
-                                     void *mask)
+                                     void *mask, StencilRanges R)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int p = pat[i];
-    if (nu <= 8) static_cast<unsigned char *>(mask)[i] = (unsigned char)pat_mask[p];
-    else static_cast<unsigned *>(mask)[i] = pat_mask[p];
+    unsigned pm = pat_mask[p];
+    for (int r = 0; r < R.n; ++r)
+        if (i >= R.range[r][0] && i < R.range[r][1]) pm = 0x80000000u;      // inside an uncovered range
+    if (nu <= 7) static_cast<unsigned char *>(mask)[i] = (pm & 0x80000000u) ? (unsigned char)0x80 : (unsigned char)pm;
+    else static_cast<unsigned *>(mask)[i] = pm;
+    if (pm & 0x80000000u) return;                                       // row stays with the pattern kernel
     const int s = Ap[i], e = Ap[i + 1], d = dict_ptr[p];
     double *vp = vals + ((size_t)(i / WG) * nu) * WG + (i % WG);
     for (int k = s; k < e; ++k) vp[(size_t)dict_slot[d + (k - s)] * WG] = Ax[k];
@@ -698,8 +708,11 @@ __global__ void stencil_build_kernel(int n, const int *Ap, const double *Ax, con
 int launch_stencil_build(const DevCsr &M, const int *dict_slot, const unsigned *pat_mask, hipStream_t st)
 {
     const int n = M.nrows;
+    StencilRanges R;
+    R.n = M.st_nranges;
+    for (int r = 0; r < STENCIL_RANGES; ++r) { R.range[r][0] = M.st_range[r][0]; R.range[r][1] = M.st_range[r][1]; }
     hipLaunchKernelGGL(stencil_build_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, M.Ap, M.Ax, M.pat,
-                       M.dict_ptr, dict_slot, pat_mask, M.st_nu, M.st_vals, M.st_mask);
+                       M.dict_ptr, dict_slot, pat_mask, M.st_nu, M.st_vals, M.st_mask, R);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "stencil build launch", __FILE__, __LINE__);
     return 0;
@@ -709,16 +722,36 @@ static int g_stencil_form = 1;
 void set_stencil_form(int on) { g_stencil_form = on; }
 bool stencil_enabled() { return g_stencil_form != 0; }
 
-int stencil_blocks(const StreamArgs &a)
+static int stencil_own_blocks(const StreamArgs &a)
 {
     if (a.row_hi <= a.row_lo) return 0;
     return (a.row_hi - 1) / WG - a.row_lo / WG + 1;
 }
 
+static int pattern_rpb(const StreamArgs &a)
+{
+    int rpb = a.rows_per_wg;
+    if (rpb < 1 || rpb > WG) rpb = WG;
+    return rpb;
+}
+
+// workgroups of launch_stencil = partial sums SM_RESIDUAL_SUMSQ writes: the stencil launch's blocks,
+// then those of the pattern launches over the uncovered row ranges
+int stencil_blocks(const StreamArgs &a, const DevCsr &M)
+{
+    int nb = stencil_own_blocks(a);
+    const int rpb = pattern_rpb(a);
+    for (int r = 0; r < M.st_nranges; ++r) {
+        const int lo = std::max(a.row_lo, M.st_range[r][0]), hi = std::min(a.row_hi, M.st_range[r][1]);
+        if (hi > lo) nb += (hi - lo + rpb - 1) / rpb;
+    }
+    return nb;
+}
+
 template <int MODE>
 static int launch_stencil_mode(const StreamArgs &a, const DevCsr &M, hipStream_t st)
 {
-    const int nb = stencil_blocks(a);
+    const int nb = stencil_own_blocks(a);
     if (nb <= 0) return 0;
     StreamArgs b = a;
     if (b.gscale == 0.0) b.gscale = 1.0;
@@ -737,7 +770,7 @@ static int launch_stencil_mode(const StreamArgs &a, const DevCsr &M, hipStream_t
             grid = 8 * G * ((nb + S - 1) / S);
         }
     }
-    if (M.st_nu <= 8)
+    if (M.st_nu <= 7)
         hipLaunchKernelGGL((stencil_kernel<MODE, 8>), dim3(grid), dim3(WG), 0, st, b, E, g_xcd_chunk);
     else if (M.st_nu <= 16)
         hipLaunchKernelGGL((stencil_kernel<MODE, 16>), dim3(grid), dim3(WG), 0, st, b, E, g_xcd_chunk);
@@ -745,6 +778,19 @@ static int launch_stencil_mode(const StreamArgs &a, const DevCsr &M, hipStream_t
         hipLaunchKernelGGL((stencil_kernel<MODE, 32>), dim3(grid), dim3(WG), 0, st, b, E, g_xcd_chunk);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "stencil launch", __FILE__, __LINE__);
+    // rows outside the stencil form
+    const int rpb = pattern_rpb(a);
+    int done = nb;
+    for (int r = 0; r < M.st_nranges; ++r) {
+        StreamArgs c = a;
+        c.row_lo = std::max(a.row_lo, M.st_range[r][0]);
+        c.row_hi = std::min(a.row_hi, M.st_range[r][1]);
+        if (c.row_hi <= c.row_lo) continue;
+        if (MODE == SM_RESIDUAL_SUMSQ) c.out2 = a.out2 + done;
+        int rc = launch_pattern((StreamMode)MODE, c, M, st);
+        if (rc != 0) return rc;
+        done += (c.row_hi - c.row_lo + rpb - 1) / rpb;
+    }
     return 0;
 }
 

@@ -211,6 +211,8 @@ class DistributedSolver(object):
                 else:
                     break
         self.lv = []
+        self.keep_residual = _os.environ.get("AMG_KEEP_RESIDUAL", "1") != "0"
+        self._r_kept = False
         self._build(levels, coarse_dense)
 
     # ------------------------------------------------------------------ setup
@@ -389,7 +391,7 @@ class DistributedSolver(object):
         return float(np.sqrt(self.be.to_host(self.acc, 1)[0]))
 
     # ------------------------------------------------------------------ smoothers (relaxation.py)
-    def relax(self, l, s, xname, bvec, x_zero):
+    def relax(self, l, s, xname, bvec, x_zero, r_ready=False):
         lv = self.lv[l]
         if s is None or s.get("name") is None:
             return
@@ -417,11 +419,13 @@ class DistributedSolver(object):
                 lv.xalt = x
             return
         co = s["coefficients"]
-        for _ in range(it):
+        for k in range(it):
             # h = c0*r is gathered from r on the fly (one rounding either way); see hier.hip relax()
             x = getattr(lv, xname)
             if x_zero:
                 rvec = bvec
+            elif r_ready and k == 0:
+                rvec = lv.r                # b - A x of this very x, left there by the residual norm
             else:
                 self.xapply(l, RESIDUAL, x, bvec, None, lv.r, None, 0.0)
                 rvec = lv.r
@@ -467,9 +471,9 @@ class DistributedSolver(object):
         self.dist.all_to_all_single(out, inp, counts, [int(mine.numel())] * W, group=self.group)
 
     # ------------------------------------------------------------------ cycle (multilevel.py:473-548)
-    def cycle(self, l, cyc, x_zero):
+    def cycle(self, l, cyc, x_zero, r_ready=False):
         lv, nx = self.lv[l], self.lv[l + 1]
-        self.relax(l, lv.pre, "x", lv.b, x_zero)
+        self.relax(l, lv.pre, "x", lv.b, x_zero, r_ready)
         self.xapply(l, RESIDUAL, lv.x, lv.b, None, lv.r, None, 0.0)
         self.exchange(l, lv.r)
         if lv.rslice is not None:
@@ -497,9 +501,17 @@ class DistributedSolver(object):
         self.be.apply(lv.P, MATVEC_ACC, nx.x, None, None, lv.x, None, 0.0)
         self.relax(l, lv.post, "x", lv.b, False)
 
+    def _keeps_residual(self):
+        # the residual of the convergence test stays in lv[0].r; a polynomial pre-smoother on level 0
+        # starts from exactly that vector (relaxation.py:655), so it need not be formed twice
+        pre = self.lv[0].pre if self.nlevels > 1 else None
+        return bool(self.keep_residual and pre is not None and pre.get("name") == "polynomial"
+                    and int(pre.get("iterations", 1)) >= 1)
+
     def residual_norm(self):
         lv = self.lv[0]
         self.xapply(0, RESIDUAL, lv.x, lv.b, None, lv.r, None, 0.0)
+        self._r_kept = self._keeps_residual()
         return self.global_norm(lv.r, lv.n_own)
 
     def set_problem(self, b_local, x0_local=None):
@@ -509,12 +521,14 @@ class DistributedSolver(object):
             self.be.zero(lv.x, lv.n_own)
         else:
             self.be.from_host(lv.x, x0_local)
+        self._r_kept = False
 
     def iterate(self, cyc, x_zero):
+        r_ready, self._r_kept = self._r_kept, False
         if self.nlevels == 1:
             self.coarse_solve()
         else:
-            self.cycle(0, cyc, x_zero)
+            self.cycle(0, cyc, x_zero, r_ready)
 
     def solve(self, b_local, x0_local=None, tol=1e-5, maxiter=100, cycle="V", fixed=False):
         """multilevel.py:316-471 on the local slices; returns (x_local, residuals)"""
@@ -549,6 +563,7 @@ class DistributedSolver(object):
             self.iterate(cycle, x_zero)
             x_zero = False
             self.xapply(0, RESIDUAL, lv.x, lv.b, None, lv.r, None, 0.0)
+            self._r_kept = self._keeps_residual()
             self.be.sumsq(lv.r, lv.n_own, hist[k:k + 1])
         if self.world > 1 and steps:
             self.dist.all_reduce(hist[:steps], group=self.group)

@@ -57,6 +57,54 @@ def test_two_ranks_equal_single_gpu(case, tmp_path):
     assert len(rf) == 6 and np.allclose(rf, res1[:6], rtol=1e-12, atol=1e-13 * res1[0])
 
 
+def _own_hierarchy(grid):
+    from pyamg_amd.aggregation import poisson, smoothed_aggregation_solver
+    A = poisson(grid)
+    np.random.seed(0)
+    sm = ("chebyshev", {"degree": 2})
+    ml = smoothed_aggregation_solver(A, presmoother=sm, postsmoother=sm)
+    b = np.random.RandomState(7).rand(A.shape[0])
+    return ml, b
+
+
+def _worker_stencil(rank, world, port, grid, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pyamg_amd.distributed import DistributedSolver, HipBackend, split_rows, levels_from_ml
+        ml, b = _own_hierarchy(grid)
+        levels, coarse = levels_from_ml(ml)
+        S = DistributedSolver(levels, coarse, HipBackend(0), rank, world, replicate_below=600)
+        assert S.be.L.amg_mat_form(S.lv[0].A) == 2, "level 0 of the slab should be in stencil form"
+        bnd = split_rows(len(b), world)
+        lo, hi = int(bnd[rank]), int(bnd[rank + 1])
+        x, res = S.solve(b[lo:hi], None, tol=0.0, maxiter=5, cycle="V", fixed=True)
+        np.save(os.path.join(out_dir, "x_%d.npy" % rank), x)
+        if rank == 0:
+            np.save(os.path.join(out_dir, "res.npy"), np.array(res))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_rank_local_stencil_form_with_halos(world, tmp_path):
+    """Level 0 of a rank's slab is large enough (>= 1024 rows) for the stencil form: its halo columns
+    enter the union stencil as extra offsets, the lower-halo one FIRST in stored order although its
+    local index is the largest (slot order is topological, not increasing).  3 ranks: the middle one
+    has both halos; the slab boundaries cut through grid planes.  Also covers the residual of the
+    convergence test being handed to the next pre-smoother in the partitioned driver."""
+    grid = (25, 24, 23)
+    ml, b = _own_hierarchy(grid)
+    res1 = []
+    x1 = ml.solve(b, tol=0.0, maxiter=5, residuals=res1)
+    mp.spawn(_worker_stencil, args=(world, _free_port(), grid, str(tmp_path)), nprocs=world, join=True)
+    x = np.concatenate([np.load(tmp_path / ("x_%d.npy" % r)) for r in range(world)])
+    res = np.load(tmp_path / "res.npy")
+    assert np.array_equal(x, x1), np.abs(x - x1).max()
+    assert np.allclose(res, res1, rtol=1e-12, atol=1e-13 * res1[0])
+
+
 def _worker_hybrid(rank, world, port, case, out_dir, rep=0):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)

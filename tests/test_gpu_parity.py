@@ -433,6 +433,50 @@ def test_plane_periodic_xcd_mapping_is_only_a_schedule():
     assert np.allclose(got[1][1], reso, rtol=1e-12)
 
 
+def test_stencil_form_with_rows_left_to_the_pattern_kernel():
+    """A structured operator with a few irregular rows: the rare offsets are dropped from the union
+    stencil and their rows (two ranges) are applied by the offset-pattern kernel after the stencil
+    launch -- also in the fused residual-norm pass, whose partial sums then come from both launches.
+    Same bits as with the stencil form switched off, and as the oracle."""
+    import scipy.sparse as sp
+    from pyamg_amd.aggregation import poisson as native, smoothed_aggregation_solver
+    from pyamg_amd import _lib
+    A = native((20, 21, 22)).tolil()
+    for i in range(3000, 3011):
+        A[i, i + 1234] = -0.0625
+        A[i + 1234, i] = -0.0625
+    A = sp.csr_matrix(A)
+    A.sort_indices()
+    np.random.seed(0)
+    sm = ("chebyshev", {"degree": 2})
+    ml = smoothed_aggregation_solver(A, presmoother=sm, postsmoother=sm)
+    dev = ml.device_hierarchy()
+    assert _lib.lib().amg_hier_operator_form(dev.h, 0) == 2
+    rng = np.random.RandomState(11)
+    b = rng.rand(A.shape[0])
+    got = {}
+    for stencil in (1, 0):
+        _lib.lib().amg_set_stencil_form(stencil)
+        res = []
+        x = ml.solve(b, tol=0.0, maxiter=4, residuals=res)
+        got[stencil] = (x, np.array(res))
+    _lib.lib().amg_set_stencil_form(1)
+    assert np.array_equal(got[0][0], got[1][0])
+    assert np.allclose(got[0][1], got[1][1], rtol=1e-14)          # norms: partial sums grouped differently
+    levels = []
+    for lvl in ml.levels:
+        L = {"A": lvl.A}
+        if hasattr(lvl, "P"):
+            L.update(P=lvl.P, R=lvl.R, pre=dict(lvl.presmoother.desc), post=dict(lvl.postsmoother.desc))
+        levels.append(L)
+    kind, M = ml.coarse_solver.device_form(ml.levels[-1].A)
+    xo, reso = oracle_lib.Hierarchy(levels, M).solve(b, tol=0.0, maxiter=4)
+    assert np.array_equal(got[1][0], xo)
+    assert np.allclose(got[1][1], reso, rtol=1e-12)
+    y = dev.matvec(0, 0, b)
+    assert np.array_equal(y, A * b)
+
+
 def test_device_pcg_matches_reference_cg_semantics():
     """solve(accel='cg') on the device vs a host restatement of pyamg/krylov/_cg.py:84-179 whose
     preconditioner is the oracle's cycle from zero; dots are BLAS / tree / numpy sums, so the bar is
