@@ -8,6 +8,9 @@
  * All paths below are relative to /root/reference.
  */
 #include "amg_oracle.h"
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #include <math.h>
 #include <stdlib.h>
@@ -16,6 +19,18 @@
 /* ------------------------------------------------------------------------- */
 /* amg_core kernels                                                          */
 /* ------------------------------------------------------------------------- */
+
+/* Row-parallel variant for the CPU baseline of bench.py: the loops whose iterations are independent
+ * (one row of a product, one entry of a vector update) run over `oracle_threads` OpenMP threads.
+ * Each row is still summed by one thread left to right, so the results do not depend on the
+ * thread count; the Gauss-Seidel family and the norms stay sequential.  Default: 1 thread. */
+static int oracle_threads = 1;
+void oracle_set_threads(int n)
+{
+    oracle_threads = n < 1 ? 1 : n;
+}
+int oracle_get_threads(void) { return oracle_threads; }
+#define PAR_FOR _Pragma("omp parallel for schedule(static) num_threads(oracle_threads) if (oracle_threads > 1)")
 
 /* pyamg/amg_core/relaxation.h:34-62 */
 void oracle_gauss_seidel(const int *Ap, const int *Aj, const double *Ax, double *x,
@@ -98,6 +113,23 @@ void oracle_jacobi(const int *Ap, const int *Aj, const double *Ax, double *x, co
     double one = 1.0, omega2 = omega[0];
     for (int i = row_start; i != row_stop; i += row_step)
         temp[i] = x[i];
+    if (oracle_threads > 1 && row_step == 1 && row_start <= row_stop) {
+        /* every row reads temp only: independent */
+        PAR_FOR
+        for (int i = row_start; i < row_stop; i++) {
+            double rsum = 0, diag = 0;
+            for (int jj = Ap[i]; jj < Ap[i + 1]; jj++) {
+                int j = Aj[jj];
+                if (i == j)
+                    diag = Ax[jj];
+                else
+                    rsum += Ax[jj] * temp[j];
+            }
+            if (diag != 0.0)
+                x[i] = (one - omega2) * temp[i] + omega2 * ((b[i] - rsum) / diag);
+        }
+        return;
+    }
     for (int i = row_start; i != row_stop; i += row_step) {
         double rsum = 0, diag = 0;
         for (int jj = Ap[i]; jj < Ap[i + 1]; jj++) {
@@ -309,6 +341,7 @@ void oracle_block_gauss_seidel(const int *Ap, const int *Aj, const double *Ax, d
 void oracle_csr_matvec(int n_row, const int *Ap, const int *Aj, const double *Ax,
                        const double *x, double *y)
 {
+    PAR_FOR
     for (int i = 0; i < n_row; i++) {
         double sum = y[i];
         for (int jj = Ap[i]; jj < Ap[i + 1]; jj++)
@@ -325,6 +358,7 @@ void oracle_bsr_matvec(int n_brow, int R, int C, const int *Ap, const int *Aj,
         return;
     }
     long RC = (long)R * C;
+    PAR_FOR
     for (int i = 0; i < n_brow; i++) {
         double *yb = y + (long)R * i;
         for (int jj = Ap[i]; jj < Ap[i + 1]; jj++) {
@@ -513,13 +547,17 @@ static void relax_polynomial(const oracle_mat *A, double *x, const double *b, co
             memcpy(res, b, sizeof(double) * (size_t)n);
         } else {
             mat_apply(A, x, Ah);
+            PAR_FOR
             for (int i = 0; i < n; i++) res[i] = b[i] - Ah[i];
         }
+        PAR_FOR
         for (int i = 0; i < n; i++) h[i] = coef[0] * res[i];
         for (int c = 1; c < ncoef; c++) {
             mat_apply(A, h, Ah);
+            PAR_FOR
             for (int i = 0; i < n; i++) h[i] = coef[c] * res[i] + Ah[i];
         }
+        PAR_FOR
         for (int i = 0; i < n; i++) x[i] += h[i];
     }
     free(res);
@@ -708,6 +746,7 @@ void oracle_cycle(oracle_hier *h, int lvl, double *x, const double *b, int cycle
     double *residual = (double *)malloc(sizeof(double) * (size_t)n);
     double *tmp = (double *)malloc(sizeof(double) * (size_t)n);
     mat_apply(A, x, tmp);                                  /* :496 */
+    PAR_FOR
     for (int i = 0; i < n; i++) residual[i] = b[i] - tmp[i];
 
     double *coarse_b = (double *)malloc(sizeof(double) * (size_t)nc);
@@ -752,6 +791,7 @@ void oracle_cycle(oracle_hier *h, int lvl, double *x, const double *b, int cycle
     }
 
     mat_apply(&L->P, coarse_x, tmp);                       /* :544 */
+    PAR_FOR
     for (int i = 0; i < n; i++) x[i] += tmp[i];
     oracle_relax(A, &L->post, x, b);                       /* :545 */
     if (h->dup_prolong)
@@ -769,6 +809,7 @@ static double residual_norm(const oracle_mat *A, const double *x, const double *
     /* pyamg/util/linalg.py:109-112 */
     int n = A->nrows;
     mat_apply(A, x, w1);
+    PAR_FOR
     for (int i = 0; i < n; i++) w2[i] = b[i] - w1[i];
     return oracle_norm2(w2, n);
 }

@@ -59,6 +59,10 @@ void oracle_block_gauss_seidel(const int *Ap, const int *Aj, const double *Ax, d
                                int row_stop, int row_step, int blocksize);
 
 /* ---- scipy sparsetools SpMV (third party, restated) ---- */
+/* threads for the row-parallel loops (results independent of the count); default 1 */
+void oracle_set_threads(int n);
+int oracle_get_threads(void);
+
 void oracle_csr_matvec(int n_row, const int *Ap, const int *Aj, const double *Ax,
                        const double *x, double *y /* accumulated into */);
 void oracle_bsr_matvec(int n_brow, int R, int C, const int *Ap, const int *Aj,

@@ -86,6 +86,10 @@ def load():
         f = getattr(lib, name)
         f.argtypes = args
         f.restype = None
+    lib.oracle_set_threads.argtypes = [I]
+    lib.oracle_set_threads.restype = None
+    lib.oracle_get_threads.argtypes = []
+    lib.oracle_get_threads.restype = I
     lib.oracle_norm2.argtypes = [c_dbl_p, C.c_long]
     lib.oracle_norm2.restype = D
     lib.oracle_hier_create.argtypes = [I]

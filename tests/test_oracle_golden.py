@@ -205,3 +205,19 @@ def test_kat_polynomial(oracle):
     _relax(oracle, A, {"name": "polynomial", "coefficients": [0.2, -1.0]}, x, b)
     r = b - A * x0
     assert np.allclose(x, x0 + 0.2 * (A * r) - r)
+
+
+def test_row_parallel_oracle_is_thread_count_independent():
+    """bench.py's CPU baseline runs the oracle's row loops over all host cores; a row is still summed by
+    one thread, left to right, so solves must agree bit for bit for any thread count."""
+    lib = oracle_lib.load()
+    for case in ("sa_cheb2_3d", "sa_jacobi_2d"):
+        g = golden_io.load_hier(case)
+        H = oracle_lib.Hierarchy(g["levels"], g["coarse_pinv"])
+        out = []
+        for threads in (1, 4):
+            lib.oracle_set_threads(threads)
+            out.append(H.solve(g["b"], tol=0.0, maxiter=4))
+        lib.oracle_set_threads(1)
+        assert np.array_equal(out[0][0], out[1][0])
+        assert np.array_equal(out[0][1], out[1][1])
