@@ -362,7 +362,7 @@ def main():
 
             # the row-parallel loops of the oracle over the host cores this process may use (same bits
             # for any thread count), then the scalar port
-            cores = max(1, min(len(os.sched_getaffinity(0)), 64))
+            cores = max(1, min(len(os.sched_getaffinity(0)), 16))      # a 1-GPU box's share of host cores
             t_par, rn_par = cpu_step(cores)
             t_cpu, rn = cpu_step(1)
             H.lib.oracle_set_threads(1)

@@ -468,7 +468,13 @@ void oracle_hier_set_duplicate_prolongation(oracle_hier *h, int on)
 /* y = M*x (fresh y), the scipy `A * x` operator */
 static void mat_apply(const oracle_mat *M, const double *x, double *y)
 {
-    memset(y, 0, sizeof(double) * (size_t)M->nrows);
+    if (oracle_threads > 1) {                /* first touch of a fresh buffer: spread the page faults */
+        int n = M->nrows;
+        PAR_FOR
+        for (int i = 0; i < n; i++) y[i] = 0.0;
+    } else {
+        memset(y, 0, sizeof(double) * (size_t)M->nrows);
+    }
     if (M->fmt == ORACLE_FMT_CSR)
         oracle_csr_matvec(M->nrows, M->Ap, M->Aj, M->Ax, x, y);
     else

@@ -928,6 +928,13 @@ int amg_hier_set_matrix(amg_hier *h, int lvl, int which, int fmt, int nrows, int
             AMG_HIP(hipMemcpy(M.Aj, Aj, sizeof(int) * (size_t)last, hipMemcpyDeviceToDevice));
             AMG_HIP(hipMemcpy(M.Ax, Ax, sizeof(double) * (size_t)last, hipMemcpyDeviceToDevice));
         }
+        if (which == AMG_MAT_A && nrows >= 1024) {
+            // the structure analysis runs on the host: fetch the index arrays (not the values)
+            std::vector<int> hp((size_t)nrows + 1), hj((size_t)last);
+            AMG_HIP(hipMemcpy(hp.data(), Ap, sizeof(int) * hp.size(), hipMemcpyDeviceToHost));
+            if (last) AMG_HIP(hipMemcpy(hj.data(), Aj, sizeof(int) * hj.size(), hipMemcpyDeviceToHost));
+            CHK(try_patterns(M, hp.data(), hj.data(), &h->dev_bytes));
+        }
     } else if (fmt == AMG_FMT_CSR || (R == 1 && C == 1)) {
         CHK(upload_csr(M, nrows, ncols, Ap, Aj, Ax, &h->dev_bytes));
         if (which == AMG_MAT_A) CHK(try_patterns(M, Ap, Aj, &h->dev_bytes));
