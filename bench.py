@@ -113,7 +113,7 @@ def partitioned_main(args, rank, local_rank, world, torch, dist):
         ok = 0.0
     flag = torch.tensor([ok], dtype=torch.float64)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=host_group)
-    transport = "RCCL"
+    transport = "RCCL" if dist.get_backend() == "nccl" else dist.get_backend() + " (rehearsal transport)"
     if flag.item() < 0.5:
         dev_group = host_group
         transport = "gloo (RCCL self-test failed)"
