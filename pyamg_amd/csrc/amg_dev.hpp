@@ -51,6 +51,16 @@ struct DevCsr {
     // contiguous row ranges that the offset-pattern kernel applies after the stencil launch.
     int st_nranges = 0;
     int st_range[8][2] = {{0}};
+    // 16-bit column codes for csr_stream_kernel (irregular operators: coarse A_l, P_l, R_l).  The
+    // columns one workgroup's rows reference fall into a few narrow clusters; when at most 16
+    // aligned windows of 4096 columns cover them, entry k is stored as (window slot << 12) | (column
+    // & 4095) and the 16 window origins sit in LDS: 2 B per entry instead of 4.  Workgroups that
+    // need more windows keep reading Aj (flag per workgroup).  Same columns, same order, same bits.
+    unsigned short *Aj16 = nullptr;    // [nnz]
+    int *wg_base = nullptr;            // [nwg * 16]
+    unsigned char *wg_flag = nullptr;  // [nwg] 1 = this workgroup's entries are coded
+    int i16_rpb = 0;                   // rows per workgroup the coding was built for
+    double i16_frac = 0.0;             // fraction of the entries that are coded
     int st_u0 = -1;                // slot of offset 0 (the diagonal), -1 if absent
     int st_off[32] = {0};          // U, increasing
 };
@@ -102,6 +112,9 @@ struct StreamArgs {
     const int *diagpos;      // GS levels: position of the diagonal entry of permuted row i (-1: none)
     long nnz_total;          // entries in Aj/Ax (bound for 16-byte loads)
     int rows_per_wg;         // rows handled by one workgroup (1..256; 0 -> 256)
+    const unsigned short *Aj16;   // 16-bit column codes (DevCsr::Aj16) or null
+    const int *wg_base;
+    const unsigned char *wg_flag;
     double gscale;           // operand scaling: products are a_ij * (gscale * xg[j]); 0 is read as 1.
                              // (polynomial smoother: gather c0*r straight from r, relaxation.py:663-666)
 };
@@ -115,6 +128,9 @@ int launch_stencil(StreamMode mode, const StreamArgs &a, const DevCsr &M, hipStr
 int stencil_blocks(const StreamArgs &a, const DevCsr &M);   // workgroups (= SM_RESIDUAL_SUMSQ partials) of launch_stencil
 int launch_stencil_build(const DevCsr &M, const int *dict_slot, const unsigned *pat_mask, hipStream_t st);
 bool stencil_enabled();
+int launch_index16_build(DevCsr &M, int rpb, hipStream_t st);   // fills Aj16 / wg_base / wg_flag (already allocated)
+bool index16_enabled();
+void set_index16(int on);
 void set_stencil_form(int on);           // 0: dispatch pattern operators to csr_pattern_kernel instead
 void set_xcd_period(int on);             // plane-periodic block->XCD mapping of pattern operators (default on)
 int stream_blocks(const StreamArgs &a);   // workgroups launch_stream will use (partials of SM_RESIDUAL_SUMSQ)

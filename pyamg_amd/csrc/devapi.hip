@@ -12,6 +12,7 @@ int gs_sweep_csr(const Schedule &S, bool bsr1, double *x, const double *b, bool 
 int try_patterns(DevCsr &M, const int *Ap, const int *Aj, long *acct);
 int apply_operator(const DevCsr &M, StreamMode mode, const StreamArgs &a, hipStream_t st);
 void free_csr(DevCsr &M);
+int build_index16(DevCsr &M, const int *Ap_host, long *acct);
 }
 using namespace amg;
 
@@ -50,6 +51,7 @@ amg_mat *amg_mat_create(int device, int nrows, int ncols, const int *Ap, const i
     if (upload_csr(m->M, nrows, ncols, Ap, Aj, Ax, nullptr) != 0) { delete m; return nullptr; }
     // structured-grid operators (also rank-local ones with a halo) get the pattern / stencil forms
     if (Aj && try_patterns(m->M, Ap, Aj, nullptr) != 0) { free_csr(m->M); delete m; return nullptr; }
+    if (Aj && build_index16(m->M, Ap, nullptr) != 0) { free_csr(m->M); delete m; return nullptr; }
     m->rpw = rows_per_wg_for(m->M.nnz, m->M.nrows);
     return m;
 }
@@ -116,6 +118,7 @@ int amg_mat_apply(amg_mat *m, int mode, const double *xg, const double *b, const
     std::memset(&a, 0, sizeof(a));
     a.Ap = m->M.Ap; a.Aj = m->M.Aj; a.Ax = m->M.Ax;
     a.row_lo = 0; a.row_hi = m->M.nrows; a.nnz_total = m->M.nnz; a.rows_per_wg = m->rpw;
+    if (m->M.Aj16 && m->M.i16_rpb == m->rpw) { a.Aj16 = m->M.Aj16; a.wg_base = m->M.wg_base; a.wg_flag = m->M.wg_flag; }
     a.xg = xg; a.b = b; a.v2 = v2; a.out = out; a.out2 = out2; a.c0 = c0; a.gscale = gscale;
     return apply_operator(m->M, (StreamMode)mode, a, (hipStream_t)stream);
 }
@@ -133,6 +136,7 @@ int amg_mat_apply_rows(amg_mat *m, int mode, int row_lo, int row_hi, const doubl
     std::memset(&a, 0, sizeof(a));
     a.Ap = m->M.Ap; a.Aj = m->M.Aj; a.Ax = m->M.Ax;
     a.row_lo = row_lo; a.row_hi = row_hi; a.nnz_total = m->M.nnz; a.rows_per_wg = m->rpw;
+    if (m->M.Aj16 && m->M.i16_rpb == m->rpw) { a.Aj16 = m->M.Aj16; a.wg_base = m->M.wg_base; a.wg_flag = m->M.wg_flag; }
     a.xg = xg; a.b = b; a.v2 = v2; a.out = out; a.out2 = out2; a.c0 = c0; a.gscale = gscale;
     return apply_operator(m->M, (StreamMode)mode, a, (hipStream_t)stream);
 }

@@ -52,6 +52,9 @@ void free_csr(DevCsr &M)
     if (M.dict_off) hipFree(M.dict_off);
     if (M.st_vals) hipFree(M.st_vals);
     if (M.st_mask) hipFree(M.st_mask);
+    if (M.Aj16) hipFree(M.Aj16);
+    if (M.wg_base) hipFree(M.wg_base);
+    if (M.wg_flag) hipFree(M.wg_flag);
     M = DevCsr();
 }
 static void free_bsr(DevBsr &M)
@@ -77,6 +80,39 @@ int upload_csr(DevCsr &M, int nrows, int ncols, const int *Ap, const int *Aj, co
         AMG_HIP(hipMemcpy(M.Ax, Ax, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice));
     }
     return 0;
+}
+
+// 16-bit column codes for the stream kernel (amg_dev.hpp, DevCsr::Aj16).  Built on the device for the
+// row blocking the kernel will use; kept when at least 30 % of the entries could be coded.
+int build_index16(DevCsr &M, const int *Ap_host, long *acct)
+{
+    const char *env = getenv("AMG_INDEX16");
+    if (!(index16_enabled() || (env && atoi(env) != 0))) return 0;      // opt-in (amg_set_index16 before upload)
+    if (M.nnz < 65536 || M.ncols < 8192 || M.st_vals) return 0;
+    const int rpb = rows_per_wg_for(M.nnz, M.nrows);
+    const int nwg = (M.nrows + rpb - 1) / rpb;
+    long before = acct ? *acct : 0;
+    CHK(dev_alloc(&M.Aj16, M.nnz, acct));
+    CHK(dev_alloc(&M.wg_base, (long)nwg * 16, acct));
+    CHK(dev_alloc(&M.wg_flag, nwg, acct));
+    M.i16_rpb = rpb;
+    int rc = launch_index16_build(M, rpb, 0);
+    AMG_HIP(hipDeviceSynchronize());
+    std::vector<unsigned char> flag((size_t)nwg);
+    AMG_HIP(hipMemcpy(flag.data(), M.wg_flag, (size_t)nwg, hipMemcpyDeviceToHost));
+    double coded = 0.0;
+    for (int w = 0; w < nwg; ++w)
+        if (flag[w]) {
+            const int r0 = w * rpb, r1 = std::min(M.nrows, r0 + rpb);
+            coded += (double)(Ap_host[r1] - Ap_host[r0]);
+        }
+    M.i16_frac = M.nnz ? coded / (double)M.nnz : 0.0;
+    if (rc != 0 || M.i16_frac < 0.3) {
+        hipFree(M.Aj16); hipFree(M.wg_base); hipFree(M.wg_flag);
+        M.Aj16 = nullptr; M.wg_base = nullptr; M.wg_flag = nullptr; M.i16_rpb = 0; M.i16_frac = 0.0;
+        if (acct) *acct = before;
+    }
+    return rc;
 }
 
 // Stencil form on top of the pattern dictionary.  U = the offsets that at least 1/32 of the rows
@@ -421,6 +457,7 @@ static StreamArgs base_args(const DevCsr &M)
     a.row_lo = 0; a.row_hi = M.nrows;
     a.nnz_total = M.nnz;
     a.rows_per_wg = rows_per_wg_for(M.nnz, M.nrows);
+    if (M.Aj16 && M.i16_rpb == a.rows_per_wg) { a.Aj16 = M.Aj16; a.wg_base = M.wg_base; a.wg_flag = M.wg_flag; }
     return a;
 }
 
@@ -934,10 +971,12 @@ int amg_hier_set_matrix(amg_hier *h, int lvl, int which, int fmt, int nrows, int
             AMG_HIP(hipMemcpy(hp.data(), Ap, sizeof(int) * hp.size(), hipMemcpyDeviceToHost));
             if (last) AMG_HIP(hipMemcpy(hj.data(), Aj, sizeof(int) * hj.size(), hipMemcpyDeviceToHost));
             CHK(try_patterns(M, hp.data(), hj.data(), &h->dev_bytes));
+            CHK(build_index16(M, hp.data(), &h->dev_bytes));
         }
     } else if (fmt == AMG_FMT_CSR || (R == 1 && C == 1)) {
         CHK(upload_csr(M, nrows, ncols, Ap, Aj, Ax, &h->dev_bytes));
         if (which == AMG_MAT_A) CHK(try_patterns(M, Ap, Aj, &h->dev_bytes));
+        CHK(build_index16(M, Ap, &h->dev_bytes));
     } else {
         std::vector<int> cp, cj;
         std::vector<double> cx;
@@ -1391,7 +1430,10 @@ static double bytes_spmv_moved(const DevCsr &M)
     if (M.st_vals && stencil_enabled())     // padded values + one mask word per row; no row pointer
         return 8.0 * (double)M.st_nu * 256.0 * (double)((M.nrows + 255) / 256) + (M.st_nu <= 7 ? 1.0 : 4.0) * M.nrows +
                8.0 * M.ncols + 8.0 * M.nrows;
-    if (!M.pat) return bytes_spmv(M);
+    if (!M.pat) {
+        double idx = (M.Aj16 && index16_enabled()) ? (2.0 * M.i16_frac + 4.0 * (1.0 - M.i16_frac)) : 4.0;
+        return (8.0 + idx) * (double)M.nnz + 4.0 * (M.nrows + 1.0) + 8.0 * M.ncols + 8.0 * M.nrows;
+    }
     return 8.0 * (double)M.nnz + 4.0 * M.nrows + 4.0 * (M.nrows + 1.0) + 8.0 * M.ncols + 8.0 * M.nrows;
 }
 
@@ -1466,7 +1508,7 @@ int amg_hier_time_spmv(amg_hier *h, int lvl, int which, int mode, int reps, doub
     else { in = L.r; out = h->lv[lvl + 1].b; }
     StreamMode sm = ((mode & 1) && which == AMG_MAT_A) ? SM_RESIDUAL : SM_MATVEC;
     DevCsr Mplain = M;                     // mode bit 1 (value 2): time the plain CSR kernel even if
-    if (mode & 2) { Mplain.pat = nullptr; Mplain.st_vals = nullptr; }   // the operator has derived forms;
+    if (mode & 2) { Mplain.pat = nullptr; Mplain.st_vals = nullptr; Mplain.Aj16 = nullptr; }   // the operator has derived forms;
     if (mode & 4) Mplain.st_vals = nullptr;                             // bit 2 (value 4): the pattern kernel
     const DevCsr &Mu = (mode & 6) ? Mplain : M;
     CHK(spmv(Mu, sm, in, L.b, nullptr, out, nullptr, 0.0, h->stream));   // warm-up
@@ -1604,6 +1646,7 @@ void amg_set_stream_variant(int v) { amg::set_stream_variant(v); }
 void amg_set_xcd_chunk(int c) { amg::set_xcd_chunk(c); }
 void amg_set_xcd_period(int on) { amg::set_xcd_period(on); }
 void amg_set_stencil_form(int on) { amg::set_stencil_form(on); }
+void amg_set_index16(int on) { amg::set_index16(on); }
 void amg_set_tile_target(int t) { amg::set_tile_target(t); }
 void amg_hier_use_graphs(amg_hier *h, int on) { if (h) { h->use_graphs = on; if (!on) drop_graphs(h); } }
 void amg_hier_keep_residual(amg_hier *h, int on) { if (h) { h->keep_residual = on; h->r_kept = false; drop_graphs(h); } }

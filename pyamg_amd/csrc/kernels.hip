@@ -134,6 +134,15 @@ __global__ __launch_bounds__(WG) void csr_stream_kernel(StreamArgs a, int xcd_ch
 
     for (int i = t; i <= nr; i += WG) sAp[i] = a.Ap[r0 + i];
     if (MT::jac) sdiag[t] = 0.0;
+    // 16-bit column codes: the launcher passes Aj16 only when this launch's row blocks are the
+    // ones the coding was built for (r0 is then a multiple of rpb)
+    __shared__ int sbase[16];
+    bool use16 = false;
+    if (VEC && a.Aj16) {
+        const int wg = r0 / rpb;
+        use16 = a.wg_flag[wg] != 0;
+        if (use16 && t < 16) sbase[t] = a.wg_base[wg * 16 + t];
+    }
     __syncthreads();
 
     const int kbeg = sAp[0], kend = sAp[nr];
@@ -175,7 +184,13 @@ __global__ __launch_bounds__(WG) void csr_stream_kernel(StreamArgs a, int xcd_ch
                 any[p] = e[p] < tile_hi;
                 full[p] = any[p] && ((long)e[p] + 4 <= nnz_total);
                 if (full[p]) {
-                    cj[p] = load_v4i(a.Aj + e[p]);
+                    if (use16) {
+                        // 4 codes in 8 bytes, decoded after all loads of the tile have been issued
+                        const uint2 cc = *reinterpret_cast<const uint2 *>(a.Aj16 + e[p]);
+                        cj[p] = v4i{(int)cc.x, (int)cc.y, 0, 0};
+                    } else {
+                        cj[p] = load_v4i(a.Aj + e[p]);
+                    }
                     av[p][0] = load_v2d(a.Ax + e[p]);
                     av[p][1] = load_v2d(a.Ax + e[p] + 2);
                 } else if (any[p]) {
@@ -183,7 +198,7 @@ __global__ __launch_bounds__(WG) void csr_stream_kernel(StreamArgs a, int xcd_ch
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         bool ok = (long)e[p] + u < nnz_total;
-                        c[u] = ok ? a.Aj[e[p] + u] : 0;
+                        c[u] = ok ? a.Aj[e[p] + u] : 0;            // the last quad of the array: plain indices
                         v[u] = ok ? a.Ax[e[p] + u] : 0.0;
                     }
                     cj[p] = v4i{c[0], c[1], c[2], c[3]};
@@ -195,6 +210,17 @@ __global__ __launch_bounds__(WG) void csr_stream_kernel(StreamArgs a, int xcd_ch
             for (int p = 0; p < NQ; ++p) {
                 if (!any[p]) continue;
                 int c[4] = {cj[p].x, cj[p].y, cj[p].z, cj[p].w};
+                if (use16 && full[p]) {
+                    // entries of the neighbouring row blocks that share the first / last quad carry
+                    // THEIR blocks' codes: give them column 0 (their products are never summed)
+                    const unsigned cx = (unsigned)cj[p].x, cy = (unsigned)cj[p].y;
+                    const unsigned code[4] = {cx & 0xFFFFu, cx >> 16, cy & 0xFFFFu, cy >> 16};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int k = e[p] + u;
+                        c[u] = (k >= kbeg && k < kend) ? sbase[code[u] >> 12] + (int)(code[u] & 4095u) : 0;
+                    }
+                }
                 double v[4] = {av[p][0].x, av[p][0].y, av[p][1].x, av[p][1].y};
                 double xv[4];
 #pragma unroll
@@ -811,6 +837,58 @@ int launch_stencil(StreamMode mode, const StreamArgs &a, const DevCsr &M, hipStr
     return -1;
 }
 
+// 16-bit column codes (DevCsr::Aj16): one workgroup per row block of the stream kernel
+__global__ __launch_bounds__(WG) void index16_build_kernel(int nrows, int rpb, const int *Ap, const int *Aj,
+                                                          unsigned short *Aj16, int *wg_base, unsigned char *wg_flag)
+{
+    __shared__ int sset[16];
+    __shared__ int sover;
+    const int t = threadIdx.x, wg = blockIdx.x;
+    const int r0 = wg * rpb;
+    const int nr = min(rpb, nrows - r0);
+    const int kbeg = Ap[r0], kend = Ap[r0 + nr];
+    if (t < 16) sset[t] = -1;
+    if (t == 0) sover = 0;
+    __syncthreads();
+    for (int k = kbeg + t; k < kend; k += WG) {
+        const int w = Aj[k] >> 12;
+        bool placed = false;
+        for (int s = 0; s < 16 && !placed; ++s) {
+            int cur = atomicCAS(&sset[s], -1, w);          // claims an empty slot, else returns its window
+            placed = (cur == -1 || cur == w);
+        }
+        if (!placed) sover = 1;
+    }
+    __syncthreads();
+    if (sover) {
+        if (t == 0) wg_flag[wg] = 0;
+        return;
+    }
+    for (int k = kbeg + t; k < kend; k += WG) {
+        const int c = Aj[k], w = c >> 12;
+        int slot = 0;
+        for (int s = 0; s < 16; ++s) if (sset[s] == w) slot = s;
+        Aj16[k] = (unsigned short)((slot << 12) | (c & 4095));
+    }
+    if (t < 16) wg_base[wg * 16 + t] = sset[t] >= 0 ? (sset[t] << 12) : 0;
+    if (t == 0) wg_flag[wg] = 1;
+}
+
+static int g_index16 = 0;   // opt-in: measured -6 % on R_0, -1 % on A_1, +8 % on P_0 at 500^3
+void set_index16(int on) { g_index16 = on; }
+bool index16_enabled() { return g_index16 != 0; }
+
+int launch_index16_build(DevCsr &M, int rpb, hipStream_t st)
+{
+    const int nwg = (M.nrows + rpb - 1) / rpb;
+    if (nwg <= 0) return 0;
+    hipLaunchKernelGGL(index16_build_kernel, dim3(nwg), dim3(WG), 0, st, M.nrows, rpb, M.Ap, M.Aj, M.Aj16, M.wg_base,
+                       M.wg_flag);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "index16 build launch", __FILE__, __LINE__);
+    return 0;
+}
+
 template <int MODE>
 static int launch_stream_mode(const StreamArgs &a, hipStream_t st)
 {
@@ -821,6 +899,7 @@ static int launch_stream_mode(const StreamArgs &a, hipStream_t st)
     int nb = (rows + rpb - 1) / rpb;
     StreamArgs b = a;
     if (b.gscale == 0.0) b.gscale = 1.0;
+    if (!g_index16 || (a.row_lo % rpb) != 0) b.Aj16 = nullptr;     // row blocks must be the coded ones
     if (g_stream_variant)
         hipLaunchKernelGGL((csr_stream_kernel<MODE, 1>), dim3(nb), dim3(WG), 0, st, b, g_xcd_chunk, rpb);
     else

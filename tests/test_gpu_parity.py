@@ -596,3 +596,81 @@ def test_device_resident_operator_source_and_device_vectors():
     assert nres.value == 5
     assert np.array_equal(tx.cpu().numpy(), x_ref)
     assert np.allclose(out[:5], res, rtol=1e-13)
+
+
+def test_index16_column_codes_are_lossless():
+    """Irregular operators keep 16-bit column codes (16 windows of 4096 columns per row block) next to
+    their 32-bit indices.  The stream kernel must give the same bits from either, for every epilogue
+    the cycle uses, on: a matrix whose row blocks all fit, one where some blocks need more than 16
+    windows (mixed, flag per block), row-range launches that are / are not aligned with the coded
+    blocks, and a real hierarchy's A_1 / P_0 / R_0."""
+    import scipy.sparse as sp
+    import torch
+    from pyamg_amd import _lib
+    from pyamg_amd.distributed import HipBackend
+    be = HipBackend(0)
+    _lib.lib().amg_set_index16(1)               # opt-in: codes are built for operators uploaded from now on
+    rng = np.random.RandomState(3)
+    n, m = 40000, 90000
+
+    def banded(spread):
+        rows = np.repeat(np.arange(n), 12)
+        centre = (rows * (m / n)).astype(np.int64)
+        cols = centre + rng.randint(-spread, spread, size=len(rows))
+        cols = np.clip(cols, 0, m - 1)
+        M = sp.csr_matrix((rng.rand(len(rows)) - 0.5, (rows, cols)), shape=(n, m))
+        M.sum_duplicates()
+        return M
+
+    narrow = banded(3000)                                   # every block fits
+    wide = banded(3000).tolil()
+    for i in range(0, n, 997):                              # a scattered row every ~1000: its block falls back
+        wide[i, rng.randint(0, m, size=40)] = 1.0
+    wide = sp.csr_matrix(wide)
+    for M in (narrow, wide):
+        M.sort_indices()
+        hm = be.mat(M.shape[0], M.shape[1], M.indptr, M.indices, M.data)
+        x = torch.from_numpy(rng.rand(m)).cuda()
+        b = torch.from_numpy(rng.rand(n)).cuda()
+        out = {}
+        for on in (1, 0):
+            _lib.lib().amg_set_index16(on)
+            y = torch.zeros(n, dtype=torch.float64, device="cuda")
+            be.apply(hm, 0, x, None, None, y, None, 0.0)                       # y = M x
+            r = torch.zeros(n, dtype=torch.float64, device="cuda")
+            be.apply(hm, 2, x, b, None, r, None, 0.0)                          # r = b - M x
+            z = torch.zeros(n, dtype=torch.float64, device="cuda")
+            be.apply_rows(hm, 0, 4096, 30001, x, None, None, z, None, 0.0)     # aligned start
+            be.apply_rows(hm, 0, 1, 4096, x, None, None, z, None, 0.0)         # unaligned start
+            torch.cuda.synchronize()
+            out[on] = (y.cpu().numpy(), r.cpu().numpy(), z.cpu().numpy())
+        _lib.lib().amg_set_index16(1)
+        ref = M * x.cpu().numpy()
+        assert np.array_equal(out[1][0], ref) and np.array_equal(out[0][0], ref)
+        assert np.array_equal(out[1][1], out[0][1])
+        assert np.array_equal(out[1][2][1:30001], ref[1:30001]) and np.array_equal(out[0][2], out[1][2])
+    be.close()
+
+    from pyamg_amd.aggregation import poisson as native, smoothed_aggregation_solver
+    A = native((64, 63, 62))
+    np.random.seed(0)
+    sm = ("jacobi", {"omega": 4.0 / 3.0})
+    ml = smoothed_aggregation_solver(A, presmoother=sm, postsmoother=sm)
+    dev = ml.device_hierarchy()
+    for lvl, which, M in ((1, 0, ml.levels[1].A), (0, 1, ml.levels[0].P), (0, 2, ml.levels[0].R)):
+        v = rng.rand(M.shape[1])
+        for on in (1, 0):
+            _lib.lib().amg_set_index16(on)
+            assert np.array_equal(dev.matvec(lvl, which, v), M * v), (lvl, which, on)
+    _lib.lib().amg_set_index16(1)
+    moved_on = dev.cycle_bytes_moved("V")
+    _lib.lib().amg_set_index16(0)
+    assert moved_on < dev.cycle_bytes_moved("V")           # the codes exist and are accounted for
+    b = rng.rand(A.shape[0])
+    got = {}
+    for on in (1, 0):
+        _lib.lib().amg_set_index16(on)
+        res = []
+        got[on] = (ml.solve(b, tol=0.0, maxiter=3, residuals=res), np.array(res))
+    _lib.lib().amg_set_index16(0)               # back to the default
+    assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1])
