@@ -76,6 +76,15 @@ int amgcore_jacobi_ne_f64(const int Ap[], int Ap_size, const int Aj[], int Aj_si
                           double temp[], int temp_size,
                           int row_start, int row_stop, int row_step,
                           const double omega[], int omega_size);
+/* relaxation.h:935-1007, relaxation.py:272-277: one sweep of multiplicative overlapping Schwarz over
+ * the subdomains row_start, row_start+row_step, ... (Sj/Sp sorted index lists, Tx/Tp their inverted
+ * diagonal blocks, row-major) */
+int amgcore_overlapping_schwarz_csr_f64(const int Ap[], int Ap_size, const int Aj[], int Aj_size,
+                                        const double Ax[], int Ax_size, double x[], int x_size,
+                                        const double b[], int b_size, const double Tx[], int Tx_size,
+                                        const int Tp[], int Tp_size, const int Sj[], int Sj_size,
+                                        const int Sp[], int Sp_size, int nsdomains, int nrows,
+                                        int row_start, int row_stop, int row_step);
 /* relaxation.h:529-561, relaxation.py:907 */
 int amgcore_gauss_seidel_ne_f64(const int Ap[], int Ap_size, const int Aj[], int Aj_size,
                                 const double Ax[], int Ax_size, double x[], int x_size,

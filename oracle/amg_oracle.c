@@ -330,6 +330,64 @@ void oracle_block_gauss_seidel(const int *Ap, const int *Aj, const double *Ax, d
     free(rsum);
 }
 
+/* pyamg/amg_core/relaxation.h:836-899 (helper of the Schwarz relaxation): dense diagonal block of A
+ * for every subdomain, row-major, rows and columns in the subdomain's (sorted) index order.  Both
+ * the row of A and the subdomain are sorted, so one merge per row finds the common columns. */
+void oracle_extract_subblocks(const int *Ap, const int *Aj, const double *Ax, double *Tx,
+                              const int *Tp, const int *Sj, const int *Sp, int nsdomains, int nrows)
+{
+    (void)nrows;
+    for (int k = 0; k < Tp[nsdomains]; k++) Tx[k] = 0.0;
+    for (int d = 0; d < nsdomains; d++) {
+        int m = Sp[d + 1] - Sp[d];
+        const int *S = Sj + Sp[d];
+        for (int li = 0; li < m; li++) {
+            int row = S[li];
+            double *Trow = Tx + Tp[d] + (long)li * m;
+            int lc = 0;
+            for (int k = Ap[row]; k < Ap[row + 1] && lc < m; k++) {
+                int col = Aj[k];
+                while (lc < m && S[lc] < col) lc++;
+                if (lc < m && S[lc] == col) { Trow[lc] = Ax[k]; lc++; }
+            }
+        }
+    }
+}
+
+/* pyamg/amg_core/relaxation.h:935-1007: multiplicative overlapping Schwarz, subdomains visited as
+ * for(d = row_start; d != row_stop; d += row_step).  Per subdomain: r_c = 0 - sum_jj Ax*x (left to
+ * right), then + b[row]; delta = Tx_d * r with each entry summed from 0.0 left to right (gemm,
+ * linalg.h:396-419); x[S] += delta. */
+void oracle_overlapping_schwarz_csr(const int *Ap, const int *Aj, const double *Ax, double *x,
+                                    const double *b, const double *Tx, const int *Tp, const int *Sj,
+                                    const int *Sp, int nsdomains, int nrows, int row_start,
+                                    int row_stop, int row_step)
+{
+    (void)nsdomains;
+    double *r = (double *)malloc(sizeof(double) * (size_t)(nrows > 0 ? nrows : 1));
+    double *delta = (double *)malloc(sizeof(double) * (size_t)(nrows > 0 ? nrows : 1));
+    for (int d = row_start; d != row_stop; d += row_step) {
+        int m = Sp[d + 1] - Sp[d];
+        const int *S = Sj + Sp[d];
+        for (int c = 0; c < m; c++) {
+            int row = S[c];
+            double acc = 0.0;
+            for (int jj = Ap[row]; jj < Ap[row + 1]; jj++) acc -= Ax[jj] * x[Aj[jj]];
+            acc += b[row];
+            r[c] = acc;
+        }
+        const double *T = Tx + Tp[d];
+        for (int i = 0; i < m; i++) {
+            double acc = 0.0;
+            for (int k = 0; k < m; k++) acc += T[(long)i * m + k] * r[k];
+            delta[i] = acc;
+        }
+        for (int c = 0; c < m; c++) x[S[c]] += delta[c];
+    }
+    free(r);
+    free(delta);
+}
+
 /* ------------------------------------------------------------------------- */
 /* scipy.sparse._sparsetools (third party; scipy 1.15.3 in the image):        */
 /* csr_matvec: per row, sum starts from y[i] and adds Ax[jj]*x[Aj[jj]] left   */

@@ -59,6 +59,13 @@ void oracle_block_gauss_seidel(const int *Ap, const int *Aj, const double *Ax, d
                                int row_stop, int row_step, int blocksize);
 
 /* ---- scipy sparsetools SpMV (third party, restated) ---- */
+void oracle_extract_subblocks(const int *Ap, const int *Aj, const double *Ax, double *Tx,
+                              const int *Tp, const int *Sj, const int *Sp, int nsdomains, int nrows);
+void oracle_overlapping_schwarz_csr(const int *Ap, const int *Aj, const double *Ax, double *x,
+                                    const double *b, const double *Tx, const int *Tp, const int *Sj,
+                                    const int *Sp, int nsdomains, int nrows, int row_start,
+                                    int row_stop, int row_step);
+
 /* threads for the row-parallel loops (results independent of the count); default 1 */
 void oracle_set_threads(int n);
 int oracle_get_threads(void);

@@ -68,6 +68,8 @@ def lib():
         "amgcore_bsr_jacobi_f64": arr + xb + [c_dbl_p, I, I, I, I, I, c_dbl_p, I],
         "amgcore_gauss_seidel_indexed_f64": arr + xb + [c_int_p, I, I, I, I],
         "amgcore_jacobi_ne_f64": arr + xb + [c_dbl_p, I, c_dbl_p, I, I, I, I, c_dbl_p, I],
+        "amgcore_overlapping_schwarz_csr_f64": arr + xb + [c_dbl_p, I, c_int_p, I, c_int_p, I, c_int_p, I,
+                                                           I, I, I, I, I],
         "amgcore_gauss_seidel_ne_f64": arr + xb + [I, I, I, c_dbl_p, I, D],
         "amgcore_gauss_seidel_nr_f64": arr + xb + [I, I, I, c_dbl_p, I, D],
         "amgcore_block_jacobi_f64": arr + xb + [c_dbl_p, I, c_dbl_p, I, I, I, I, c_dbl_p, I, I],

@@ -70,6 +70,8 @@ def host_lib():
         L.amgsetup_smooth_prolongator.restype = C.c_int64
         L.amgsetup_greedy_coloring.argtypes = [C.c_int, ip, ip, ip]
         L.amgsetup_greedy_coloring.restype = C.c_int
+        L.amgsetup_extract_subblocks.argtypes = [ip, ip, dp, dp, ip, ip, ip, C.c_int, C.c_int]
+        L.amgsetup_extract_subblocks.restype = None
         L.amgsetup_num_threads.restype = C.c_int
         L.amgsetup_set_num_threads.argtypes = [C.c_int]
         L.amgsetup_set_num_threads.restype = None

@@ -15,7 +15,7 @@ from . import _lib
 
 __all__ = ["gauss_seidel", "bsr_gauss_seidel", "jacobi", "bsr_jacobi", "gauss_seidel_indexed",
            "jacobi_ne", "gauss_seidel_ne", "gauss_seidel_nr", "block_jacobi", "block_gauss_seidel",
-           "csr_matvec", "bsr_matvec"]
+           "csr_matvec", "bsr_matvec", "overlapping_schwarz_csr", "extract_subblocks"]
 
 
 def _chk(name, a, dtype):
@@ -140,3 +140,26 @@ def bsr_matvec(n_brow, n_bcol, R, C, Ap, Aj, Ax, Xx, Yx):
     Ap, Aj, Ax, Xx, Yx = _I(n, Ap), _I(n, Aj), _D(n, Ax), _D(n, Xx), _D(n, Yx)
     _lib.check(_lib.lib().amgcore_bsr_matvec_f64(int(n_brow), int(n_bcol), int(R), int(C), _lib.ip(Ap),
                                                  _lib.ip(Aj), _lib.dp(Ax), _lib.dp(Xx), _lib.dp(Yx)))
+
+
+def overlapping_schwarz_csr(Ap, Aj, Ax, x, b, Tx, Tp, Sj, Sp, nsdomains, nrows, row_start, row_stop, row_step):
+    """relaxation.h:935-1007: one sweep of multiplicative overlapping Schwarz (HIP, by dependency levels)"""
+    n = "overlapping_schwarz_csr"
+    x, b, Tx = _D(n, x), _D(n, b), _D(n, Tx)
+    Tp, Sj, Sp = _I(n, Tp), _I(n, Sj), _I(n, Sp)
+    _lib.check(_lib.lib().amgcore_overlapping_schwarz_csr_f64(
+        *_csr(n, Ap, Aj, Ax), _lib.dp(x), len(x), _lib.dp(b), len(b), _lib.dp(Tx), len(Tx), _lib.ip(Tp), len(Tp),
+        _lib.ip(Sj), len(Sj), _lib.ip(Sp), len(Sp), int(nsdomains), int(nrows), int(row_start), int(row_stop),
+        int(row_step)))
+
+
+def extract_subblocks(Ap, Aj, Ax, Tx, Tp, Sj, Sp, nsdomains, nrows):
+    """relaxation.h:836-899 (setup helper of the Schwarz smoother; runs on the host)"""
+    from .aggregation import host_lib
+    n = "extract_subblocks"
+    Ap, Aj, Ax, Tx = _I(n, Ap), _I(n, Aj), _D(n, Ax), _D(n, Tx)
+    Tp, Sj, Sp = _I(n, Tp), _I(n, Sj), _I(n, Sp)
+    if len(Sp) < nsdomains + 1 or len(Tp) < nsdomains + 1 or (nsdomains and len(Tx) < Tp[nsdomains]):
+        raise ValueError("extract_subblocks: pointer arrays too short")
+    host_lib().amgsetup_extract_subblocks(_lib.ip(Ap), _lib.ip(Aj), _lib.dp(Ax), _lib.dp(Tx), _lib.ip(Tp),
+                                          _lib.ip(Sj), _lib.ip(Sp), int(nsdomains), int(nrows))

@@ -593,4 +593,32 @@ int amgsetup_num_threads(void)
 #endif
 }
 
+
+// Dense diagonal block of A for every subdomain (sorted index lists Sj[Sp[d]..Sp[d+1])), row-major into
+// Tx[Tp[d]..]: the input of the Schwarz smoother's block inversion (pyamg/amg_core/relaxation.h:836-899).
+// Rows of A and subdomains are both sorted, so a merge per row finds the common columns.
+void amgsetup_extract_subblocks(const int *Ap, const int *Aj, const double *Ax, double *Tx, const int *Tp,
+                                const int *Sj, const int *Sp, int nsdomains, int nrows)
+{
+    (void)nrows;
+    const long total = nsdomains > 0 ? Tp[nsdomains] : 0;
+#pragma omp parallel for schedule(static)
+    for (long k = 0; k < total; ++k) Tx[k] = 0.0;
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int d = 0; d < nsdomains; ++d) {
+        const int m = Sp[d + 1] - Sp[d];
+        const int *S = Sj + Sp[d];
+        for (int li = 0; li < m; ++li) {
+            const int row = S[li];
+            double *Trow = Tx + Tp[d] + (long)li * m;
+            int lc = 0;
+            for (int k = Ap[row]; k < Ap[row + 1] && lc < m; ++k) {
+                const int col = Aj[k];
+                while (lc < m && S[lc] < col) ++lc;
+                if (lc < m && S[lc] == col) { Trow[lc] = Ax[k]; ++lc; }
+            }
+        }
+    }
+}
+
 }  // extern "C"

@@ -18,7 +18,7 @@ from .util import get_block_diag, get_diagonal, type_prep
 
 __all__ = ["sor", "gauss_seidel", "jacobi", "polynomial", "jacobi_ne", "gauss_seidel_ne",
            "gauss_seidel_nr", "gauss_seidel_indexed", "block_jacobi", "block_gauss_seidel",
-           "make_system"]
+           "make_system", "schwarz", "schwarz_parameters"]
 
 
 def make_system(A, x, b, formats=None):
@@ -309,3 +309,79 @@ def gauss_seidel_nr(A, x, b, iterations=1, sweep="forward", omega=1.0, Dinv=None
     for i in range(iterations):
         amg_core.gauss_seidel_nr(Ap, Aj, np.ascontiguousarray(A.data), x, r, col_start, col_stop, col_step,
                                  Dinv, omega)
+
+
+def schwarz(A, x, b, iterations=1, subdomain=None, subdomain_ptr=None, inv_subblock=None,
+            inv_subblock_ptr=None, sweep="forward"):
+    """Overlapping multiplicative Schwarz (relaxation.py:172-278).  Subdomains default to the rows'
+    sparsity patterns; x is modified in place."""
+    A, x, b = make_system(A, x, b, formats=["csr"])
+    if subdomain is None and inv_subblock is not None:
+        raise ValueError("inv_subblock must be None if subdomain is None")
+    (subdomain, subdomain_ptr, inv_subblock, inv_subblock_ptr) = \
+        schwarz_parameters(A, subdomain, subdomain_ptr, inv_subblock, inv_subblock_ptr)
+    nsd = subdomain_ptr.shape[0] - 1
+    if sweep == "forward":
+        row_start, row_stop, row_step = 0, nsd, 1
+    elif sweep == "backward":
+        row_start, row_stop, row_step = nsd - 1, -1, -1
+    elif sweep == "symmetric":
+        for _ in range(iterations):
+            schwarz(A, x, b, iterations=1, subdomain=subdomain, subdomain_ptr=subdomain_ptr,
+                    inv_subblock=inv_subblock, inv_subblock_ptr=inv_subblock_ptr, sweep="forward")
+            schwarz(A, x, b, iterations=1, subdomain=subdomain, subdomain_ptr=subdomain_ptr,
+                    inv_subblock=inv_subblock, inv_subblock_ptr=inv_subblock_ptr, sweep="backward")
+        return
+    else:
+        raise ValueError("valid sweep directions are 'forward', 'backward', and 'symmetric'")
+    Ap, Aj = _ptr(A)
+    b = _bvec(b)
+    Ax = np.ascontiguousarray(A.data)
+    for _ in range(iterations):
+        amg_core.overlapping_schwarz_csr(Ap, Aj, Ax, x, b, inv_subblock, inv_subblock_ptr, subdomain,
+                                         subdomain_ptr, nsd, A.shape[0], row_start, row_stop, row_step)
+
+
+def schwarz_parameters(A, subdomain=None, subdomain_ptr=None, inv_subblock=None, inv_subblock_ptr=None):
+    """relaxation.py:1011-1083: subdomains (default: A's sparsity pattern) and the pseudo-inverses of
+    their diagonal blocks, cached on A as ``A.schwarz_parameters``.  The reference inverts block by
+    block with LAPACK gelss (cond = eps*1e6); here the blocks of equal size are inverted together
+    with numpy's batched SVD pseudo-inverse and the same cut-off."""
+    if hasattr(A, "schwarz_parameters"):
+        if subdomain is not None and subdomain_ptr is not None:
+            if np.array(A.schwarz_parameters[0] == subdomain).all() and \
+               np.array(A.schwarz_parameters[1] == subdomain_ptr).all():
+                return A.schwarz_parameters
+        else:
+            return A.schwarz_parameters
+    if subdomain is None or subdomain_ptr is None:
+        subdomain_ptr = A.indptr.copy()
+        subdomain = A.indices.copy()
+    subdomain = np.ascontiguousarray(subdomain, dtype=np.intc)
+    subdomain_ptr = np.ascontiguousarray(subdomain_ptr, dtype=np.intc)
+    if inv_subblock is None or inv_subblock_ptr is None:
+        nsd = subdomain_ptr.shape[0] - 1
+        blocksize = (subdomain_ptr[1:] - subdomain_ptr[:-1]).astype(np.int64)
+        ptr64 = np.zeros(nsd + 1, dtype=np.int64)
+        ptr64[1:] = np.cumsum(blocksize * blocksize)
+        if ptr64[-1] > np.iinfo(np.intc).max:
+            raise ValueError("subdomain blocks need more than 2^31-1 entries")
+        inv_subblock_ptr = ptr64.astype(np.intc)
+        inv_subblock = np.zeros((int(ptr64[-1]),), dtype=np.float64)
+        Ap, Aj = _ptr(A)
+        amg_core.extract_subblocks(Ap, Aj, np.ascontiguousarray(A.data, dtype=np.float64), inv_subblock,
+                                   inv_subblock_ptr, subdomain, subdomain_ptr, nsd, A.shape[0])
+        cond = np.finfo(np.float64).eps * 1e6
+        for m in np.unique(blocksize):
+            m = int(m)
+            if m == 0:
+                continue
+            which = np.nonzero(blocksize == m)[0]
+            idx = ptr64[which][:, None] + np.arange(m * m)[None, :]
+            blocks = inv_subblock[idx].reshape(len(which), m, m)
+            inv_subblock[idx] = np.linalg.pinv(blocks, rcond=cond).reshape(len(which), m * m)
+    else:
+        inv_subblock = np.ascontiguousarray(inv_subblock, dtype=np.float64)
+        inv_subblock_ptr = np.ascontiguousarray(inv_subblock_ptr, dtype=np.intc)
+    A.schwarz_parameters = (subdomain, subdomain_ptr, inv_subblock, inv_subblock_ptr)
+    return A.schwarz_parameters

@@ -234,6 +234,30 @@ def setup_gauss_seidel_nr(lvl, iterations=1, sweep="forward", omega=1.0):
     return smoother
 
 
+def setup_schwarz(lvl, iterations=1, subdomain=None, subdomain_ptr=None, inv_subblock=None,
+                  inv_subblock_ptr=None, sweep="symmetric"):
+    """smoothing.py:335-348"""
+    Acsr = lvl.A.tocsr()
+    Acsr.sort_indices()
+    lvl.Acsr = Acsr
+    subdomain, subdomain_ptr, inv_subblock, inv_subblock_ptr = \
+        relaxation.schwarz_parameters(Acsr, subdomain, subdomain_ptr, inv_subblock, inv_subblock_ptr)
+
+    def smoother(A, x, b):
+        relaxation.schwarz(Acsr, x, b, iterations=iterations, subdomain=subdomain, subdomain_ptr=subdomain_ptr,
+                           inv_subblock=inv_subblock, inv_subblock_ptr=inv_subblock_ptr, sweep=sweep)
+    return _with_desc(smoother, name="schwarz", iterations=iterations, sweep=sweep, subdomain=subdomain,
+                      subdomain_ptr=subdomain_ptr, inv_subblock=inv_subblock, inv_subblock_ptr=inv_subblock_ptr)
+
+
+def setup_strength_based_schwarz(lvl, iterations=1, sweep="symmetric"):
+    """smoothing.py:351-363: subdomains from the strength-of-connection matrix of the level"""
+    Cm = lvl.C.tocsr() if hasattr(lvl, "C") else lvl.A.tocsr()
+    Cm.sort_indices()
+    return setup_schwarz(lvl, iterations=iterations, subdomain=Cm.indices.copy(),
+                         subdomain_ptr=Cm.indptr.copy(), sweep=sweep)
+
+
 def setup_None(lvl):
     def smoother(A, x, b):
         pass

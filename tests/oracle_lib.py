@@ -71,6 +71,9 @@ def load():
         "oracle_gauss_seidel_nr": [c_int_p, c_int_p, c_dbl_p, c_dbl_p, c_dbl_p, I, I, I, c_dbl_p, D],
         "oracle_block_jacobi": [c_int_p, c_int_p, c_dbl_p, c_dbl_p, c_dbl_p, c_dbl_p, c_dbl_p, I, I, I, c_dbl_p, I],
         "oracle_block_gauss_seidel": [c_int_p, c_int_p, c_dbl_p, c_dbl_p, c_dbl_p, c_dbl_p, I, I, I, I],
+        "oracle_extract_subblocks": [c_int_p, c_int_p, c_dbl_p, c_dbl_p, c_int_p, c_int_p, c_int_p, I, I],
+        "oracle_overlapping_schwarz_csr": [c_int_p, c_int_p, c_dbl_p, c_dbl_p, c_dbl_p, c_dbl_p, c_int_p, c_int_p,
+                                           c_int_p, I, I, I, I, I],
         "oracle_csr_matvec": [I, c_int_p, c_int_p, c_dbl_p, c_dbl_p, c_dbl_p],
         "oracle_bsr_matvec": [I, I, I, c_int_p, c_int_p, c_dbl_p, c_dbl_p, c_dbl_p],
         "oracle_hier_destroy": [C.c_void_p],
