@@ -135,7 +135,7 @@ enum { AMG_SWEEP_FORWARD = 0, AMG_SWEEP_BACKWARD = 1, AMG_SWEEP_SYMMETRIC = 2 };
 /* smoother kinds = the relaxation.py entry points a smoothing.py closure calls */
 enum { AMG_SM_NONE = 0, AMG_SM_JACOBI = 1, AMG_SM_GAUSS_SEIDEL = 2, AMG_SM_SOR = 3,
        AMG_SM_POLYNOMIAL = 4, AMG_SM_BLOCK_JACOBI = 5, AMG_SM_BLOCK_GAUSS_SEIDEL = 6,
-       AMG_SM_GAUSS_SEIDEL_INDEXED = 7 };
+       AMG_SM_GAUSS_SEIDEL_INDEXED = 7, AMG_SM_SCHWARZ = 8 };
 
 typedef struct {
     int kind;            /* AMG_SM_* */
@@ -148,6 +148,12 @@ typedef struct {
     const double *Dinv;  /* host pointer, (n/bs)*bs*bs row-major inverse diagonal blocks, copied */
     const int *indices;  /* gauss_seidel_indexed: row order (host pointer, copied) */
     int nindices;
+    /* schwarz (relaxation.py:172-278; level A must be CSR or BSR(1,1)): sorted subdomain index lists
+     * Sj[Sp[d]..Sp[d+1]) and their inverted diagonal blocks Tx[Tp[d]..Tp[d+1]), row-major
+     * (relaxation.schwarz_parameters); host pointers, copied */
+    const int *Sj, *Sp, *Tp;
+    const double *Tx;
+    int nsdomains;
 } amg_smoother_desc;
 
 /* flags for amg_hier_solve */

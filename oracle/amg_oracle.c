@@ -748,6 +748,20 @@ static void relax_jacobi_ne(const oracle_mat *A, const oracle_smoother *s, doubl
 }
 
 /* dispatch of a smoother closure built by pyamg/relaxation/smoothing.py:320-515 */
+/* pyamg/relaxation/relaxation.py:254-277 */
+static void relax_schwarz(const oracle_mat *A, const oracle_smoother *s, double *x, const double *b)
+{
+    int nsd = s->nsdomains, n = A->nrows;
+    for (int it = 0; it < s->iterations; it++) {
+        if (s->sweep == ORACLE_SWEEP_FORWARD || s->sweep == ORACLE_SWEEP_SYMMETRIC)
+            oracle_overlapping_schwarz_csr(A->Ap, A->Aj, A->Ax, x, b, s->Tx, s->Tp, s->Sj, s->Sp, nsd, n,
+                                           0, nsd, 1);
+        if (s->sweep == ORACLE_SWEEP_BACKWARD || s->sweep == ORACLE_SWEEP_SYMMETRIC)
+            oracle_overlapping_schwarz_csr(A->Ap, A->Aj, A->Ax, x, b, s->Tx, s->Tp, s->Sj, s->Sp, nsd, n,
+                                           nsd - 1, -1, -1);
+    }
+}
+
 void oracle_relax(const oracle_mat *A, const oracle_smoother *s, double *x, const double *b)
 {
     switch (s->kind) {
@@ -768,6 +782,7 @@ void oracle_relax(const oracle_mat *A, const oracle_smoother *s, double *x, cons
         break;
     case ORACLE_SM_GAUSS_SEIDEL_NR: relax_gs_nr(A, s->Aalt, s, x, b, s->iterations, s->sweep); break;
     case ORACLE_SM_JACOBI_NE: relax_jacobi_ne(s->Aalt ? s->Aalt : A, s, x, b); break;
+    case ORACLE_SM_SCHWARZ: relax_schwarz(s->Aalt ? s->Aalt : A, s, x, b); break;
     default: abort();
     }
 }

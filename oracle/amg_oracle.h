@@ -83,7 +83,7 @@ enum { ORACLE_FMT_CSR = 0, ORACLE_FMT_BSR = 1 };
 enum { ORACLE_SM_NONE = 0, ORACLE_SM_JACOBI = 1, ORACLE_SM_GAUSS_SEIDEL = 2, ORACLE_SM_SOR = 3,
        ORACLE_SM_POLYNOMIAL = 4, ORACLE_SM_BLOCK_JACOBI = 5, ORACLE_SM_BLOCK_GAUSS_SEIDEL = 6,
        ORACLE_SM_GAUSS_SEIDEL_INDEXED = 7, ORACLE_SM_GAUSS_SEIDEL_NE = 8,
-       ORACLE_SM_GAUSS_SEIDEL_NR = 9, ORACLE_SM_JACOBI_NE = 10 };
+       ORACLE_SM_GAUSS_SEIDEL_NR = 9, ORACLE_SM_JACOBI_NE = 10, ORACLE_SM_SCHWARZ = 11 };
 enum { ORACLE_SWEEP_FORWARD = 0, ORACLE_SWEEP_BACKWARD = 1, ORACLE_SWEEP_SYMMETRIC = 2 };
 enum { ORACLE_CYCLE_V = 0, ORACLE_CYCLE_W = 1, ORACLE_CYCLE_F = 2, ORACLE_CYCLE_AMLI = 3 };
 
@@ -109,6 +109,11 @@ typedef struct {
     /* block smoothers / ne / nr act on a re-formatted copy of A, as the
      * reference does with A.tobsr(bs) / lvl.Acsr / lvl.Acsc */
     const oracle_mat *Aalt;
+    /* schwarz (relaxation.py:172-278): sorted subdomain index lists and their inverted diagonal
+     * blocks (row-major); acts on lvl.Acsr = Aalt when A is not CSR */
+    const int *Sj, *Sp, *Tp;
+    const double *Tx;
+    int nsdomains;
 } oracle_smoother;
 
 typedef struct oracle_hier oracle_hier;

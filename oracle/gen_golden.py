@@ -249,6 +249,13 @@ def smoother_desc(out, key, spec, fn, lvl):
     if "Dinv" in cv and cv["Dinv"] is not None:
         out[key + "_Dinv"] = np.ravel(np.asarray(cv["Dinv"], dtype=np.float64)).copy()
         d["has_Dinv"] = True
+    if str(name) in ("schwarz", "strength_based_schwarz"):
+        # smoothing.py:335-348: subdomains and their inverted diagonal blocks
+        d["name"] = "schwarz"
+        for k in ("subdomain", "subdomain_ptr", "inv_subblock_ptr"):
+            out[key + "_" + k] = np.asarray(cv[k], dtype=np.intc).copy()
+        out[key + "_inv_subblock"] = np.asarray(cv["inv_subblock"], dtype=np.float64).copy()
+        d["has_schwarz"] = True
     return d
 
 

@@ -71,6 +71,17 @@ def main():
     rec("schwarz_docstring", Ap=A.indptr, Aj=A.indices, Ax=A.data, x=np.ravel(x), resnorm=[norm(b - A * x)])
     out["cases"] = np.array(cases)
     np.savez_compressed(os.path.join(OUT, "schwarz.npz"), **out)
+    # whole hierarchies smoothed by Schwarz (the docstring's configuration, relaxation.py:233-241, on a
+    # larger grid; and strength-based subdomains with a forward pre- / backward post-sweep)
+    from gen_golden import gen_hier
+    P = ref_env.poisson
+    gen_hier(pyamg, "sa_schwarz_2d", P((24, 24)),
+             lambda A, **kw: pyamg.smoothed_aggregation_solver(A, B=np.ones((A.shape[0], 1)), max_coarse=50, **kw),
+             "schwarz", "schwarz", dict(tol=1e-8))
+    gen_hier(pyamg, "sa_sbschwarz_3d", P((9, 9, 9)),
+             lambda A, **kw: pyamg.smoothed_aggregation_solver(A, max_coarse=20, **kw),
+             ("strength_based_schwarz", {"sweep": "forward", "iterations": 2}),
+             ("strength_based_schwarz", {"sweep": "backward"}), dict(tol=1e-9))
     print("schwarz.npz: %d cases; docstring residual %.12f" % (len(cases), norm(b - A * x)))
 
 

@@ -30,7 +30,8 @@ class SmootherDesc(C.Structure):
     _fields_ = [("kind", C.c_int), ("iterations", C.c_int), ("sweep", C.c_int),
                 ("omega", C.c_double), ("ncoef", C.c_int), ("coef", c_dbl_p),
                 ("blocksize", C.c_int), ("Dinv", c_dbl_p), ("indices", c_int_p),
-                ("nindices", C.c_int)]
+                ("nindices", C.c_int),
+                ("Sj", c_int_p), ("Sp", c_int_p), ("Tp", c_int_p), ("Tx", c_dbl_p), ("nsdomains", C.c_int)]
 
 
 def build_library():

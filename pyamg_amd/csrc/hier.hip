@@ -632,6 +632,24 @@ static int relax(amg_hier *h, Level &L, Smoother &s, double *&x, double *&xalt, 
         }
         return 0;
     }
+    case AMG_SM_SCHWARZ: {
+        // relaxation.py:254-277: subdomains by dependency levels; descending levels = backward sweep
+        const std::vector<int> &lp = s.sw_level_ptr;
+        const int nl = (int)lp.size() - 1;
+        auto sweep_once = [&](bool reverse) -> int {
+            for (int q = 0; q < nl; ++q) {
+                const int l = reverse ? nl - 1 - q : q;
+                CHK(launch_schwarz_level(L.A.Ap, L.A.Aj, L.A.Ax, x, b, s.sw_Tx, s.sw_Tp, s.sw_Sj, s.sw_Sp,
+                                         s.sw_scratch, s.sw_order + lp[l], lp[l + 1] - lp[l], st));
+            }
+            return 0;
+        };
+        for (int it = 0; it < s.iterations; ++it) {
+            if (s.sweep == AMG_SWEEP_FORWARD || s.sweep == AMG_SWEEP_SYMMETRIC) CHK(sweep_once(false));
+            if (s.sweep == AMG_SWEEP_BACKWARD || s.sweep == AMG_SWEEP_SYMMETRIC) CHK(sweep_once(true));
+        }
+        return 0;
+    }
     case AMG_SM_BLOCK_JACOBI: {
         // relaxation.py:430-506
         const DevBsr &Ab = s.Ablk_owned ? s.Ablk : L.Ab;
@@ -900,6 +918,14 @@ amg_hier *amg_hier_create(int nlevels, int device)
 
 static void free_smoother(Smoother &s)
 {
+    if (s.sw_Sj) hipFree(s.sw_Sj);
+    if (s.sw_Sp) hipFree(s.sw_Sp);
+    if (s.sw_Tp) hipFree(s.sw_Tp);
+    if (s.sw_order) hipFree(s.sw_order);
+    if (s.sw_Tx) hipFree(s.sw_Tx);
+    if (s.sw_scratch) hipFree(s.sw_scratch);
+    s.sw_Sj = s.sw_Sp = s.sw_Tp = s.sw_order = nullptr;
+    s.sw_Tx = s.sw_scratch = nullptr;
     if (s.Dinv) hipFree(s.Dinv);
     s.Dinv = nullptr;
     if (s.Ablk_owned) free_bsr(s.Ablk);
@@ -1022,6 +1048,30 @@ static int fill_smoother(amg_hier *h, Smoother &s, const amg_smoother_desc *d, i
         if (d->nindices < 0 || (d->nindices && !d->indices)) { set_error("indexed GS needs indices"); return AMG_EINVAL; }
         s.indices.assign(d->indices, d->indices + d->nindices);
     }
+    if (d->kind == AMG_SM_SCHWARZ) {
+        const int nsd = d->nsdomains;
+        if (nsd < 0 || !d->Sp || !d->Tp || (nsd && (!d->Sj || !d->Tx))) { set_error("schwarz smoother needs subdomains and inverse blocks"); return AMG_EINVAL; }
+        for (int k = 0; k < nsd; ++k) {
+            const long m = (long)d->Sp[k + 1] - d->Sp[k];
+            if (m < 0 || m * m != (long)d->Tp[k + 1] - d->Tp[k]) { set_error("schwarz: inverse block size does not match its subdomain"); return AMG_EINVAL; }
+        }
+        s.nsd = nsd;
+        s.hSp.assign(d->Sp, d->Sp + nsd + 1);
+        s.hSj.assign(d->Sj, d->Sj + (nsd ? d->Sp[nsd] : 0));
+        for (int v : s.hSj) if (v < 0 || v >= n) { set_error("schwarz: subdomain index out of range"); return AMG_EINVAL; }
+        CHK(dev_alloc(&s.sw_Sp, nsd + 1, &h->dev_bytes));
+        CHK(dev_alloc(&s.sw_Tp, nsd + 1, &h->dev_bytes));
+        CHK(dev_alloc(&s.sw_Sj, (long)s.hSj.size(), &h->dev_bytes));
+        CHK(dev_alloc(&s.sw_Tx, nsd ? d->Tp[nsd] : 0, &h->dev_bytes));
+        CHK(dev_alloc(&s.sw_scratch, (long)s.hSj.size(), &h->dev_bytes));
+        CHK(dev_alloc(&s.sw_order, nsd, &h->dev_bytes));
+        AMG_HIP(hipMemcpy(s.sw_Sp, d->Sp, sizeof(int) * (size_t)(nsd + 1), hipMemcpyHostToDevice));
+        AMG_HIP(hipMemcpy(s.sw_Tp, d->Tp, sizeof(int) * (size_t)(nsd + 1), hipMemcpyHostToDevice));
+        if (nsd) {
+            AMG_HIP(hipMemcpy(s.sw_Sj, d->Sj, sizeof(int) * s.hSj.size(), hipMemcpyHostToDevice));
+            AMG_HIP(hipMemcpy(s.sw_Tx, d->Tx, sizeof(double) * (size_t)d->Tp[nsd], hipMemcpyHostToDevice));
+        }
+    }
     return 0;
 }
 
@@ -1110,6 +1160,15 @@ static int need_schedule(amg_hier *h, Level &L, Smoother &s)
             }
             s.sched = L.sched_csr;
         }
+    } else if (s.kind == AMG_SM_SCHWARZ) {
+        if (!(L.fmt == AMG_FMT_CSR || (L.R == 1 && L.C == 1))) { set_error("schwarz smoother: level operator must be CSR or BSR(1,1)"); return AMG_ENOTIMPL; }
+        std::vector<int> ap((size_t)n + 1), aj((size_t)L.A.nnz);
+        AMG_HIP(hipMemcpy(ap.data(), L.A.Ap, sizeof(int) * ap.size(), hipMemcpyDeviceToHost));
+        if (L.A.nnz) AMG_HIP(hipMemcpy(aj.data(), L.A.Aj, sizeof(int) * aj.size(), hipMemcpyDeviceToHost));
+        std::vector<int> tasks((size_t)s.nsd), order;
+        for (int k = 0; k < s.nsd; ++k) tasks[k] = k;
+        CHK(schwarz_levels(n, ap.data(), aj.data(), s.hSj.data(), s.hSp.data(), tasks, s.sw_level_ptr, order));
+        if (s.nsd) AMG_HIP(hipMemcpy(s.sw_order, order.data(), sizeof(int) * order.size(), hipMemcpyHostToDevice));
     } else if (s.kind == AMG_SM_GAUSS_SEIDEL_INDEXED) {
         std::vector<int> ap((size_t)n + 1), aj((size_t)L.A.nnz);
         std::vector<double> ax((size_t)L.A.nnz);

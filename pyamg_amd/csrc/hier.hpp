@@ -47,6 +47,12 @@ struct Smoother {
     DevBsr Ablk;                     // re-blocked A for block smoothers (owned) ...
     bool Ablk_owned = false;
     std::shared_ptr<Schedule> sched; // GS-type smoothers
+    // schwarz: subdomains + inverse blocks (device), dependency levels of the subdomain tasks
+    int nsd = 0;
+    std::vector<int> hSj, hSp;       // host copies for the level analysis at finalize
+    int *sw_Sj = nullptr, *sw_Sp = nullptr, *sw_Tp = nullptr, *sw_order = nullptr;
+    double *sw_Tx = nullptr, *sw_scratch = nullptr;
+    std::vector<int> sw_level_ptr;
 };
 
 struct Level {
@@ -61,6 +67,15 @@ struct Level {
     std::shared_ptr<Schedule> sched_csr, sched_blk;   // natural-order schedules, shared pre/post
 };
 
+}  // namespace amg
+
+namespace amg {
+// schwarz.hip
+int schwarz_levels(int nrows, const int *Ap, const int *Aj, const int *Sj, const int *Sp,
+                   const std::vector<int> &tasks, std::vector<int> &level_ptr, std::vector<int> &order);
+int launch_schwarz_level(const int *Ap, const int *Aj, const double *Ax, double *x, const double *b,
+                         const double *Tx, const int *Tp, const int *Sj, const int *Sp, double *scratch,
+                         const int *doms, int count, hipStream_t st);
 }  // namespace amg
 
 namespace amg {

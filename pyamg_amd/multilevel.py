@@ -19,7 +19,7 @@ from . import _lib
 __all__ = ["multilevel_solver", "coarse_grid_solver"]
 
 _SM_KIND = {None: 0, "None": 0, "jacobi": 1, "gauss_seidel": 2, "sor": 3, "polynomial": 4,
-            "block_jacobi": 5, "block_gauss_seidel": 6, "gauss_seidel_indexed": 7}
+            "block_jacobi": 5, "block_gauss_seidel": 6, "gauss_seidel_indexed": 7, "schwarz": 8}
 _SWEEP = {"forward": 0, "backward": 1, "symmetric": 2}
 _CYCLE = {"V": 0, "W": 1, "F": 2, "AMLI": 3}
 _X0_ZERO, _NO_EARLY_STOP, _DEVICE_VECTORS = 1, 2, 4
@@ -53,6 +53,12 @@ def _desc_struct(desc, keep):
         idx = np.ascontiguousarray(desc["indices"], dtype=np.intc)
         keep.append(idx)
         d.indices, d.nindices = _lib.ip(idx), len(idx)
+    if name == "schwarz":
+        arrs = [np.ascontiguousarray(desc[k], dtype=np.intc) for k in ("subdomain", "subdomain_ptr", "inv_subblock_ptr")]
+        Tx = np.ascontiguousarray(desc["inv_subblock"], dtype=np.float64)
+        keep.extend(arrs + [Tx])
+        d.Sj, d.Sp, d.Tp, d.Tx = _lib.ip(arrs[0]), _lib.ip(arrs[1]), _lib.ip(arrs[2]), _lib.dp(Tx)
+        d.nsdomains = len(arrs[1]) - 1
     return d
 
 

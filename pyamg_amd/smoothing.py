@@ -19,9 +19,10 @@ from .util import (approximate_spectral_radius, approximate_spectral_radius_devi
 __all__ = ["change_smoothers", "rho_D_inv_A", "rho_block_D_inv_A"]
 
 # names the device cycle implements; the rest of the reference's list
-# (schwarz, cg, gmres, cgne, cgnr, *_ne, *_nr) is outside the hot path
+# (cg, gmres, cgne, cgnr, *_ne, *_nr) is outside the hot path
 DEVICE_SMOOTHERS = ("gauss_seidel", "jacobi", "block_jacobi", "block_gauss_seidel", "richardson",
-                    "sor", "chebyshev", "polynomial", "gauss_seidel_indexed", "None")
+                    "sor", "chebyshev", "polynomial", "gauss_seidel_indexed", "schwarz",
+                    "strength_based_schwarz", "None")
 
 
 def unpack_arg(v):

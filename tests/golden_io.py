@@ -54,6 +54,9 @@ def load_hier(name):
                 d = dict(meta["levels"][i][side])
                 if d.pop("has_Dinv", False):
                     d["Dinv"] = z["%s%d_Dinv" % (side, i)]
+                if d.pop("has_schwarz", False):
+                    for k in ("subdomain", "subdomain_ptr", "inv_subblock", "inv_subblock_ptr"):
+                        d[k] = z["%s%d_%s" % (side, i, k)]
                 L[side] = canonical(d)
         levels.append(L)
     out = dict(meta=meta, levels=levels, coarse_pinv=z["coarse_pinv"])
@@ -111,6 +114,10 @@ def smoother_spec(d):
     if name == "block_gauss_seidel":
         return ("block_gauss_seidel", {"iterations": it, "sweep": d.get("sweep", "forward"), "blocksize": bs,
                                        "Dinv": np.asarray(d["Dinv"]).reshape(-1, bs, bs)})
+    if name == "schwarz":
+        return ("schwarz", {"iterations": it, "sweep": d.get("sweep", "symmetric"), "subdomain": d["subdomain"],
+                            "subdomain_ptr": d["subdomain_ptr"], "inv_subblock": d["inv_subblock"],
+                            "inv_subblock_ptr": d["inv_subblock_ptr"]})
     raise KeyError(name)
 
 

@@ -18,7 +18,7 @@ c_dbl_p = C.POINTER(C.c_double)
 FMT_CSR, FMT_BSR = 0, 1
 SM = {None: 0, "None": 0, "jacobi": 1, "gauss_seidel": 2, "sor": 3, "polynomial": 4,
       "block_jacobi": 5, "block_gauss_seidel": 6, "gauss_seidel_indexed": 7,
-      "gauss_seidel_ne": 8, "gauss_seidel_nr": 9, "jacobi_ne": 10}
+      "gauss_seidel_ne": 8, "gauss_seidel_nr": 9, "jacobi_ne": 10, "schwarz": 11}
 SWEEP = {"forward": 0, "backward": 1, "symmetric": 2}
 CYCLE = {"V": 0, "W": 1, "F": 2, "AMLI": 3}
 
@@ -32,7 +32,8 @@ class Smoother(C.Structure):
     _fields_ = [("kind", C.c_int), ("iterations", C.c_int), ("sweep", C.c_int),
                 ("omega", C.c_double), ("ncoef", C.c_int), ("coef", c_dbl_p),
                 ("blocksize", C.c_int), ("Dinv", c_dbl_p), ("indices", c_int_p),
-                ("nindices", C.c_int), ("Aalt", C.POINTER(Mat))]
+                ("nindices", C.c_int), ("Aalt", C.POINTER(Mat)),
+                ("Sj", c_int_p), ("Sp", c_int_p), ("Tp", c_int_p), ("Tx", c_dbl_p), ("nsdomains", C.c_int)]
 
 
 def ip(a):
@@ -143,6 +144,17 @@ def make_smoother(desc, A, keep):
         idx = np.ascontiguousarray(desc["indices"], dtype=np.intc)
         keep.append(idx)
         s.indices, s.nindices = ip(idx), len(idx)
+    if name == "schwarz":
+        arrs = [np.ascontiguousarray(desc[k], dtype=np.intc) for k in ("subdomain", "subdomain_ptr", "inv_subblock_ptr")]
+        Tx = np.ascontiguousarray(desc["inv_subblock"], dtype=np.float64)
+        keep.extend(arrs + [Tx])
+        s.Sj, s.Sp, s.Tp, s.Tx = ip(arrs[0]), ip(arrs[1]), ip(arrs[2]), dp(Tx)
+        s.nsdomains = len(arrs[1]) - 1
+        Ac = A.tocsr()
+        Ac.sort_indices()
+        m = make_mat(Ac, keep)
+        keep.append(m)
+        s.Aalt = C.pointer(m)
     if name in ("block_jacobi", "block_gauss_seidel"):
         # the shim re-blocks A: relaxation.py:471,563  A = A.tobsr(blocksize=(bs,bs))
         Ab = A.tobsr(blocksize=(bs, bs))
