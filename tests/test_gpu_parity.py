@@ -739,3 +739,54 @@ def test_schwarz_at_scale_vs_oracle(oracle):
                                               oracle_lib.dp(b), oracle_lib.dp(Tx), oracle_lib.ip(Tp), oracle_lib.ip(Sj),
                                               oracle_lib.ip(Sp), n, n, rs, re, rt)
         assert np.array_equal(x, xo)
+
+
+@pytest.mark.parametrize("dims,expect_nu", [((70, 75), 9), ((30, 31, 32), 27)])
+def test_stencil_form_wide_stencils(dims, expect_nu, oracle):
+    """9-point (2-D) and 27-point (3-D) operators with variable coefficients: the 16- and 32-slot
+    instantiations of the stencil kernel (uint32 row masks).  Operator application and a Jacobi /
+    Chebyshev V-cycle against scipy / the oracle, bit for bit, stencil form on and off."""
+    import scipy.sparse as sp
+    from pyamg_amd import _lib
+    from pyamg_amd.aggregation import smoothed_aggregation_solver
+    rng = np.random.RandomState(17)
+    T = [sp.diags([np.ones(d - 1), 2.0 * np.ones(d), np.ones(d - 1)], [-1, 0, 1]) for d in dims]
+    S = T[0]
+    for t in T[1:]:
+        S = sp.kron(S, t)
+    S = sp.csr_matrix(S)
+    S.sort_indices()
+    n = S.shape[0]
+    assert S.nnz / n > 0.8 * expect_nu
+    # symmetric, diagonally dominant, every entry different
+    W = sp.csr_matrix((-rng.rand(S.nnz), S.indices, S.indptr), shape=S.shape)
+    W = sp.csr_matrix(0.5 * (W + W.T))
+    W.setdiag(0.0)
+    W.eliminate_zeros()
+    A = sp.csr_matrix(W + sp.diags(np.asarray(abs(W).sum(axis=1)).ravel() + 1.0))
+    A.sort_indices()
+    np.random.seed(0)
+    sm = ("chebyshev", {"degree": 3})
+    ml = smoothed_aggregation_solver(A, presmoother=("jacobi", {"omega": 4.0 / 3.0}), postsmoother=sm)
+    dev = ml.device_hierarchy()
+    assert _lib.lib().amg_hier_operator_form(dev.h, 0) == 2
+    v = rng.rand(n)
+    b = rng.rand(n)
+    got = {}
+    for on in (1, 0):
+        _lib.lib().amg_set_stencil_form(on)
+        assert np.array_equal(dev.matvec(0, 0, v), A * v), on
+        res = []
+        got[on] = (ml.solve(b, tol=0.0, maxiter=3, residuals=res), np.array(res))
+    _lib.lib().amg_set_stencil_form(1)
+    assert np.array_equal(got[0][0], got[1][0]) and np.allclose(got[0][1], got[1][1], rtol=1e-14)
+    levels = []
+    for lvl in ml.levels:
+        L = {"A": lvl.A}
+        if hasattr(lvl, "P"):
+            L.update(P=lvl.P, R=lvl.R, pre=dict(lvl.presmoother.desc), post=dict(lvl.postsmoother.desc))
+        levels.append(L)
+    kind, M = ml.coarse_solver.device_form(ml.levels[-1].A)
+    xo, reso = oracle_lib.Hierarchy(levels, M).solve(b, tol=0.0, maxiter=3)
+    assert np.array_equal(got[1][0], xo)
+    assert np.allclose(got[1][1], reso, rtol=1e-12)
