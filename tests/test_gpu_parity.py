@@ -790,3 +790,16 @@ def test_stencil_form_wide_stencils(dims, expect_nu, oracle):
     xo, reso = oracle_lib.Hierarchy(levels, M).solve(b, tol=0.0, maxiter=3)
     assert np.array_equal(got[1][0], xo)
     assert np.allclose(got[1][1], reso, rtol=1e-12)
+
+
+def test_operator_forms_randomised():
+    """tools/stress_forms.py: 40 random structured operators (1-D..3-D grids, size-1 axes, dropped
+    entries, halo-like rectangular extensions, unsorted rows) through the CSR / offset-pattern /
+    stencil forms and random row ranges -- every product equals scipy's bit for bit."""
+    import importlib.util
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "stress_forms.py")
+    spec = importlib.util.spec_from_file_location("stress_forms", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    forms = mod.run(5, 40)
+    assert forms[2] > 0 and forms[0] + forms[1] > 0          # the draw exercised stencil and non-stencil forms
