@@ -127,6 +127,7 @@ bool pattern_supports(StreamMode mode);
 int launch_stencil(StreamMode mode, const StreamArgs &a, const DevCsr &M, hipStream_t st);
 int stencil_blocks(const StreamArgs &a, const DevCsr &M);   // workgroups (= SM_RESIDUAL_SUMSQ partials) of launch_stencil
 int launch_stencil_build(const DevCsr &M, const int *dict_slot, const unsigned *pat_mask, hipStream_t st);
+int config_epoch();                      // bumped by every set_* knob below
 bool stencil_enabled();
 int launch_index16_build(DevCsr &M, int rpb, hipStream_t st);   // fills Aj16 / wg_base / wg_flag (already allocated)
 bool index16_enabled();

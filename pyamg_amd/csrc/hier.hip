@@ -810,11 +810,17 @@ static int iteration_with_norm(amg_hier *h, int cyc, bool x_zero, double *slot)
     return residual_norm_to(h, slot);
 }
 
+static void drop_graphs(amg_hier *h);
+
 static int graph_iteration(amg_hier *h, int cyc, bool x_zero, double *dst)
 {
     hipStream_t st = h->stream;
     double *slot = h->norm_scratch + 1028;
     if (!h->use_graphs || cyc == AMG_CYCLE_AMLI) return iteration_with_norm(h, cyc, x_zero, dst);
+    if (h->graph_epoch != config_epoch()) {      // a launch knob changed: the captured launches are stale
+        drop_graphs(h);
+        h->graph_epoch = config_epoch();
+    }
     std::vector<double *> state = buffer_state(h);
     GraphEntry *ge = nullptr;
     for (auto &g : h->graphs)

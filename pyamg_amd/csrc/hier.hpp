@@ -119,6 +119,7 @@ struct amg_hier {
     // hipGraph replay of the iteration (launch-bound hierarchies: small levels, level-scheduled GS)
     std::vector<amg::GraphEntry> graphs;
     int use_graphs = 1;
+    int graph_epoch = 0;                         // amg::config_epoch() the cached graphs were captured under
     int keep_residual = 1;                       // hand the outer residual to the next pre-smoother
     bool r_kept = false;                         // lv[0].r == lv[0].b - A*lv[0].x right now (solve loop only)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;

@@ -48,7 +48,10 @@ __device__ __forceinline__ v2d load_v2d(const double *p)
 static int g_stream_variant = 1;
 static int g_xcd_chunk = 32;   // consecutive row blocks per XCD (PMC: -15 % L2-miss traffic, time -1..2 %)
 static int g_tile_target = 2048;   // products per workgroup aimed at when choosing rows per workgroup
-void set_tile_target(int t) { g_tile_target = t > 0 ? t : 2048; }
+// every change of a launch knob bumps this; hierarchies drop their captured graphs when they see a new value
+static int g_config_epoch = 0;
+int config_epoch() { return g_config_epoch; }
+void set_tile_target(int t) { g_tile_target = t > 0 ? t : 2048; ++g_config_epoch; }
 
 // Rows per workgroup for a matrix with `nnz` entries in `rows` rows: enough rows to fill about
 // one LDS tile, so that long-row operators (restriction, coarse levels) still spread over many
@@ -62,11 +65,11 @@ int rows_per_wg_for(long nnz, long rows)
     while (p * 2 <= r && p < WG) p *= 2;
     return p;
 }
-void set_stream_variant(int v) { g_stream_variant = v; }
+void set_stream_variant(int v) { g_stream_variant = v; ++g_config_epoch; }
 int stream_variant() { return g_stream_variant; }
-void set_xcd_chunk(int c) { g_xcd_chunk = c; }
+void set_xcd_chunk(int c) { g_xcd_chunk = c; ++g_config_epoch; }
 static int g_xcd_period = 1;
-void set_xcd_period(int on) { g_xcd_period = on; }
+void set_xcd_period(int on) { g_xcd_period = on; ++g_config_epoch; }
 
 // Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2).
 // With chunk > 0, each group of 8*chunk consecutive logical blocks is laid out
@@ -745,7 +748,7 @@ int launch_stencil_build(const DevCsr &M, const int *dict_slot, const unsigned *
 }
 
 static int g_stencil_form = 1;
-void set_stencil_form(int on) { g_stencil_form = on; }
+void set_stencil_form(int on) { g_stencil_form = on; ++g_config_epoch; }
 bool stencil_enabled() { return g_stencil_form != 0; }
 
 static int stencil_own_blocks(const StreamArgs &a)
@@ -875,7 +878,7 @@ __global__ __launch_bounds__(WG) void index16_build_kernel(int nrows, int rpb, c
 }
 
 static int g_index16 = 0;   // opt-in: measured -6 % on R_0, -1 % on A_1, +8 % on P_0 at 500^3
-void set_index16(int on) { g_index16 = on; }
+void set_index16(int on) { g_index16 = on; ++g_config_epoch; }
 bool index16_enabled() { return g_index16 != 0; }
 
 int launch_index16_build(DevCsr &M, int rpb, hipStream_t st)
