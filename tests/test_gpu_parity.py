@@ -803,3 +803,40 @@ def test_operator_forms_randomised():
     spec.loader.exec_module(mod)
     forms = mod.run(5, 40)
     assert forms[2] > 0 and forms[0] + forms[1] > 0          # the draw exercised stencil and non-stencil forms
+
+
+def test_schwarz_definition_on_small_systems():
+    """Same property the reference's own test checks (relaxation/tests/test_relaxation.py:678-750):
+    relaxation.schwarz with the default subdomains equals the textbook multiplicative Schwarz update
+    x[S_i] += pinv(A[S_i, S_i]) (b[S_i] - A[S_i, :] x), subdomain after subdomain, for forward, backward
+    and symmetric sweeps -- on 1-D / 2-D Poisson operators, a perturbed one and tiny dense SPD blocks."""
+    import scipy.sparse as sp
+    from pyamg_amd.aggregation import poisson as native
+    rng = np.random.RandomState(0)
+    cases = [native((4,)), native((4, 4))]
+    A = native((8, 8)).copy()
+    A.data[0] = 10.0; A.data[1] = -0.5; A.data[3] = -0.5
+    cases.append(A)
+    for m in (1, 2, 4):
+        t = rng.rand(m, m)
+        cases.append(sp.csr_matrix(t.T.dot(t)))
+
+    def textbook(A, x, b, order):
+        A = sp.csr_matrix(A)
+        Ad = A.toarray()
+        for i in order:
+            S = A.indices[A.indptr[i]:A.indptr[i + 1]]
+            x[S] = x[S] + np.linalg.pinv(Ad[np.ix_(S, S)]).dot(b[S] - Ad[S, :].dot(x))
+        return x
+
+    for A in cases:
+        A = sp.csr_matrix(A)
+        A.sort_indices()
+        n = A.shape[0]
+        b = rng.rand(n)
+        for sweep, order in (("forward", list(range(n))), ("backward", list(range(n - 1, -1, -1))),
+                             ("symmetric", list(range(n)) + list(range(n - 1, -1, -1)))):
+            x = rng.rand(n)
+            want = textbook(A, x.copy(), b, order)
+            relaxation.schwarz(A, x, b, iterations=1, sweep=sweep)
+            assert np.allclose(x, want, rtol=1e-7, atol=1e-9), (n, sweep)
