@@ -135,7 +135,8 @@ enum { AMG_SWEEP_FORWARD = 0, AMG_SWEEP_BACKWARD = 1, AMG_SWEEP_SYMMETRIC = 2 };
 /* smoother kinds = the relaxation.py entry points a smoothing.py closure calls */
 enum { AMG_SM_NONE = 0, AMG_SM_JACOBI = 1, AMG_SM_GAUSS_SEIDEL = 2, AMG_SM_SOR = 3,
        AMG_SM_POLYNOMIAL = 4, AMG_SM_BLOCK_JACOBI = 5, AMG_SM_BLOCK_GAUSS_SEIDEL = 6,
-       AMG_SM_GAUSS_SEIDEL_INDEXED = 7, AMG_SM_SCHWARZ = 8 };
+       AMG_SM_GAUSS_SEIDEL_INDEXED = 7, AMG_SM_SCHWARZ = 8, AMG_SM_GAUSS_SEIDEL_NE = 9,
+       AMG_SM_GAUSS_SEIDEL_NR = 10, AMG_SM_JACOBI_NE = 11 };
 
 typedef struct {
     int kind;            /* AMG_SM_* */
@@ -145,7 +146,8 @@ typedef struct {
     int ncoef;           /* polynomial: Horner coefficients (chebyshev: -coeffs[:-1]) */
     const double *coef;  /* host pointer, copied */
     int blocksize;       /* block_jacobi / block_gauss_seidel */
-    const double *Dinv;  /* host pointer, (n/bs)*bs*bs row-major inverse diagonal blocks, copied */
+    const double *Dinv;  /* host pointer, (n/bs)*bs*bs row-major inverse diagonal blocks, copied;
+                            normal-equation kinds: n entries 1/diag(A A^H) (ne, jacobi_ne) or 1/diag(A^H A) (nr) */
     const int *indices;  /* gauss_seidel_indexed: row order (host pointer, copied) */
     int nindices;
     /* schwarz (relaxation.py:172-278; level A must be CSR or BSR(1,1)): sorted subdomain index lists
@@ -180,6 +182,12 @@ int amg_hier_set_smoother(amg_hier *h, int lvl, int which, const amg_smoother_de
  * amg_hier_set_smoother; which = AMG_PRE / AMG_POST, or 2 for the coarse smoother. */
 int amg_hier_set_block_matrix(amg_hier *h, int lvl, int which, int nbrows, int bs, const int *Ap,
                               const int *Aj, const double *Ax);
+/* Normal-equation smoothers (relaxation.py:744-997; level A must be CSR or BSR(1,1)) work on other
+ * layouts of A, passed AFTER amg_hier_set_smoother: slot 0 = A by columns (the CSC arrays: indptr over
+ * columns, row indices ascending, values) for gauss_seidel_nr and jacobi_ne; slot 1 = A by rows with
+ * sorted column indices, needed by gauss_seidel_nr only when the level's A has unsorted rows. */
+int amg_hier_set_aux_matrix(amg_hier *h, int lvl, int which, int slot, int nmajor, int nminor,
+                            const int *Ap, const int *Aj, const double *Ax);
 /* coarse_grid_solver('pinv'/'pinv2'/'lu'/'cholesky'/'splu'): a dense n x n
  * row-major operator M with x = M b (multilevel.py:608-641) */
 int amg_hier_set_coarse_dense(amg_hier *h, const double *M, int n);

@@ -82,6 +82,19 @@ def main():
              lambda A, **kw: pyamg.smoothed_aggregation_solver(A, max_coarse=20, **kw),
              ("strength_based_schwarz", {"sweep": "forward", "iterations": 2}),
              ("strength_based_schwarz", {"sweep": "backward"}), dict(tol=1e-9))
+    # the normal-equation smoothers as multigrid smoothers (smoothing.py:452-478)
+    gen_hier(pyamg, "sa_gsne_2d", P((20, 20)),
+             lambda A, **kw: pyamg.smoothed_aggregation_solver(A, max_coarse=20, **kw),
+             ("gauss_seidel_ne", {"sweep": "symmetric", "omega": 1.0}),
+             ("gauss_seidel_ne", {"sweep": "backward", "iterations": 2, "omega": 0.9}), dict(tol=1e-8, maxiter=40))
+    gen_hier(pyamg, "sa_gsnr_2d", P((20, 20)),
+             lambda A, **kw: pyamg.smoothed_aggregation_solver(A, max_coarse=20, **kw),
+             ("gauss_seidel_nr", {"sweep": "symmetric"}),
+             ("gauss_seidel_nr", {"sweep": "forward", "iterations": 2, "omega": 1.1}), dict(tol=1e-8, maxiter=40))
+    gen_hier(pyamg, "sa_jacne_2d", P((20, 20)),
+             lambda A, **kw: pyamg.smoothed_aggregation_solver(A, max_coarse=20, **kw),
+             ("jacobi_ne", {"omega": 4.0 / 3.0, "iterations": 2}), ("jacobi_ne", {"omega": 4.0 / 3.0}),
+             dict(tol=1e-8, maxiter=40))
     print("schwarz.npz: %d cases; docstring residual %.12f" % (len(cases), norm(b - A * x)))
 
 

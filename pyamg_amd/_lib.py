@@ -81,6 +81,7 @@ def lib():
         "amg_hier_set_matrix": [V, I, I, I, I, I, I, I, V, V, V, I],
         "amg_hier_set_smoother": [V, I, I, C.POINTER(SmootherDesc)],
         "amg_hier_set_block_matrix": [V, I, I, I, I, c_int_p, c_int_p, c_dbl_p],
+        "amg_hier_set_aux_matrix": [V, I, I, I, I, I, c_int_p, c_int_p, c_dbl_p],
         "amg_hier_set_coarse_dense": [V, c_dbl_p, I],
         "amg_hier_set_coarse_smoother": [V, C.POINTER(SmootherDesc)],
         "amg_hier_finalize": [V],

@@ -632,6 +632,60 @@ static int relax(amg_hier *h, Level &L, Smoother &s, double *&x, double *&xalt, 
         }
         return 0;
     }
+    case AMG_SM_GAUSS_SEIDEL_NE: {
+        // relaxation.py:821-908 (Kaczmarz sweep over the rows)
+        const std::vector<int> &lp = s.sw_level_ptr;
+        const int nl = (int)lp.size() - 1;
+        auto sweep_once = [&](bool reverse) -> int {
+            for (int q = 0; q < nl; ++q) {
+                const int l = reverse ? nl - 1 - q : q;
+                CHK(launch_gs_ne_level(L.A.Ap, L.A.Aj, L.A.Ax, x, b, s.Dinv, s.omega, s.sw_order + lp[l], lp[l + 1] - lp[l], st));
+            }
+            return 0;
+        };
+        for (int it = 0; it < s.iterations; ++it) {
+            if (s.sweep == AMG_SWEEP_FORWARD || s.sweep == AMG_SWEEP_SYMMETRIC) CHK(sweep_once(false));
+            if (s.sweep == AMG_SWEEP_BACKWARD || s.sweep == AMG_SWEEP_SYMMETRIC) CHK(sweep_once(true));
+        }
+        return 0;
+    }
+    case AMG_SM_GAUSS_SEIDEL_NR: {
+        // relaxation.py:911-997: every call starts from r = b - A x (a CSC product in the reference:
+        // terms in ascending column order = a row of A with sorted indices), then sweeps the columns,
+        // keeping r current; a symmetric sweep is a forward CALL followed by a backward CALL
+        const std::vector<int> &lp = s.sw_level_ptr;
+        const int nl = (int)lp.size() - 1;
+        const DevCsr &Arow = s.aux[1].Ap ? s.aux[1] : L.A;
+        const DevCsr &Acol = s.aux[0];
+        auto call = [&](bool reverse, int iterations) -> int {
+            CHK(spmv(Arow, SM_RESIDUAL, x, b, nullptr, L.r, nullptr, 0.0, st));
+            for (int it = 0; it < iterations; ++it)
+                for (int q = 0; q < nl; ++q) {
+                    const int l = reverse ? nl - 1 - q : q;
+                    CHK(launch_gs_nr_level(Acol.Ap, Acol.Aj, Acol.Ax, x, L.r, s.Dinv, s.omega, s.sw_order + lp[l],
+                                           lp[l + 1] - lp[l], st));
+                }
+            return 0;
+        };
+        if (s.sweep == AMG_SWEEP_SYMMETRIC) {
+            for (int it = 0; it < s.iterations; ++it) { CHK(call(false, 1)); CHK(call(true, 1)); }
+        } else {
+            CHK(call(s.sweep == AMG_SWEEP_BACKWARD, s.iterations));
+        }
+        return 0;
+    }
+    case AMG_SM_JACOBI_NE: {
+        // relaxation.py:744-818: delta = (b - A x) .* Dinv; x += A^H (omega delta), the contributions to
+        // an entry added in (row, position) order = down the column of A
+        const DevCsr &Acol = s.aux[0];
+        for (int it = 0; it < s.iterations; ++it) {
+            CHK(spmv(L.A, SM_RESIDUAL, x, b, nullptr, L.r, nullptr, 0.0, st));
+            CHK(launch_mul_elem(L.r, s.Dinv, n, st));
+            CHK(launch_jacobi_ne_gather(Acol.Ap, Acol.Aj, Acol.Ax, L.r, s.omega, L.h, n, st));
+            CHK(launch_axpy_inplace(x, L.h, n, st));
+        }
+        return 0;
+    }
     case AMG_SM_SCHWARZ: {
         // relaxation.py:254-277: subdomains by dependency levels; descending levels = backward sweep
         const std::vector<int> &lp = s.sw_level_ptr;
@@ -932,6 +986,8 @@ static void free_smoother(Smoother &s)
     if (s.sw_scratch) hipFree(s.sw_scratch);
     s.sw_Sj = s.sw_Sp = s.sw_Tp = s.sw_order = nullptr;
     s.sw_Tx = s.sw_scratch = nullptr;
+    free_csr(s.aux[0]);
+    free_csr(s.aux[1]);
     if (s.Dinv) hipFree(s.Dinv);
     s.Dinv = nullptr;
     if (s.Ablk_owned) free_bsr(s.Ablk);
@@ -1054,6 +1110,12 @@ static int fill_smoother(amg_hier *h, Smoother &s, const amg_smoother_desc *d, i
         if (d->nindices < 0 || (d->nindices && !d->indices)) { set_error("indexed GS needs indices"); return AMG_EINVAL; }
         s.indices.assign(d->indices, d->indices + d->nindices);
     }
+    if (d->kind == AMG_SM_GAUSS_SEIDEL_NE || d->kind == AMG_SM_GAUSS_SEIDEL_NR || d->kind == AMG_SM_JACOBI_NE) {
+        if (!d->Dinv) { set_error("normal-equation smoother needs the inverse diagonal of A A^H / A^H A"); return AMG_EINVAL; }
+        CHK(dev_alloc(&s.Dinv, n, &h->dev_bytes));
+        AMG_HIP(hipMemcpy(s.Dinv, d->Dinv, sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+        CHK(dev_alloc(&s.sw_order, n, &h->dev_bytes));
+    }
     if (d->kind == AMG_SM_SCHWARZ) {
         const int nsd = d->nsdomains;
         if (nsd < 0 || !d->Sp || !d->Tp || (nsd && (!d->Sj || !d->Tx))) { set_error("schwarz smoother needs subdomains and inverse blocks"); return AMG_EINVAL; }
@@ -1101,6 +1163,19 @@ int amg_hier_set_block_matrix(amg_hier *h, int lvl, int which, int nbrows, int b
     if (s.Ablk_owned) free_bsr(s.Ablk);
     CHK(upload_bsr(s.Ablk, nbrows, bs, Ap, Aj, Ax, &h->dev_bytes));
     s.Ablk_owned = true;
+    h->finalized = false;
+    return 0;
+}
+
+int amg_hier_set_aux_matrix(amg_hier *h, int lvl, int which, int slot, int nmajor, int nminor, const int *Ap,
+                            const int *Aj, const double *Ax)
+{
+    ENTER(h);
+    if (lvl < 0 || lvl >= h->nlevels || which < 0 || which > 2 || slot < 0 || slot > 1) { set_error("bad level/which/slot"); return AMG_EINVAL; }
+    if (nmajor < 0 || nminor < 0 || !Ap) { set_error("bad matrix"); return AMG_EINVAL; }
+    Smoother &s = (which == 2) ? h->coarse_sm : h->lv[lvl].sm[which];
+    free_csr(s.aux[slot]);
+    CHK(upload_csr(s.aux[slot], nmajor, nminor, Ap, Aj, Ax, &h->dev_bytes));
     h->finalized = false;
     return 0;
 }
@@ -1165,6 +1240,21 @@ static int need_schedule(amg_hier *h, Level &L, Smoother &s)
                 h->dev_bytes += 12L * L.A.nnz + 12L * n;
             }
             s.sched = L.sched_csr;
+        }
+    } else if (s.kind == AMG_SM_GAUSS_SEIDEL_NE || s.kind == AMG_SM_GAUSS_SEIDEL_NR || s.kind == AMG_SM_JACOBI_NE) {
+        if (!(L.fmt == AMG_FMT_CSR || (L.R == 1 && L.C == 1))) { set_error("normal-equation smoother: level operator must be CSR or BSR(1,1)"); return AMG_ENOTIMPL; }
+        if (s.kind != AMG_SM_GAUSS_SEIDEL_NE && (!s.aux[0].Ap || s.aux[0].nrows != n || s.aux[0].nnz != L.A.nnz)) {
+            set_error("gauss_seidel_nr / jacobi_ne: pass A by columns with amg_hier_set_aux_matrix(slot 0)");
+            return AMG_ESTATE;
+        }
+        if (s.kind != AMG_SM_JACOBI_NE) {
+            // tasks = rows of A (ne) / columns of A (nr); tasks sharing a vector entry keep their order
+            const DevCsr &T = (s.kind == AMG_SM_GAUSS_SEIDEL_NE) ? L.A : s.aux[0];
+            std::vector<int> ap((size_t)n + 1), aj((size_t)T.nnz), order;
+            AMG_HIP(hipMemcpy(ap.data(), T.Ap, sizeof(int) * ap.size(), hipMemcpyDeviceToHost));
+            if (T.nnz) AMG_HIP(hipMemcpy(aj.data(), T.Aj, sizeof(int) * aj.size(), hipMemcpyDeviceToHost));
+            CHK(ne_touch_levels(n, ap.data(), aj.data(), n, s.sw_level_ptr, order));
+            if (n) AMG_HIP(hipMemcpy(s.sw_order, order.data(), sizeof(int) * order.size(), hipMemcpyHostToDevice));
         }
     } else if (s.kind == AMG_SM_SCHWARZ) {
         if (!(L.fmt == AMG_FMT_CSR || (L.R == 1 && L.C == 1))) { set_error("schwarz smoother: level operator must be CSR or BSR(1,1)"); return AMG_ENOTIMPL; }

@@ -53,6 +53,11 @@ struct Smoother {
     int *sw_Sj = nullptr, *sw_Sp = nullptr, *sw_Tp = nullptr, *sw_order = nullptr;
     double *sw_Tx = nullptr, *sw_scratch = nullptr;
     std::vector<int> sw_level_ptr;
+    // normal-equation family: aux[0] = A by columns (CSC arrays; gauss_seidel_nr sweeps it, jacobi_ne
+    // gathers through it), aux[1] = A with sorted rows when the level's own copy is not (the residual
+    // gauss_seidel_nr starts from is a CSC product: terms in ascending column order).  Dinv holds
+    // 1/diag(A A^H) or 1/diag(A^H A); the task levels reuse sw_order / sw_level_ptr.
+    DevCsr aux[2];
 };
 
 struct Level {
@@ -76,6 +81,15 @@ int schwarz_levels(int nrows, const int *Ap, const int *Aj, const int *Sj, const
 int launch_schwarz_level(const int *Ap, const int *Aj, const double *Ax, double *x, const double *b,
                          const double *Tx, const int *Tp, const int *Sj, const int *Sp, double *scratch,
                          const int *doms, int count, hipStream_t st);
+// ne.hip
+int ne_touch_levels(int nvec, const int *Ap, const int *Aj, int ntasks, std::vector<int> &level_ptr,
+                    std::vector<int> &order);
+int launch_gs_ne_level(const int *Ap, const int *Aj, const double *Ax, double *x, const double *b, const double *Dinv,
+                       double omega, const int *rows, int count, hipStream_t st);
+int launch_gs_nr_level(const int *Ap, const int *Aj, const double *Ax, double *x, double *r, const double *Dinv,
+                       double omega, const int *cols, int count, hipStream_t st);
+int launch_jacobi_ne_gather(const int *Tp, const int *Trow, const double *Tval, const double *delta, double omega,
+                            double *temp, int n, hipStream_t st);
 }  // namespace amg
 
 namespace amg {

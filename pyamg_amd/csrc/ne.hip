@@ -116,7 +116,7 @@ __global__ void jacobi_ne_gather(const int *Tp, const int *Trow, const double *T
 {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n) return;
-    double acc = in_range[c] ? 0.0 : temp[c];
+    double acc = (!in_range || in_range[c]) ? 0.0 : temp[c];      // null mask: every row is swept
     for (int k = Tp[c]; k < Tp[c + 1]; ++k) acc = acc + (omega * Tval[k]) * delta[Trow[k]];
     temp[c] = acc;
 }
@@ -129,6 +129,46 @@ __global__ void jacobi_ne_update(double *x, const double *temp, const int *rows,
 }
 
 }  // namespace
+
+// entry points for the in-cycle smoothers of the resident hierarchy (hier.hip)
+namespace amg {
+int ne_touch_levels(int nvec, const int *Ap, const int *Aj, int ntasks, std::vector<int> &level_ptr,
+                    std::vector<int> &order)
+{
+    std::vector<int> tasks((size_t)ntasks);
+    for (int i = 0; i < ntasks; ++i) tasks[i] = i;
+    return touch_levels(nvec, Ap, Aj, tasks, level_ptr, order);
+}
+int launch_gs_ne_level(const int *Ap, const int *Aj, const double *Ax, double *x, const double *b, const double *Dinv,
+                       double omega, const int *rows, int count, hipStream_t st)
+{
+    if (count <= 0) return 0;
+    hipLaunchKernelGGL(gs_ne_level, dim3((count + 127) / 128), dim3(128), 0, st, Ap, Aj, Ax, x, b, Dinv, omega, rows, count);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "gs_ne level launch", __FILE__, __LINE__);
+    return 0;
+}
+int launch_gs_nr_level(const int *Ap, const int *Aj, const double *Ax, double *x, double *r, const double *Dinv,
+                       double omega, const int *cols, int count, hipStream_t st)
+{
+    if (count <= 0) return 0;
+    hipLaunchKernelGGL(gs_nr_level, dim3((count + 127) / 128), dim3(128), 0, st, Ap, Aj, Ax, x, r, Dinv, omega, cols, count);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "gs_nr level launch", __FILE__, __LINE__);
+    return 0;
+}
+// temp[c] = sum over column c of A, rows ascending, of (omega * a) * delta[row]  (relaxation.h:485-495)
+int launch_jacobi_ne_gather(const int *Tp, const int *Trow, const double *Tval, const double *delta, double omega,
+                            double *temp, int n, hipStream_t st)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(jacobi_ne_gather, dim3((n + 127) / 128), dim3(128), 0, st, Tp, Trow, Tval, delta, omega, temp,
+                       (const unsigned char *)nullptr, n);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "jacobi_ne gather launch", __FILE__, __LINE__);
+    return 0;
+}
+}  // namespace amg
 
 extern "C" {
 

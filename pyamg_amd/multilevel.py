@@ -19,7 +19,8 @@ from . import _lib
 __all__ = ["multilevel_solver", "coarse_grid_solver"]
 
 _SM_KIND = {None: 0, "None": 0, "jacobi": 1, "gauss_seidel": 2, "sor": 3, "polynomial": 4,
-            "block_jacobi": 5, "block_gauss_seidel": 6, "gauss_seidel_indexed": 7, "schwarz": 8}
+            "block_jacobi": 5, "block_gauss_seidel": 6, "gauss_seidel_indexed": 7, "schwarz": 8,
+            "gauss_seidel_ne": 9, "gauss_seidel_nr": 10, "jacobi_ne": 11}
 _SWEEP = {"forward": 0, "backward": 1, "symmetric": 2}
 _CYCLE = {"V": 0, "W": 1, "F": 2, "AMLI": 3}
 _X0_ZERO, _NO_EARLY_STOP, _DEVICE_VECTORS = 1, 2, 4
@@ -123,6 +124,24 @@ class _DeviceHierarchy(object):
                 Ax = np.ascontiguousarray(np.ravel(Ab.data), dtype=np.float64)
                 _lib.check(self.L.amg_hier_set_block_matrix(self.h, lvl, which, Ab.shape[0] // bs, bs,
                                                             _lib.ip(Ap), _lib.ip(Aj), _lib.dp(Ax)))
+        if d.kind in (10, 11):
+            # gauss_seidel_nr sweeps / jacobi_ne gathers through A by columns (lvl.Acsc, smoothing.py:472-478)
+            self._set_aux(lvl, which, 0, A.tocsc())
+        if d.kind == 10 and not A.tocsr().has_sorted_indices:
+            # its starting residual is a CSC product: terms in ascending column order (relaxation.py:992)
+            As = A.tocsr().copy()
+            As.sort_indices()
+            self._set_aux(lvl, which, 1, As)
+
+    def _set_aux(self, lvl, which, slot, M):
+        M.sort_indices()
+        Ap = np.ascontiguousarray(M.indptr, dtype=np.intc)
+        Aj = np.ascontiguousarray(M.indices, dtype=np.intc)
+        Ax = np.ascontiguousarray(M.data, dtype=np.float64)
+        nmajor = len(Ap) - 1
+        nminor = M.shape[0] if sparse.isspmatrix_csc(M) else M.shape[1]
+        _lib.check(self.L.amg_hier_set_aux_matrix(self.h, lvl, which, slot, nmajor, nminor, _lib.ip(Ap), _lib.ip(Aj),
+                                                  _lib.dp(Ax)))
 
     def _build(self, ml):
         levels = ml.levels

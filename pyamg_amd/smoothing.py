@@ -19,10 +19,10 @@ from .util import (approximate_spectral_radius, approximate_spectral_radius_devi
 __all__ = ["change_smoothers", "rho_D_inv_A", "rho_block_D_inv_A"]
 
 # names the device cycle implements; the rest of the reference's list
-# (cg, gmres, cgne, cgnr, *_ne, *_nr) is outside the hot path
+# (cg, gmres, cgne, cgnr: the Krylov smoothers) is outside the hot path
 DEVICE_SMOOTHERS = ("gauss_seidel", "jacobi", "block_jacobi", "block_gauss_seidel", "richardson",
                     "sor", "chebyshev", "polynomial", "gauss_seidel_indexed", "schwarz",
-                    "strength_based_schwarz", "None")
+                    "strength_based_schwarz", "jacobi_ne", "gauss_seidel_ne", "gauss_seidel_nr", "None")
 
 
 def unpack_arg(v):
@@ -210,29 +210,37 @@ def setup_multicolor_gauss_seidel(lvl, iterations=1, sweep="forward"):
 
 
 def setup_jacobi_ne(lvl, iterations=1, omega=1.0, withrho=True):
+    """smoothing.py:452-460"""
     Acsr = lvl.A.tocsr()
     if withrho:
         omega = omega / rho_D_inv_A(Acsr) ** 2
+    Dinv = np.ravel(get_diagonal(Acsr, norm_eq=2, inv=True))
 
     def smoother(A, x, b):
         relaxation.jacobi_ne(Acsr, x, b, iterations=iterations, omega=omega)
-    return smoother
+    return _with_desc(smoother, name="jacobi_ne", iterations=iterations, omega=float(omega), Dinv=Dinv)
 
 
 def setup_gauss_seidel_ne(lvl, iterations=1, sweep="forward", omega=1.0):
+    """smoothing.py:463-469"""
     Acsr = lvl.A.tocsr()
+    Dinv = np.ravel(get_diagonal(Acsr, norm_eq=2, inv=True))
 
     def smoother(A, x, b):
-        relaxation.gauss_seidel_ne(Acsr, x, b, iterations=iterations, sweep=sweep, omega=omega)
-    return smoother
+        relaxation.gauss_seidel_ne(Acsr, x, b, iterations=iterations, sweep=sweep, omega=omega, Dinv=Dinv)
+    return _with_desc(smoother, name="gauss_seidel_ne", iterations=iterations, sweep=sweep, omega=float(omega),
+                      Dinv=Dinv)
 
 
 def setup_gauss_seidel_nr(lvl, iterations=1, sweep="forward", omega=1.0):
+    """smoothing.py:472-478"""
     Acsc = lvl.A.tocsc()
+    Dinv = np.ravel(get_diagonal(Acsc, norm_eq=1, inv=True))
 
     def smoother(A, x, b):
-        relaxation.gauss_seidel_nr(Acsc, x, b, iterations=iterations, sweep=sweep, omega=omega)
-    return smoother
+        relaxation.gauss_seidel_nr(Acsc, x, b, iterations=iterations, sweep=sweep, omega=omega, Dinv=Dinv)
+    return _with_desc(smoother, name="gauss_seidel_nr", iterations=iterations, sweep=sweep, omega=float(omega),
+                      Dinv=Dinv)
 
 
 def setup_schwarz(lvl, iterations=1, subdomain=None, subdomain_ptr=None, inv_subblock=None,

@@ -114,6 +114,10 @@ def smoother_spec(d):
     if name == "block_gauss_seidel":
         return ("block_gauss_seidel", {"iterations": it, "sweep": d.get("sweep", "forward"), "blocksize": bs,
                                        "Dinv": np.asarray(d["Dinv"]).reshape(-1, bs, bs)})
+    if name == "gauss_seidel_ne" or name == "gauss_seidel_nr":
+        return (name, {"iterations": it, "sweep": d.get("sweep", "forward"), "omega": d.get("omega", 1.0)})
+    if name == "jacobi_ne":
+        return ("jacobi_ne", {"iterations": it, "omega": d["omega"], "withrho": False})
     if name == "schwarz":
         return ("schwarz", {"iterations": it, "sweep": d.get("sweep", "symmetric"), "subdomain": d["subdomain"],
                             "subdomain_ptr": d["subdomain_ptr"], "inv_subblock": d["inv_subblock"],

@@ -144,6 +144,26 @@ def make_smoother(desc, A, keep):
         idx = np.ascontiguousarray(desc["indices"], dtype=np.intc)
         keep.append(idx)
         s.indices, s.nindices = ip(idx), len(idx)
+    if name in ("gauss_seidel_ne", "jacobi_ne", "gauss_seidel_nr"):
+        # the shims act on lvl.Acsr / lvl.Acsc (smoothing.py:452-478)
+        M = A.tocsc() if name == "gauss_seidel_nr" else A.tocsr()
+        M.sort_indices() if name == "gauss_seidel_nr" else None
+        Ap = np.ascontiguousarray(M.indptr, dtype=np.intc)
+        Aj = np.ascontiguousarray(M.indices, dtype=np.intc)
+        Ax = np.ascontiguousarray(M.data, dtype=np.float64)
+        keep.extend([Ap, Aj, Ax])
+        m = Mat(0, M.shape[0], M.shape[1], 1, 1, ip(Ap), ip(Aj), dp(Ax))
+        keep.append(m)
+        s.Aalt = C.pointer(m)
+        if desc.get("Dinv") is None:
+            # util/utils.py:526-588 get_diagonal(A, norm_eq=2 | 1, inv=True): squared entries times ones
+            Ms = M.copy() if name != "gauss_seidel_nr" else M.T.tocsr()
+            Ms.sort_indices()
+            D = np.asarray((Ms.multiply(Ms)) * np.ones((Ms.shape[1],))).ravel()
+            Dn = np.zeros_like(D)
+            Dn[D != 0.0] = 1.0 / D[D != 0.0]
+            keep.append(Dn)
+            s.Dinv = dp(Dn)
     if name == "schwarz":
         arrs = [np.ascontiguousarray(desc[k], dtype=np.intc) for k in ("subdomain", "subdomain_ptr", "inv_subblock_ptr")]
         Tx = np.ascontiguousarray(desc["inv_subblock"], dtype=np.float64)
