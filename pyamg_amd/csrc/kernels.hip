@@ -600,6 +600,17 @@ int launch_pattern(StreamMode mode, const StreamArgs &a, const DevCsr &M, hipStr
 // sum runs over the slots whose mask bit is set, in increasing slot order = increasing column =
 // the CSR's stored order, so the result is bit-identical to csr_stream_kernel's.
 // ---------------------------------------------------------------------------
+// operands the stencil kernel reads exactly once per launch (values, masks, right-hand side): loaded
+// non-temporally so that they do not displace the gathered vector in L2 (measured -1.2 % per launch)
+template <class T> __device__ __forceinline__ T stream_load(const T *p)
+{
+#ifndef AMG_STENCIL_PLAIN_LOADS
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+
 struct StencilArgs {
     const double *vals;
     const void *mask;                    // uint8 per row in the NUB == 8 instantiation (|U| <= 7), else uint32;
@@ -637,7 +648,7 @@ __global__ __launch_bounds__(WG) void stencil_kernel(StreamArgs a, StencilArgs E
     for (int u = 0; u < NUB; ++u) {
         v[u] = 0.0; xv[u] = 0.0;
         if (u < E.nu && live) {
-            v[u] = vp[(size_t)u * WG];
+            v[u] = stream_load(&vp[(size_t)u * WG]);
             const long j = (long)i + E.off[u];
             if (j >= 0 && j < E.ncols) xv[u] = a.xg[j];
         }
@@ -645,11 +656,12 @@ __global__ __launch_bounds__(WG) void stencil_kernel(StreamArgs a, StencilArgs E
     unsigned m = 0;
     double bval = 0.0, pre2 = 0.0;
     if (live) {
-        m = (NUB == 8) ? (unsigned)static_cast<const unsigned char *>(E.mask)[i] : static_cast<const unsigned *>(E.mask)[i];
+        m = (NUB == 8) ? (unsigned)stream_load(static_cast<const unsigned char *>(E.mask) + i)
+                       : stream_load(static_cast<const unsigned *>(E.mask) + i);
         if (m & ((NUB == 8) ? 0x80u : 0x80000000u)) m = 0xFFFFFFFFu;          // not covered
         if (MT::sub || MODE == SM_RESIDUAL || MODE == SM_RESIDUAL_SUMSQ || MODE == SM_POLY_STEP ||
             MODE == SM_POLY_LAST || MODE == SM_JACOBI)
-            bval = a.b[i];
+            bval = stream_load(&a.b[i]);
         if (MODE == SM_MATVEC_ACC) pre2 = a.out[i];
         else if (MODE == SM_POLY_LAST || MODE == SM_JACOBI || MODE == SM_JACOBI_BSR1) pre2 = a.v2[i];
     }
