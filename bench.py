@@ -358,18 +358,27 @@ def main():
                 Ah = np.zeros(n)
                 H.lib.oracle_csr_matvec(n, ip(A0c.indptr), ip(A0c.indices), dp(A0c.data), dp(xo), dp(Ah))
                 rn = H.lib.oracle_norm2(dp(b - Ah), n)
-                return time.perf_counter() - t0, rn
+                return time.perf_counter() - t0, rn, xo
 
             # the row-parallel loops of the oracle over the host cores this process may use (same bits
             # for any thread count), then the scalar port
             cores = max(1, min(len(os.sched_getaffinity(0)), 16))      # a 1-GPU box's share of host cores
-            t_par, rn_par = cpu_step(cores)
-            t_cpu, rn = cpu_step(1)
+            t_par, rn_par, xo_par = cpu_step(cores)
+            t_cpu, rn, xo = cpu_step(1)
             H.lib.oracle_set_threads(1)
+            # parity at the full size: the GPU's iterate after one cycle from x0 = 0, entry by entry
+            xg = np.zeros(n)
+            r1 = np.zeros(3); n1 = C.c_int(0)
+            _lib.check(L.amg_hier_solve(h, b.ctypes.data, xg.ctypes.data, 0.0, 1, 0, _lib.dp(r1), C.byref(n1),
+                                        NO_EARLY_STOP | X0_ZERO))
+            iterate_equal = bool(np.array_equal(xg, xo)) and bool(np.array_equal(xo, xo_par))
+            del xo_par, xg
             log("[bench] CPU oracle: 1 step in %.2fs on 1 thread, %.2fs on %d threads, residual %.6e (GPU first step: %.6e)"
                 % (t_cpu, t_par, cores, rn, warm_res[1]))
             first_step_agrees = bool(abs(rn - warm_res[1]) <= 1e-12 * abs(rn)) and rn_par == rn
+            log("[bench] first iterate at full size bit-identical to the oracle's: %s" % iterate_equal)
             cpu = {"value": round(1.0 / t_par, 5), "first_step_residual_equals_gpu": first_step_agrees,
+                   "first_step_iterate_bit_identical_to_gpu": iterate_equal,
                    "unit": "V-cycle iterations/s", "cores": cores, "kind": "port",
                    "sample": "1 V-cycle + residual norm of the same hierarchy and RHS from x0=0 with the C oracle "
                              "(oracle/amg_oracle.c, -O3, row-parallel OpenMP loops: SpMV, Chebyshev and vector "
