@@ -18,6 +18,7 @@ that against the captured hierarchies.
 """
 import ctypes as C
 import os
+import time
 
 import numpy as np
 import scipy.sparse as sparse
@@ -518,6 +519,14 @@ def _extend_scalar(levels, smooth_l, keep, rho_fn):
     B = levels[-1].B
     L = host_lib()
     n = A.shape[0]
+    verbose = os.environ.get("AMG_SETUP_VERBOSE", "0") != "0"
+    _t = [time.perf_counter()]
+
+    def lap(what):
+        if verbose:
+            now = time.perf_counter()
+            print("[setup] level %d (%d rows) %-22s %6.2fs" % (len(levels) - 1, n, what, now - _t[0]), flush=True)
+            _t[0] = now
     Ap, Aj, Ax = _csr_arrays64(A)
     Ap32 = np.ascontiguousarray(A.indptr, dtype=np.intc)
     # strength with theta = 0 keeps every entry: the aggregation only reads the pattern
@@ -525,6 +534,7 @@ def _extend_scalar(levels, smooth_l, keep, rho_fn):
     cpts = np.empty(n, dtype=np.intc)
     n_agg = L.amgsetup_standard_aggregation(n, _ip(Ap32), _ip(Aj), _ip(agg), _ip(cpts))
     del cpts
+    lap("aggregation")
     if n_agg == 0:
         raise ValueError("aggregation produced no aggregates")
     # tentative prolongator
@@ -538,8 +548,10 @@ def _extend_scalar(levels, smooth_l, keep, rho_fn):
     # Jacobi prolongation smoothing: rho(D^-1 A), then P = T - (omega/rho) D^-1 A T
     fn, kw = unpack_arg(smooth_l)
     omega = kw.get("omega", 4.0 / 3.0)
+    lap("tentative prolongator")
     D_inv = get_diagonal(A, inv=True)
     rho = rho_fn(A, D_inv)
+    lap("rho(D^-1 A)")
     w = omega / rho
     Pp = np.empty(n + 1, dtype=np.int64)
     dnull = C.POINTER(C.c_double)()
@@ -554,11 +566,15 @@ def _extend_scalar(levels, smooth_l, keep, rho_fn):
     Rp = np.empty(n_agg + 1, dtype=np.int64)
     Rj = np.empty(pnnz, dtype=np.intc)
     Rx = np.empty(pnnz, dtype=np.float64)
+    lap("smoothed prolongator")
     L.amgsetup_csr_transpose(n, n_agg, _lp(Pp), _ip(Pj), _dp(Px), _lp(Rp), _ip(Rj), _dp(Rx))
+    lap("R = P^T")
     # Galerkin product (R*A)*P
     RA = _matmat((Rp, Rj, Rx), (Ap, Aj, Ax), (n_agg, n))
+    lap("R*A")
     Ac = _matmat(RA, (Pp, Pj, Px), (n_agg, n_agg))
     del RA
+    lap("(R*A)*P")
     P = _as_bsr11((Pp, Pj, Px), (n, n_agg))
     R = _as_bsr11((Rp, Rj, Rx), (n_agg, n))
     Anew = _as_bsr11(Ac, (n_agg, n_agg))
