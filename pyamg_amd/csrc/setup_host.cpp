@@ -123,24 +123,60 @@ void amgsetup_block_gauss_seidel(const int *Ap, const int *Aj, const double *Ax,
 // products rounds exactly like scipy's (and hence the reference's R*A*P).
 // Pass 1: returns per-row upper bounds in Cp64 (as counts, length n_row+1 after
 // prefix sum).  Pass 2 fills Cj/Cx and rewrites Cp64 with the compacted offsets.
+// Per-row accumulator of the SMMP product: a small open-addressing table keyed by output column
+// (sized from the row's upper bound) instead of scipy's dense arrays of length n_col -- at 10^8
+// columns those cost 2 GB per thread to allocate and clear.  What fixes the bits is kept: every
+// output entry accumulates its products in traversal order, and the entries come out in reverse
+// first-touch order (scipy's linked list, walked from its head).
+struct RowTable {
+    std::vector<int> key;        // column, -1 = empty
+    std::vector<double> sum;
+    std::vector<int> order;      // slots in first-touch order
+    unsigned mask = 0;
+    void reserve_for(int64_t upper)
+    {
+        size_t want = 16;
+        while ((int64_t)want < 2 * upper) want <<= 1;
+        if (want > key.size()) { key.assign(want, -1); sum.assign(want, 0.0); }
+        mask = (unsigned)(key.size() - 1);
+        order.clear();
+    }
+    inline int slot_of(int k, bool &fresh)
+    {
+        unsigned h = ((unsigned)k * 2654435761u) & mask;
+        for (;;) {
+            const int c = key[h];
+            if (c == k) { fresh = false; return (int)h; }
+            if (c == -1) { key[h] = k; fresh = true; order.push_back((int)h); return (int)h; }
+            h = (h + 1) & mask;
+        }
+    }
+    void clear_touched()
+    {
+        for (int s : order) { key[(size_t)s] = -1; sum[(size_t)s] = 0.0; }
+        order.clear();
+    }
+};
+
 int64_t amgsetup_csr_matmat_count(int n_row, int n_col, const int64_t *Ap, const int *Aj,
                                   const int64_t *Bp, const int *Bj, int64_t *Cp)
 {
+    (void)n_col;
     Cp[0] = 0;
 #pragma omp parallel
     {
-        std::vector<int> mask((size_t)n_col, -1);
+        RowTable T;
 #pragma omp for schedule(dynamic, 4096)
         for (int i = 0; i < n_row; i++) {
-            int64_t row_nnz = 0;
+            int64_t upper = 0;
+            for (int64_t jj = Ap[i]; jj < Ap[i + 1]; jj++) upper += Bp[Aj[jj] + 1] - Bp[Aj[jj]];
+            T.reserve_for(upper);
             for (int64_t jj = Ap[i]; jj < Ap[i + 1]; jj++) {
                 int j = Aj[jj];
-                for (int64_t kk = Bp[j]; kk < Bp[j + 1]; kk++) {
-                    int k = Bj[kk];
-                    if (mask[k] != i) { mask[k] = i; row_nnz++; }
-                }
+                for (int64_t kk = Bp[j]; kk < Bp[j + 1]; kk++) { bool fresh; T.slot_of(Bj[kk], fresh); }
             }
-            Cp[i + 1] = row_nnz;
+            Cp[i + 1] = (int64_t)T.order.size();
+            T.clear_touched();
         }
     }
     for (int i = 0; i < n_row; i++) Cp[i + 1] += Cp[i];
@@ -151,48 +187,43 @@ int64_t amgsetup_csr_matmat_fill(int n_row, int n_col, const int64_t *Ap, const 
                                  const int64_t *Bp, const int *Bj, const double *Bx, int64_t *Cp, int *Cj,
                                  double *Cx)
 {
+    (void)n_col;
     std::vector<int64_t> actual((size_t)n_row, 0);
 #pragma omp parallel
     {
-        std::vector<int> next((size_t)n_col, -1);
-        std::vector<double> sums((size_t)n_col, 0.0);
+        RowTable T;
 #pragma omp for schedule(dynamic, 4096)
         for (int i = 0; i < n_row; i++) {
-            int head = -2, length = 0;
+            T.reserve_for(Cp[i + 1] - Cp[i]);          // the count pass sized the row exactly
             for (int64_t jj = Ap[i]; jj < Ap[i + 1]; jj++) {
                 int j = Aj[jj];
                 double v = Ax[jj];
                 for (int64_t kk = Bp[j]; kk < Bp[j + 1]; kk++) {
-                    int k = Bj[kk];
-                    sums[k] += v * Bx[kk];
-                    if (next[k] == -1) { next[k] = head; head = k; length++; }
+                    bool fresh;
+                    const int s = T.slot_of(Bj[kk], fresh);
+                    T.sum[(size_t)s] += v * Bx[kk];
                 }
             }
             int64_t nnz = Cp[i];
-            for (int jj = 0; jj < length; jj++) {
-                if (sums[head] != 0) { Cj[nnz] = head; Cx[nnz] = sums[head]; nnz++; }
-                int temp = head;
-                head = next[head];
-                next[temp] = -1;
-                sums[temp] = 0;
+            for (size_t q = T.order.size(); q-- > 0;) {          // reverse first-touch order
+                const int s = T.order[q];
+                if (T.sum[(size_t)s] != 0) { Cj[nnz] = T.key[(size_t)s]; Cx[nnz] = T.sum[(size_t)s]; nnz++; }
             }
             actual[i] = nnz - Cp[i];
+            T.clear_touched();
         }
     }
     // compact rows whose exact-zero results were dropped
     int64_t pos = 0;
-    bool moved = false;
     for (int i = 0; i < n_row; i++) {
         int64_t start = Cp[i], cnt = actual[i];
         if (start != pos) {
-            moved = true;
             std::memmove(Cj + pos, Cj + start, sizeof(int) * (size_t)cnt);
             std::memmove(Cx + pos, Cx + start, sizeof(double) * (size_t)cnt);
         }
         Cp[i] = pos;
         pos += cnt;
     }
-    (void)moved;
     Cp[n_row] = pos;
     return pos;
 }
