@@ -305,6 +305,9 @@ void amg_set_xcd_period(int on);
 /* 1 (default): operators whose rows are subsets of one stencil of <= 32 offsets are applied from
  * the stencil form (padded values + row masks, no indices); 0: from the pattern / CSR forms */
 void amg_set_stencil_form(int on);
+/* 1 (default): runs of narrow Gauss-Seidel dependency levels are swept by one workgroup in one launch;
+ * 0: one launch per level */
+void amg_set_gs_chain(int on);
 /* 1: operators uploaded from now on also get 16-bit column codes (row blocks whose columns fit 16
  * windows of 4096) and the stream kernel reads those; 0 (default): always the 32-bit indices.
  * Lossless; off by default because the measured gain is within +-8 % per operator */

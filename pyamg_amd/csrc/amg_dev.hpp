@@ -128,6 +128,13 @@ int launch_stencil(StreamMode mode, const StreamArgs &a, const DevCsr &M, hipStr
 int stencil_blocks(const StreamArgs &a, const DevCsr &M);   // workgroups (= SM_RESIDUAL_SUMSQ partials) of launch_stencil
 int launch_stencil_build(const DevCsr &M, const int *dict_slot, const unsigned *pat_mask, hipStream_t st);
 int config_epoch();                      // bumped by every set_* knob below
+// Gauss-Seidel: runs of dependency levels of at most gs_chain_max_rows() rows swept by ONE workgroup in
+// one launch (barrier between levels, next level's rows prefetched) instead of a launch per level
+int launch_gs_chain(const DevCsr &G, const int *rowmap, const int *diagpos, const int *level_ptr_dev, int l_first,
+                    int nlevels, bool reverse, bool bsr1, double *x, const double *b, hipStream_t st);
+int gs_chain_max_rows();
+bool gs_chain_enabled();
+void set_gs_chain(int on);
 bool stencil_enabled();
 int launch_index16_build(DevCsr &M, int rpb, hipStream_t st);   // fills Aj16 / wg_base / wg_flag (already allocated)
 bool index16_enabled();

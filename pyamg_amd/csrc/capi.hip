@@ -15,6 +15,9 @@ int spmv(const DevCsr &M, StreamMode mode, const double *xg, const double *b, co
 void expand_bsr(int nbrows, int R, int C, const int *Ap, const int *Aj, const double *Ax,
                 std::vector<int> &cp, std::vector<int> &cj, std::vector<double> &cx);
 }
+namespace amg {
+int gs_sweep_csr(const Schedule &S, bool bsr1, double *x, const double *b, bool reverse, hipStream_t st);
+}
 using namespace amg;
 
 #define CHK(call)                   \
@@ -117,17 +120,8 @@ int check_csr(const int *Ap, int Ap_size, int Aj_size, int Ax_size, int per_entr
 
 int run_csr_levels(const Schedule &S, bool bsr1, double *x, const double *b)
 {
-    StreamArgs a;
-    std::memset(&a, 0, sizeof(a));
-    a.Ap = S.G.Ap; a.Aj = S.G.Aj; a.Ax = S.G.Ax; a.nnz_total = S.G.nnz;
-    a.rows_per_wg = rows_per_wg_for(S.G.nnz, S.G.nrows);
-    a.xg = x; a.b = b; a.out = x; a.rowmap = S.rowmap; a.diagpos = S.diagpos;
-    for (int l = 0; l < S.nlevels(); ++l) {
-        a.row_lo = S.level_ptr[l];
-        a.row_hi = S.level_ptr[l + 1];
-        CHK(launch_stream(bsr1 ? SM_GS_BSR1 : SM_GS, a, nullptr));
-    }
-    return 0;
+    // the schedule lists the tasks in the caller's sweep order: always walked forward
+    return amg::gs_sweep_csr(S, bsr1, x, b, false, nullptr);
 }
 
 int gs_csr_common(const int *Ap, int Ap_size, const int *Aj, const double *Ax, double *x, int x_size,

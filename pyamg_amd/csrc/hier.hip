@@ -340,8 +340,10 @@ void Schedule::release()
     if (rowmap) hipFree(rowmap);
     if (diagpos) hipFree(diagpos);
     if (rows) hipFree(rows);
+    if (level_ptr_dev) hipFree(level_ptr_dev);
     free_bsr(Gb);
-    rowmap = diagpos = rows = nullptr;
+    rowmap = diagpos = rows = level_ptr_dev = nullptr;
+    chains.clear();
 }
 
 int build_levels(int n, const int *Ap, const int *Aj, const int *tasks, int ntasks,
@@ -415,6 +417,23 @@ int build_csr_schedule(const int *Ap, const int *Aj, const double *Ax, int n, co
     CHK(dev_alloc(&S.diagpos, ntasks, (long *)nullptr));
     AMG_HIP(hipMemcpy(S.rowmap, rowmap.data(), sizeof(int) * (size_t)ntasks, hipMemcpyHostToDevice));
     AMG_HIP(hipMemcpy(S.diagpos, dpos.data(), sizeof(int) * (size_t)ntasks, hipMemcpyHostToDevice));
+    // runs of narrow levels for the chained sweep
+    CHK(dev_alloc(&S.level_ptr_dev, (long)S.level_ptr.size(), (long *)nullptr));
+    AMG_HIP(hipMemcpy(S.level_ptr_dev, S.level_ptr.data(), sizeof(int) * S.level_ptr.size(), hipMemcpyHostToDevice));
+    S.chains.clear();
+    // Measured (tools/gs_chain_ab.py): one workgroup beats a launch per level only when the levels are
+    // really small -- a few hundred short rows (2-D 5/9-point operators: -12 % per cycle); on levels of
+    // ~1000 rows or rows of 30 entries (SA coarse levels) it is 1.5-2.5x slower.  Hence the narrow window.
+    const int nl = S.nlevels();
+    const bool short_rows = ntasks > 0 && (double)S.G.nnz <= 10.0 * (double)ntasks;
+    const int max_rows = std::min(512, gs_chain_max_rows());
+    for (int l = 0; short_rows && l < nl;) {
+        if (S.level_ptr[l + 1] - S.level_ptr[l] > max_rows) { ++l; continue; }
+        int e = l;
+        while (e < nl && S.level_ptr[e + 1] - S.level_ptr[e] <= max_rows) ++e;
+        if (e - l >= 4) S.chains.emplace_back(l, e);
+        l = e;
+    }
     return 0;
 }
 
@@ -492,13 +511,28 @@ int gs_sweep_csr(const Schedule &S, bool bsr1, double *x, const double *b, bool 
 {
     StreamArgs a = base_args(S.G);
     a.xg = x; a.b = b; a.out = x; a.rowmap = S.rowmap; a.diagpos = S.diagpos;
-    int nl = S.nlevels();
-    for (int q = 0; q < nl; ++q) {
-        int l = reverse ? nl - 1 - q : q;
-        a.row_lo = S.level_ptr[l];
-        a.row_hi = S.level_ptr[l + 1];
-        CHK(launch_stream(bsr1 ? SM_GS_BSR1 : SM_GS, a, st));
+    const int nl = S.nlevels();
+    auto launches = [&](int l0, int l1) -> int {          // levels [l0, l1), one launch each, in sweep order
+        for (int q = 0; q < l1 - l0; ++q) {
+            const int l = reverse ? l1 - 1 - q : l0 + q;
+            a.row_lo = S.level_ptr[l];
+            a.row_hi = S.level_ptr[l + 1];
+            CHK(launch_stream(bsr1 ? SM_GS_BSR1 : SM_GS, a, st));
+        }
+        return 0;
+    };
+    if (!gs_chain_enabled() || S.chains.empty()) return launches(0, nl);
+    // segments in sweep order: wide levels by launches, runs of narrow levels by one chained launch each
+    const int nc = (int)S.chains.size();
+    int pos = reverse ? nl : 0;
+    for (int c = 0; c < nc; ++c) {
+        const auto &ch = S.chains[(size_t)(reverse ? nc - 1 - c : c)];
+        if (!reverse) { CHK(launches(pos, ch.first)); pos = ch.second; }
+        else { CHK(launches(ch.second, pos)); pos = ch.first; }
+        CHK(launch_gs_chain(S.G, S.rowmap, S.diagpos, S.level_ptr_dev, ch.first, ch.second - ch.first, reverse, bsr1, x, b, st));
     }
+    if (!reverse) CHK(launches(pos, nl));
+    else CHK(launches(0, pos));
     return 0;
 }
 
@@ -1801,6 +1835,7 @@ void amg_set_stream_variant(int v) { amg::set_stream_variant(v); }
 void amg_set_xcd_chunk(int c) { amg::set_xcd_chunk(c); }
 void amg_set_xcd_period(int on) { amg::set_xcd_period(on); }
 void amg_set_stencil_form(int on) { amg::set_stencil_form(on); }
+void amg_set_gs_chain(int on) { amg::set_gs_chain(on); }
 void amg_set_index16(int on) { amg::set_index16(on); }
 void amg_set_tile_target(int t) { amg::set_tile_target(t); }
 void amg_hier_use_graphs(amg_hier *h, int on) { if (h) { h->use_graphs = on; if (!on) drop_graphs(h); } }

@@ -21,6 +21,10 @@ struct Schedule {
     DevCsr G;                     // permuted rows, ORIGINAL column indices
     int *rowmap = nullptr;        // device: original row of permuted row
     int *diagpos = nullptr;       // device: position of the diagonal entry in G (-1 if none)
+    int *level_ptr_dev = nullptr; // device copy of level_ptr (the chained sweep walks the levels on the GPU)
+    // maximal runs [first, last) of consecutive levels that are all narrow enough for ONE workgroup:
+    // such a run is swept by a single launch (gs_chain_kernel) instead of one launch per level
+    std::vector<std::pair<int, int>> chains;
     // BSR flavour: block rows listed in level order
     int *rows = nullptr;          // device
     DevBsr Gb;                    // BSR flavour with values: block rows copied in level order (streamed)

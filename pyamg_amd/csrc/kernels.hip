@@ -351,6 +351,143 @@ __global__ __launch_bounds__(WG) void csr_stream_kernel(StreamArgs a, int xcd_ch
 }
 
 // ---------------------------------------------------------------------------
+// Chained Gauss-Seidel sweep over a run of NARROW dependency levels (each at most CHAIN_WG rows): one
+// workgroup, one launch.  Thread t owns row t of the current level; a barrier separates the levels.
+// What makes a level cheap here is that everything that does not depend on x -- the row's entries, its
+// diagonal and right-hand side -- is requested for the NEXT level before the current one is computed,
+// so the per-level critical path is barrier -> gather x (L2) -> multiply-adds -> store, not the three
+// dependent memory round trips of a fresh launch.  Same per-row arithmetic as SM_GS / SM_GS_BSR1.
+// ---------------------------------------------------------------------------
+constexpr int CHAIN_WG = 1024;
+constexpr int CHAIN_PF = 12;         // entries of a row carried in registers through the pipeline
+constexpr int CHAIN_LMAX = 4096;     // levels per launch (their offsets sit in LDS)
+
+// Software pipeline over the levels (vector-memory loads return in issue order, so what a level waits
+// for must be issued BEFORE anything it does not need yet, and nothing issued late may be waited for in
+// the same iteration):
+//   level q   : gather x for the row whose entries are already in registers, compute, store, barrier
+//   level q+1 : its entries / right-hand side / diagonal are requested after q's gathers were issued,
+//               from row pointers that were requested two iterations ago
+//   level q+3 : its row pointers (and row / diagonal positions) are requested; the level offsets they
+//               need come from LDS (loaded once), not from a dependent global load
+template <bool BSR1>
+__global__ __launch_bounds__(CHAIN_WG) void gs_chain_kernel(const int *Ap, const int *Aj, const double *Ax, const int *rowmap,
+                                                           const int *diagpos, double *x, const double *b,
+                                                           const int *lp, int l_first, int nl, int reverse)
+{
+    const int t = threadIdx.x;
+    volatile double *xs = x;         // re-read every level (values change between barriers)
+    __shared__ int slp[CHAIN_LMAX + 1];
+    for (int k = t; k <= nl; k += CHAIN_WG) slp[k] = lp[l_first + k];
+    __syncthreads();
+    auto level_of = [&](int q) { return reverse ? nl - 1 - q : q; };      // index into slp
+
+    // stage A (row pointers) of a level
+    struct RowRef { int s, e, row, dp; };
+    auto stage_a = [&](int q) -> RowRef {
+        RowRef r{0, 0, -1, -1};
+        if (q < nl) {
+            const int l = level_of(q);
+            const int p = slp[l] + t;
+            if (p < slp[l + 1]) { r.s = Ap[p]; r.e = Ap[p + 1]; r.row = rowmap ? rowmap[p] : p; r.dp = diagpos[p]; }
+        }
+        return r;
+    };
+
+    RowRef cur = stage_a(0);
+    int cc[CHAIN_PF];
+    double cv[CHAIN_PF];
+    double c_b = 0.0, c_d = 0.0;
+    if (cur.row >= 0) {
+        c_b = b[cur.row];
+        c_d = (cur.dp >= 0) ? Ax[cur.dp] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < CHAIN_PF; ++u) {
+        const int k = cur.s + u;
+        cc[u] = (k < cur.e) ? Aj[k] : 0;
+        cv[u] = (k < cur.e) ? Ax[k] : 0.0;
+    }
+    RowRef nxt = stage_a(1);
+    RowRef nx2 = stage_a(2);
+
+    for (int q = 0; q < nl; ++q) {
+        // 1. operands of the current level first
+        double xv[CHAIN_PF];
+#pragma unroll
+        for (int u = 0; u < CHAIN_PF; ++u) xv[u] = (cur.s + u < cur.e) ? xs[cc[u]] : 0.0;
+        // 2. entries of the next level, 3. row pointers of the one after (neither depends on x)
+        int pc[CHAIN_PF];
+        double pv[CHAIN_PF];
+        double n_b = 0.0, n_d = 0.0;
+        if (nxt.row >= 0) {
+            n_b = b[nxt.row];
+            n_d = (nxt.dp >= 0) ? Ax[nxt.dp] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < CHAIN_PF; ++u) {
+            const int k = nxt.s + u;
+            pc[u] = (k < nxt.e) ? Aj[k] : 0;
+            pv[u] = (k < nxt.e) ? Ax[k] : 0.0;
+        }
+        const RowRef aft = stage_a(q + 3);
+        // 4. the row sum in stored order, diagonal skipped
+        if (cur.row >= 0) {
+            double acc = BSR1 ? c_b : 0.0;
+#pragma unroll
+            for (int u = 0; u < CHAIN_PF; ++u) {
+                const int k = cur.s + u;
+                if (k < cur.e && k != cur.dp) {
+                    const double pr = cv[u] * xv[u];
+                    acc = BSR1 ? (acc - pr) : (acc + pr);
+                }
+            }
+            for (int k = cur.s + CHAIN_PF; k < cur.e; ++k) {        // rows longer than the register window
+                if (k == cur.dp) continue;
+                const double pr = Ax[k] * xs[Aj[k]];
+                acc = BSR1 ? (acc - pr) : (acc + pr);
+            }
+            if (c_d != 0.0) xs[cur.row] = BSR1 ? (acc / c_d) : ((c_b - acc) / c_d);
+        }
+        // One workgroup = one CU: its waves share the L1, so workgroup-scope ordering (what __syncthreads
+        // provides: stores complete, then the barrier) is all the next level needs -- no cache maintenance
+        __syncthreads();
+        cur = nxt; c_b = n_b; c_d = n_d;
+#pragma unroll
+        for (int u = 0; u < CHAIN_PF; ++u) { cc[u] = pc[u]; cv[u] = pv[u]; }
+        nxt = nx2;
+        nx2 = aft;
+    }
+}
+
+static int g_gs_chain = 1;
+void set_gs_chain(int on) { g_gs_chain = on; ++g_config_epoch; }
+bool gs_chain_enabled() { return g_gs_chain != 0; }
+int gs_chain_max_rows() { return CHAIN_WG; }
+
+int launch_gs_chain(const DevCsr &G, const int *rowmap, const int *diagpos, const int *level_ptr_dev, int l_first,
+                    int nlevels, bool reverse, bool bsr1, double *x, const double *b, hipStream_t st)
+{
+    if (nlevels <= 0) return 0;
+    // at most CHAIN_LMAX levels per launch, pieces in sweep order
+    const int npiece = (nlevels + CHAIN_LMAX - 1) / CHAIN_LMAX;
+    for (int c = 0; c < npiece; ++c) {
+        const int piece = reverse ? npiece - 1 - c : c;
+        const int lf = l_first + piece * CHAIN_LMAX;
+        const int cnt = std::min(CHAIN_LMAX, nlevels - piece * CHAIN_LMAX);
+        if (bsr1)
+            hipLaunchKernelGGL((gs_chain_kernel<true>), dim3(1), dim3(CHAIN_WG), 0, st, G.Ap, G.Aj, G.Ax, rowmap, diagpos, x, b,
+                               level_ptr_dev, lf, cnt, reverse ? 1 : 0);
+        else
+            hipLaunchKernelGGL((gs_chain_kernel<false>), dim3(1), dim3(CHAIN_WG), 0, st, G.Ap, G.Aj, G.Ax, rowmap, diagpos, x, b,
+                               level_ptr_dev, lf, cnt, reverse ? 1 : 0);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "gs chain launch", __FILE__, __LINE__);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
 // csr_pattern: the same operator application for matrices whose rows repeat a few column-offset
 // patterns (stencil operators: 27 patterns for a 7-point grid operator with boundaries).  Only the
 // values are streamed (8 B per entry, 16-byte loads through the same LDS tile); a row's columns

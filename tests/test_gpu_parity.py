@@ -840,3 +840,35 @@ def test_schwarz_definition_on_small_systems():
             want = textbook(A, x.copy(), b, order)
             relaxation.schwarz(A, x, b, iterations=1, sweep=sweep)
             assert np.allclose(x, want, rtol=1e-7, atol=1e-9), (n, sweep)
+
+
+def test_chained_gauss_seidel_equals_per_level_launches():
+    """Runs of narrow dependency levels are swept by one workgroup in one launch (gs_chain_kernel).  Same
+    bits as one launch per level and as the sequential oracle: 2-D 5-point operator (every level narrow),
+    3-D 7-point (narrow runs at both ends of the sweep, wide levels in between), CSR and BSR(1,1)
+    rounding flavours, forward / backward / symmetric."""
+    import scipy.sparse as sp
+    from pyamg_amd import _lib
+    from pyamg_amd.aggregation import poisson as native
+    rng = np.random.RandomState(23)
+    for dims in ((90, 70), (40, 45, 50)):
+        A = native(dims)
+        n = A.shape[0]
+        b = rng.rand(n)
+        for M in (A, sp.bsr_matrix(A, blocksize=(1, 1))):
+            for sweep in ("forward", "backward", "symmetric"):
+                out = {}
+                for on in (1, 0):
+                    _lib.lib().amg_set_gs_chain(on)
+                    x = np.linspace(0.0, 1.0, n)
+                    relaxation.gauss_seidel(M, x, b, iterations=2, sweep=sweep)
+                    out[on] = x
+                _lib.lib().amg_set_gs_chain(1)
+                assert np.array_equal(out[0], out[1]), (dims, type(M).__name__, sweep)
+                xo = np.linspace(0.0, 1.0, n)
+                keep = []
+                m = oracle_lib.make_mat(M, keep)
+                s = oracle_lib.make_smoother({"name": "gauss_seidel", "iterations": 2, "sweep": sweep}, M, keep)
+                import ctypes as C
+                oracle_lib.load().oracle_relax(C.byref(m), C.byref(s), oracle_lib.dp(xo), oracle_lib.dp(b))
+                assert np.array_equal(out[1], xo), (dims, type(M).__name__, sweep)
