@@ -158,6 +158,8 @@ def lib():
     L.amg_set_tile_target.restype = None
     L.amg_set_index16.argtypes = [I]
     L.amg_set_index16.restype = None
+    L.amg_set_bsr_spmv.argtypes = [I]
+    L.amg_set_bsr_spmv.restype = None
     L.amg_set_gs_chain.argtypes = [I]
     L.amg_set_gs_chain.restype = None
     L.amg_set_stencil_form.argtypes = [I]

@@ -22,6 +22,7 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line);
 // bounds.
 constexpr int PAD = 16;
 
+struct DevBsr;
 struct DevCsr {
     int nrows = 0, ncols = 0;
     long nnz = 0;
@@ -29,6 +30,9 @@ struct DevCsr {
     int *Aj = nullptr;
     double *Ax = nullptr;
     bool owned = true;
+    // The operator's own square blocks (a BSR level of the hierarchy), not owned: when set, applications
+    // stream 8 B per entry + 4 B per block from there instead of 12 B per entry from the expanded CSR
+    const DevBsr *blk = nullptr;
     // Offset-pattern form of the column indices (square operators on structured grids): row i's
     // columns are i + dict_off[dict_ptr[pat[i]] .. ], with a dictionary of a few distinct offset
     // tuples.  When present, the pattern kernel streams 8 B per entry + 4 B per row instead of
@@ -173,7 +177,8 @@ int launch_combine(double *out, const double *V, const double *coef_dev, int m, 
 int launch_dense_apply(const double *Mt, const double *b, double *x, int n, hipStream_t st);
 
 // ---------------------------------------------------------------- BSR kernels (one thread per block row)
-enum BlockMode { BM_BSR_JACOBI, BM_BLOCK_JACOBI, BM_BSR_GS, BM_BLOCK_GS };
+enum BlockMode { BM_BSR_JACOBI, BM_BLOCK_JACOBI, BM_BSR_GS, BM_BLOCK_GS,
+                 BM_SPMV };   // operator application straight from the blocks (scipy bsr_matvec order); epilogue = smode
 struct BlockArgs {
     const int *Ap; const int *Aj; const double *Ax;   // BSR arrays (blocks row-major bs x bs)
     int bs;
@@ -200,7 +205,15 @@ struct BsrStreamArgs {
     const double *b;
     const double *Dinv;
     double omega;
+    // BM_SPMV: epilogue (SM_MATVEC, SM_MATVEC_ACC, SM_RESIDUAL, SM_POLY_STEP, SM_POLY_LAST), its second
+    // streamed vector / coefficient, and the on-the-fly operand scaling of the polynomial smoother
+    int smode;
+    const double *v2;
+    double c0, gscale;
 };
+bool bsr_spmv_supports(StreamMode mode);
+bool bsr_spmv_enabled(int bs);
+void set_bsr_spmv(int on);
 int launch_bsr_stream(BlockMode m, const BsrStreamArgs &a, long nblocks_hint, hipStream_t st);
 
 }  // namespace amg

@@ -483,6 +483,17 @@ static StreamArgs base_args(const DevCsr &M)
 // the storage form an operator application runs from: stencil, offset-pattern or plain CSR
 int apply_operator(const DevCsr &M, StreamMode mode, const StreamArgs &a, hipStream_t st)
 {
+    if (M.blk && M.blk->Ap && bsr_spmv_enabled(M.blk->bs) && bsr_spmv_supports(mode) && a.row_lo == 0 && a.row_hi == M.nrows) {
+        const DevBsr &B = *M.blk;
+        BsrStreamArgs q;
+        std::memset(&q, 0, sizeof(q));
+        q.Ap = B.Ap; q.Aj = B.Aj; q.Ax = B.Ax; q.bs = B.bs;
+        q.brow_lo = 0; q.brow_hi = B.nbrows;
+        q.xin = a.xg; q.xout = a.out; q.b = a.b; q.v2 = a.v2; q.c0 = a.c0;
+        q.gscale = (a.gscale == 0.0) ? 1.0 : a.gscale;
+        q.smode = (int)mode;
+        return launch_bsr_stream(BM_SPMV, q, B.nblocks, st);
+    }
     if (M.st_vals && stencil_enabled() && pattern_supports(mode)) return launch_stencil(mode, a, M, st);
     if (M.pat && pattern_supports(mode)) return launch_pattern(mode, a, M, st);
     return launch_stream(mode, a, st);
@@ -1109,8 +1120,10 @@ int amg_hier_set_matrix(amg_hier *h, int lvl, int which, int fmt, int nrows, int
         if (nrows != ncols) { set_error("A must be square"); return AMG_EINVAL; }
         L.fmt = fmt; L.R = R; L.C = C; L.hasA = true;
         free_bsr(L.Ab);
-        if (fmt == AMG_FMT_BSR && R == C && R > 1)
+        if (fmt == AMG_FMT_BSR && R == C && R > 1) {
             CHK(upload_bsr(L.Ab, nrows / R, R, Ap, Aj, Ax, &h->dev_bytes));
+            L.A.blk = &L.Ab;           // applications of A stream the blocks (levels live in a vector sized once)
+        }
     } else if (which == AMG_MAT_P) {
         L.hasP = true;
     } else {
@@ -1697,7 +1710,7 @@ int amg_hier_time_spmv(amg_hier *h, int lvl, int which, int mode, int reps, doub
     else { in = L.r; out = h->lv[lvl + 1].b; }
     StreamMode sm = ((mode & 1) && which == AMG_MAT_A) ? SM_RESIDUAL : SM_MATVEC;
     DevCsr Mplain = M;                     // mode bit 1 (value 2): time the plain CSR kernel even if
-    if (mode & 2) { Mplain.pat = nullptr; Mplain.st_vals = nullptr; Mplain.Aj16 = nullptr; }   // the operator has derived forms;
+    if (mode & 2) { Mplain.pat = nullptr; Mplain.st_vals = nullptr; Mplain.Aj16 = nullptr; Mplain.blk = nullptr; }   // the operator has derived forms;
     if (mode & 4) Mplain.st_vals = nullptr;                             // bit 2 (value 4): the pattern kernel
     const DevCsr &Mu = (mode & 6) ? Mplain : M;
     CHK(spmv(Mu, sm, in, L.b, nullptr, out, nullptr, 0.0, h->stream));   // warm-up
@@ -1836,6 +1849,7 @@ void amg_set_xcd_chunk(int c) { amg::set_xcd_chunk(c); }
 void amg_set_xcd_period(int on) { amg::set_xcd_period(on); }
 void amg_set_stencil_form(int on) { amg::set_stencil_form(on); }
 void amg_set_gs_chain(int on) { amg::set_gs_chain(on); }
+void amg_set_bsr_spmv(int on) { amg::set_bsr_spmv(on); }
 void amg_set_index16(int on) { amg::set_index16(on); }
 void amg_set_tile_target(int t) { amg::set_tile_target(t); }
 void amg_hier_use_graphs(amg_hier *h, int on) { if (h) { h->use_graphs = on; if (!on) drop_graphs(h); } }

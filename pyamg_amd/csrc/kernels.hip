@@ -1552,18 +1552,53 @@ __global__ __launch_bounds__(WG) void bsr_stream_kernel(BsrStreamArgs a, int rpb
     for (int tb = bbeg; tb < bend; tb += tile_blocks) {
         const int te = min(tb + tile_blocks, bend);
         const long ebase = (long)tb * B2, ecount = (long)(te - tb) * B2;
-        for (long q = t; q < ecount; q += WG) {
-            const int lb = (int)(q / B2);
-            const int rc = (int)(q - (long)lb * B2);
-            const int c = rc % bs;
-            const int col = a.Aj[tb + lb];
-            if (rc == 0) sbj[lb] = col;
-            sp[q] = a.Ax[ebase + q] * a.xin[(long)col * bs + c];
+        // block columns of the tile into LDS (one load per block, not per entry), the values in one batch
+        // of independent requests, then all gathers, then the products
+        constexpr int U = TILE / WG;
+        double av[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long q = (long)u * WG + t;
+            av[u] = (q < ecount) ? a.Ax[ebase + q] : 0.0;
+        }
+        for (int lb = t; lb < te - tb; lb += WG) sbj[lb] = a.Aj[tb + lb];
+        __syncthreads();
+        int colv[U], cv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long q = (long)u * WG + t;
+            colv[u] = 0; cv[u] = 0;
+            if (q < ecount) {
+                const int lb = (int)(q / B2);
+                cv[u] = (int)(q - (long)lb * B2) % bs;
+                colv[u] = sbj[lb];
+            }
+        }
+        double xv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long q = (long)u * WG + t;
+            xv[u] = (q < ecount) ? a.xin[(long)colv[u] * bs + cv[u]] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long q = (long)u * WG + t;
+            if (q < ecount) {
+                if (BMODE == BM_SPMV) sp[q] = av[u] * (a.gscale * xv[u]);
+                else sp[q] = av[u] * xv[u];
+            }
         }
         __syncthreads();
         if (active) {
             const int s = max(my_s, tb), e = min(my_e, te);
             for (int jj = s; jj < e; ++jj) {
+                if (BMODE == BM_SPMV) {
+                    // scipy bsr_matvec: ONE running sum per scalar row, across the blocks and the
+                    // columns inside each block -- the order of the expanded CSR row
+                    const double *p = &sp[(long)(jj - tb) * B2 + r * bs];
+                    for (int c = 0; c < bs; ++c) rsum = rsum + p[c];
+                    continue;
+                }
                 if (sbj[jj - tb] == brow) { dptr = (long)jj * B2; continue; }
                 const double *p = &sp[(long)(jj - tb) * B2 + r * bs];
                 double v = 0.0;
@@ -1574,7 +1609,16 @@ __global__ __launch_bounds__(WG) void bsr_stream_kernel(BsrStreamArgs a, int rpb
         __syncthreads();
     }
 
-    if (BMODE == BM_BLOCK_JACOBI || BMODE == BM_BLOCK_GS) {
+    if (BMODE == BM_SPMV) {
+        if (!active) return;
+        const long i = ib + r;
+        if (a.smode == SM_MATVEC) a.xout[i] = rsum;
+        else if (a.smode == SM_MATVEC_ACC) a.xout[i] = a.xout[i] + rsum;
+        else if (a.smode == SM_RESIDUAL) a.xout[i] = a.b[i] - rsum;
+        else if (a.smode == SM_POLY_STEP) { double cr = a.c0 * a.b[i]; a.xout[i] = cr + rsum; }
+        else if (a.smode == SM_POLY_LAST) { double cr = a.c0 * a.b[i]; double h = cr + rsum; a.xout[i] = a.v2[i] + h; }
+        return;
+    } else if (BMODE == BM_BLOCK_JACOBI || BMODE == BM_BLOCK_GS) {
         if (active) st[t] = a.b[ib + r] - rsum;
         __syncthreads();
         if (active) {
@@ -1627,6 +1671,16 @@ __global__ __launch_bounds__(WG) void bsr_stream_kernel(BsrStreamArgs a, int rpb
     }
 }
 
+// 0 never, 1 when it pays (blocks of 4x4 and larger: measured -11 % at bs = 6, break-even at 3, +7 % at 2
+// against the CSR expansion, tools/bsr_spmv_ab.py), 2 always
+static int g_bsr_spmv = 1;
+void set_bsr_spmv(int on) { g_bsr_spmv = on; ++g_config_epoch; }
+bool bsr_spmv_enabled(int bs) { return g_bsr_spmv == 2 || (g_bsr_spmv == 1 && bs >= 4); }
+bool bsr_spmv_supports(StreamMode mode)
+{
+    return mode == SM_MATVEC || mode == SM_MATVEC_ACC || mode == SM_RESIDUAL || mode == SM_POLY_STEP || mode == SM_POLY_LAST;
+}
+
 int launch_bsr_stream(BlockMode m, const BsrStreamArgs &a, long nblocks_hint, hipStream_t st)
 {
     const int rows = a.brow_hi - a.brow_lo;
@@ -1656,6 +1710,7 @@ int launch_bsr_stream(BlockMode m, const BsrStreamArgs &a, long nblocks_hint, hi
     case BM_BLOCK_JACOBI: BSR_BY_BS(BM_BLOCK_JACOBI); break;
     case BM_BSR_GS: BSR_BY_BS(BM_BSR_GS); break;
     case BM_BLOCK_GS: BSR_BY_BS(BM_BLOCK_GS); break;
+    case BM_SPMV: BSR_BY_BS(BM_SPMV); break;
     }
 #undef BSR_BY_BS
 #undef BSR_LAUNCH
@@ -1675,6 +1730,7 @@ int launch_block(BlockMode m, const BlockArgs &a, hipStream_t st)
     case BM_BLOCK_JACOBI: hipLaunchKernelGGL(block_kernel<BM_BLOCK_JACOBI>, g, b, 0, st, a); break;
     case BM_BSR_GS: hipLaunchKernelGGL(block_kernel<BM_BSR_GS>, g, b, 0, st, a); break;
     case BM_BLOCK_GS: hipLaunchKernelGGL(block_kernel<BM_BLOCK_GS>, g, b, 0, st, a); break;
+    default: set_error("block kernel: mode not supported"); return -5;
     }
     LAUNCH_CHECK("block kernel");
 }

@@ -872,3 +872,40 @@ def test_chained_gauss_seidel_equals_per_level_launches():
                 import ctypes as C
                 oracle_lib.load().oracle_relax(C.byref(m), C.byref(s), oracle_lib.dp(xo), oracle_lib.dp(b))
                 assert np.array_equal(out[1], xo), (dims, type(M).__name__, sweep)
+
+
+def test_bsr_native_operator_application():
+    """A of a BSR(bs,bs) level is applied from its blocks (8 B per entry + 4 B per block) instead of from
+    the CSR expansion: scipy's bsr_matvec keeps one running sum per scalar row across blocks and block
+    columns, and so does the kernel -- same bits as the expansion, as scipy, and whole elasticity / bs=3
+    solves unchanged."""
+    import scipy.sparse as sp
+    from pyamg_amd import _lib
+    from pyamg_amd.aggregation import poisson as native
+    from pyamg_amd.util import _DeviceOperator
+    rng = np.random.RandomState(31)
+    for bs in (2, 3, 4, 5):
+        Mb = rng.randn(bs, bs)
+        A = sp.kron(native((11, 12, 13)), Mb).tobsr((bs, bs))
+        A.sort_indices()
+        A.data = A.data * (1.0 + 0.1 * rng.rand(*A.data.shape))       # every block different
+        op = _DeviceOperator(A)
+        _lib.check(_lib.lib().amg_hier_finalize(op.h))
+        v = rng.rand(A.shape[0])
+        y = np.zeros(A.shape[0])
+        for on in (2, 0):
+            _lib.lib().amg_set_bsr_spmv(on)
+            _lib.check(_lib.lib().amg_hier_matvec(op.h, 0, 0, _lib.dp(v), _lib.dp(y)))
+            assert np.array_equal(y, A * v), (bs, on)
+        _lib.lib().amg_set_bsr_spmv(1)
+        op.close()
+    for case in ("elas_bjac_2d", "bs3_bgs_2d", "elas_gs_2d"):
+        g = golden_io.load_hier(case)
+        ml = golden_io.build_ml(g)
+        got = {}
+        for on in (2, 0):
+            _lib.lib().amg_set_bsr_spmv(on)
+            res = []
+            got[on] = (ml.solve(g["b"], x0=g["x0"], tol=0.0, maxiter=4, residuals=res), np.array(res))
+        _lib.lib().amg_set_bsr_spmv(1)
+        assert np.array_equal(got[0][0], got[2][0]) and np.array_equal(got[0][1], got[2][1]), case
