@@ -310,7 +310,7 @@ void amg_set_stencil_form(int on);
 void amg_set_gs_chain(int on);
 /* A of a BSR(bs,bs) level can be applied straight from its blocks (8 B per entry + 4 B per block) instead
  * of from the CSR expansion (12 B per entry); same summation order, same bits.  0: never, 1 (default):
- * for blocks of 4x4 and larger (where it is measured faster), 2: always */
+ * for blocks of 3x3 and larger (where it is measured faster), 2: always */
 void amg_set_bsr_spmv(int on);
 /* 1: operators uploaded from now on also get 16-bit column codes (row blocks whose columns fit 16
  * windows of 4096) and the stream kernel reads those; 0 (default): always the 32-bit indices.

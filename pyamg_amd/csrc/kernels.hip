@@ -1536,7 +1536,7 @@ __global__ __launch_bounds__(WG) void bsr_stream_kernel(BsrStreamArgs a, int rpb
     for (int i = t; i <= nr; i += WG) sAp[i] = a.Ap[r0 + i];
     __syncthreads();
     const int bbeg = sAp[0], bend = sAp[nr];
-    const int tile_blocks = TILE / B2;
+    const int tile_blocks = (TILE - 1) / B2;     // one spare slot: the 16-byte loads may start one entry early
 
     const int li = t / bs, r = t - li * bs;
     const bool active = li < nr;
@@ -1554,21 +1554,30 @@ __global__ __launch_bounds__(WG) void bsr_stream_kernel(BsrStreamArgs a, int rpb
         const long ebase = (long)tb * B2, ecount = (long)(te - tb) * B2;
         // block columns of the tile into LDS (one load per block, not per entry), the values in one batch
         // of independent requests, then all gathers, then the products
+        // Values by 16-byte loads: lane t of pair-batch h holds the entries 2(h*WG + t) - off + {0, 1}, where
+        // off = ebase & 1 moves the origin down to a 16-byte boundary (arrays are padded at both ends of
+        // what is read: entry ebase-1 exists whenever off == 1).
         constexpr int U = TILE / WG;
+        const int off = (int)(ebase & 1);
+        const double *vbase = a.Ax + (ebase - off);
         double av[U];
+        long qv[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const long q = (long)u * WG + t;
-            av[u] = (q < ecount) ? a.Ax[ebase + q] : 0.0;
+        for (int h = 0; h < U / 2; ++h) {
+            const long j2 = 2 * ((long)h * WG + t);                   // position in the shifted stream
+            v2d v = v2d{0.0, 0.0};
+            if (j2 < ecount + off) v = *reinterpret_cast<const v2d *>(vbase + j2);
+            av[2 * h] = v.x; av[2 * h + 1] = v.y;
+            qv[2 * h] = j2 - off; qv[2 * h + 1] = j2 + 1 - off;       // entry index inside the tile (may be -1 / >= ecount)
         }
         for (int lb = t; lb < te - tb; lb += WG) sbj[lb] = a.Aj[tb + lb];
         __syncthreads();
         int colv[U], cv[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const long q = (long)u * WG + t;
+            const long q = qv[u];
             colv[u] = 0; cv[u] = 0;
-            if (q < ecount) {
+            if (q >= 0 && q < ecount) {
                 const int lb = (int)(q / B2);
                 cv[u] = (int)(q - (long)lb * B2) % bs;
                 colv[u] = sbj[lb];
@@ -1577,13 +1586,13 @@ __global__ __launch_bounds__(WG) void bsr_stream_kernel(BsrStreamArgs a, int rpb
         double xv[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const long q = (long)u * WG + t;
-            xv[u] = (q < ecount) ? a.xin[(long)colv[u] * bs + cv[u]] : 0.0;
+            const long q = qv[u];
+            xv[u] = (q >= 0 && q < ecount) ? a.xin[(long)colv[u] * bs + cv[u]] : 0.0;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const long q = (long)u * WG + t;
-            if (q < ecount) {
+            const long q = qv[u];
+            if (q >= 0 && q < ecount) {
                 if (BMODE == BM_SPMV) sp[q] = av[u] * (a.gscale * xv[u]);
                 else sp[q] = av[u] * xv[u];
             }
@@ -1671,11 +1680,11 @@ __global__ __launch_bounds__(WG) void bsr_stream_kernel(BsrStreamArgs a, int rpb
     }
 }
 
-// 0 never, 1 when it pays (blocks of 4x4 and larger: measured -11 % at bs = 6, break-even at 3, +7 % at 2
-// against the CSR expansion, tools/bsr_spmv_ab.py), 2 always
+// 0 never, 1 when it pays (blocks of 3x3 and larger: measured -19 % at bs = 3, -9 % at bs = 6, break-even at
+// bs = 2 against the CSR expansion, tools/bsr_spmv_ab.py), 2 always
 static int g_bsr_spmv = 1;
 void set_bsr_spmv(int on) { g_bsr_spmv = on; ++g_config_epoch; }
-bool bsr_spmv_enabled(int bs) { return g_bsr_spmv == 2 || (g_bsr_spmv == 1 && bs >= 4); }
+bool bsr_spmv_enabled(int bs) { return g_bsr_spmv == 2 || (g_bsr_spmv == 1 && bs >= 3); }
 bool bsr_spmv_supports(StreamMode mode)
 {
     return mode == SM_MATVEC || mode == SM_MATVEC_ACC || mode == SM_RESIDUAL || mode == SM_POLY_STEP || mode == SM_POLY_LAST;
