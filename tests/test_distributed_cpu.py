@@ -51,6 +51,7 @@ def _worker(rank, world, port, case, cycle, out_dir, replicate_below=0):
 
 @pytest.mark.parametrize("case,world,rep", [("sa_jacobi_2d", 2, 0), ("sa_cheb2_3d", 2, 0), ("sa_cheb2_3d", 3, 0),
                                             ("sa_jacobi_2d", 2, 300), ("sa_cheb2_3d", 3, 600), ("sa_cheb2_3d", 2, 20),
+                                            ("sa_cheb2_3d", 4, 600), ("sa_cheb2_3d", 8, 600), ("sa_jacobi_2d", 8, 0),
                                             ("sa_mixed_W_2d", None, 0)])
 def test_partitioned_cycle_equals_single_process(case, world, rep, tmp_path):
     g = golden_io.load_hier(case)
@@ -75,7 +76,8 @@ def test_partitioned_cycle_equals_single_process(case, world, rep, tmp_path):
     tol = golden_io.history_tolerance(g["levels"][0]["A"], g["x"], g["b"], g["residuals"])
     assert np.all(np.abs(res - g["residuals"]) <= tol)
     assert np.load(tmp_path / "halo.npy")[0] > 0          # the ranks really exchanged halos
-    assert np.load(tmp_path / "overlap.npy")[0] == 1      # ... with the interior rows overlapped on level 0
+    if world <= 3:                                        # (with 8 ranks a slab is all boundary: no window)
+        assert np.load(tmp_path / "overlap.npy")[0] == 1  # ... with the interior rows overlapped on level 0
 
 
 def test_split_rows_and_local_rows():
