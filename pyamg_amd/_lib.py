@@ -120,6 +120,8 @@ def lib():
     L.amg_hier_destroy.restype = None
     L.amg_hier_cycle_bytes.argtypes = [V, I]
     L.amg_hier_cycle_bytes.restype = D
+    L.amg_hier_value_index.argtypes = [V, I, I]
+    L.amg_hier_value_index.restype = I
     L.amg_hier_operator_form.argtypes = [V, I]
     L.amg_hier_operator_form.restype = I
     L.amg_hier_operator_bytes.argtypes = [V, I, I]

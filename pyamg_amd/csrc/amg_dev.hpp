@@ -55,6 +55,13 @@ struct DevCsr {
     // contiguous row ranges that the offset-pattern kernel applies after the stencil launch.
     int st_nranges = 0;
     int st_range[8][2] = {{0}};
+    // Value index on top of the stencil form (opt-in, amg_hier_value_index): when the operator holds at
+    // most 255 distinct values (constant-coefficient stencils), slot u of row i stores a one-byte code
+    // into a dictionary kept in LDS instead of the 8-byte value -- the product uses the very same double.
+    unsigned char *st_codes = nullptr;   // 8 slots per 64-bit word: [nblocks256][ceil(st_nu / 8)][256] words
+    double *st_dict = nullptr;           // [256]
+    int st_ndict = 0;
+    bool st_vi_on = false;
     // 16-bit column codes for csr_stream_kernel (irregular operators: coarse A_l, P_l, R_l).  The
     // columns one workgroup's rows reference fall into a few narrow clusters; when at most 16
     // aligned windows of 4096 columns cover them, entry k is stored as (window slot << 12) | (column
@@ -131,6 +138,10 @@ bool pattern_supports(StreamMode mode);
 int launch_stencil(StreamMode mode, const StreamArgs &a, const DevCsr &M, hipStream_t st);
 int stencil_blocks(const StreamArgs &a, const DevCsr &M);   // workgroups (= SM_RESIDUAL_SUMSQ partials) of launch_stencil
 int launch_stencil_build(const DevCsr &M, const int *dict_slot, const unsigned *pat_mask, hipStream_t st);
+// value index: distinct values of st_vals into a 1024-slot table (EMPTY = all ones), then the byte codes
+int launch_value_scan(const double *vals, long count, unsigned long long *table, int *overflow, hipStream_t st);
+int launch_value_encode(const double *vals, long count, const double *dict_sorted, int ndict, unsigned char *codes, int nu,
+                        hipStream_t st);
 int config_epoch();                      // bumped by every set_* knob below
 // Gauss-Seidel: runs of dependency levels of at most gs_chain_max_rows() rows swept by ONE workgroup in
 // one launch (barrier between levels, next level's rows prefetched) instead of a launch per level

@@ -52,6 +52,8 @@ void free_csr(DevCsr &M)
     if (M.dict_off) hipFree(M.dict_off);
     if (M.st_vals) hipFree(M.st_vals);
     if (M.st_mask) hipFree(M.st_mask);
+    if (M.st_codes) hipFree(M.st_codes);
+    if (M.st_dict) hipFree(M.st_dict);
     if (M.Aj16) hipFree(M.Aj16);
     if (M.wg_base) hipFree(M.wg_base);
     if (M.wg_flag) hipFree(M.wg_flag);
@@ -1629,8 +1631,8 @@ static double smoother_apps(const Smoother &s, bool x_zero)
 // streams the values, one pattern id per row and the row pointer; the column indices are implied.
 static double bytes_spmv_moved(const DevCsr &M)
 {
-    if (M.st_vals && stencil_enabled())     // padded values + one mask word per row; no row pointer
-        return 8.0 * (double)M.st_nu * 256.0 * (double)((M.nrows + 255) / 256) + (M.st_nu <= 7 ? 1.0 : 4.0) * M.nrows +
+    if (M.st_vals && stencil_enabled())     // padded values (or one-byte codes) + one mask word per row; no row pointer
+        return ((M.st_vi_on && M.st_codes) ? 8.0 * (double)((M.st_nu + 7) / 8) : 8.0 * (double)M.st_nu) * 256.0 * (double)((M.nrows + 255) / 256) + (M.st_nu <= 7 ? 1.0 : 4.0) * M.nrows +
                8.0 * M.ncols + 8.0 * M.nrows;
     if (!M.pat) {
         double idx = (M.Aj16 && index16_enabled()) ? (2.0 * M.i16_frac + 4.0 * (1.0 - M.i16_frac)) : 4.0;
@@ -1671,6 +1673,50 @@ static double cycle_bytes_impl(amg_hier *h, int cyc, bool moved)
     double ncs = h->lv[h->nlevels - 1].A.nrows;
     total += visits[h->nlevels - 1] * (8.0 * ncs * ncs + 16.0 * ncs);
     return total;
+}
+
+/* Value index of level lvl's operator (amg_dev.hpp, DevCsr::st_codes).  on != 0: build it if the operator is in
+ * stencil form and holds at most 255 distinct values, and use it; returns the number of distinct values, 0
+ * when not applicable.  on == 0: back to the 8-byte values. */
+int amg_hier_value_index(amg_hier *h, int lvl, int on)
+{
+    ENTER(h);
+    if (lvl < 0 || lvl >= h->nlevels) { set_error("bad level"); return AMG_EINVAL; }
+    DevCsr &M = h->lv[lvl].A;
+    drop_graphs(h);
+    if (!on) { M.st_vi_on = false; return 0; }
+    if (!M.st_vals) return 0;
+    if (M.st_codes) { M.st_vi_on = true; return M.st_ndict; }
+    const long count = (long)((M.nrows + 255) / 256) * M.st_nu * 256;
+    unsigned long long *table = nullptr;
+    int *ovf = nullptr;
+    if (dev_alloc(&table, 1024, nullptr) != 0 || dev_alloc(&ovf, 1, nullptr) != 0) return AMG_ENOMEM;
+    AMG_HIP(hipMemset(table, 0xFF, sizeof(unsigned long long) * 1024));
+    AMG_HIP(hipDeviceSynchronize());
+    int rc = launch_value_scan(M.st_vals, count, table, ovf, h->stream);
+    std::vector<unsigned long long> tb(1024);
+    int overflow = 0;
+    AMG_HIP(hipStreamSynchronize(h->stream));
+    AMG_HIP(hipMemcpy(tb.data(), table, sizeof(unsigned long long) * 1024, hipMemcpyDeviceToHost));
+    AMG_HIP(hipMemcpy(&overflow, ovf, sizeof(int), hipMemcpyDeviceToHost));
+    hipFree(table); hipFree(ovf);
+    if (rc != 0) return AMG_ESTATE;
+    std::vector<long long> bits;
+    for (unsigned long long v : tb) if (v != ~0ULL) bits.push_back((long long)v);
+    if (overflow || bits.empty() || bits.size() > 255) return 0;          // not a few-valued operator
+    std::sort(bits.begin(), bits.end());
+    std::vector<double> dict(256, 0.0);
+    for (size_t k = 0; k < bits.size(); ++k) std::memcpy(&dict[k], &bits[k], sizeof(double));
+    if (dev_alloc(&M.st_dict, 256, &h->dev_bytes) != 0) return AMG_ENOMEM;
+    AMG_HIP(hipMemcpy(M.st_dict, dict.data(), sizeof(double) * 256, hipMemcpyHostToDevice));
+    const long code_bytes = (long)((M.nrows + 255) / 256) * ((M.st_nu + 7) / 8) * 256 * 8;
+    if (dev_alloc(&M.st_codes, code_bytes, &h->dev_bytes) != 0) return AMG_ENOMEM;
+    M.st_ndict = (int)bits.size();
+    rc = launch_value_encode(M.st_vals, count, M.st_dict, M.st_ndict, M.st_codes, M.st_nu, h->stream);
+    AMG_HIP(hipStreamSynchronize(h->stream));
+    if (rc != 0) return AMG_ESTATE;
+    M.st_vi_on = true;
+    return M.st_ndict;
 }
 
 int amg_hier_operator_form(amg_hier *h, int lvl)

@@ -750,6 +750,9 @@ template <class T> __device__ __forceinline__ T stream_load(const T *p)
 
 struct StencilArgs {
     const double *vals;
+    const unsigned char *codes;          // value index: one byte per slot instead of vals (null = off)
+    const double *dict;                  // its dictionary (<= 256 doubles), copied to LDS by every workgroup
+    int ndict;
     const void *mask;                    // uint8 per row in the NUB == 8 instantiation (|U| <= 7), else uint32;
                                          // top bit set = the row is applied by the pattern kernel instead
     int nu, u0;
@@ -764,6 +767,7 @@ __global__ __launch_bounds__(WG) void stencil_kernel(StreamArgs a, StencilArgs E
 {
     using MT = ModeTraits<MODE>;
     __shared__ double red[8];
+    __shared__ double sdict[256];
     const int t = threadIdx.x;
     int blk;
     if (E.period_blocks > 0) {
@@ -778,14 +782,23 @@ __global__ __launch_bounds__(WG) void stencil_kernel(StreamArgs a, StencilArgs E
     blk += E.blk_lo;
     const int i = blk * WG + t;
     const bool live = (i >= a.row_lo && i < a.row_hi);
+    const bool vi = E.codes != nullptr;                       // uniform
     const double *vp = E.vals + ((size_t)blk * E.nu) * WG + t;
+    // value index: the codes of 8 slots of a row packed into one 64-bit word, [block][word][256 rows]
+    constexpr int NW = NUB / 8;
+    const int nw = (E.nu + 7) >> 3;
+    const unsigned long long *cp = reinterpret_cast<const unsigned long long *>(E.codes) + ((size_t)blk * nw) * WG + t;
+    if (vi && t < E.ndict) sdict[t] = E.dict[t];
 
     double v[NUB], xv[NUB];
+    unsigned long long cw[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) cw[w] = (vi && live && w < nw) ? stream_load(&cp[(size_t)w * WG]) : 0ULL;
 #pragma unroll
     for (int u = 0; u < NUB; ++u) {
         v[u] = 0.0; xv[u] = 0.0;
         if (u < E.nu && live) {
-            v[u] = stream_load(&vp[(size_t)u * WG]);
+            if (!vi) v[u] = stream_load(&vp[(size_t)u * WG]);
             const long j = (long)i + E.off[u];
             if (j >= 0 && j < E.ncols) xv[u] = a.xg[j];
         }
@@ -804,6 +817,11 @@ __global__ __launch_bounds__(WG) void stencil_kernel(StreamArgs a, StencilArgs E
     }
     const bool covered = live && m != 0xFFFFFFFFu;
     if (!covered) m = 0;
+    if (vi) {
+        __syncthreads();                                      // dictionary in LDS
+#pragma unroll
+        for (int u = 0; u < NUB; ++u) v[u] = sdict[(unsigned)(cw[u >> 3] >> (8 * (u & 7))) & 0xFFu];
+    }
     const double gscale = a.gscale;
     double acc = MT::sub ? bval : 0.0, diag = 0.0;
 #pragma unroll
@@ -896,6 +914,62 @@ int launch_stencil_build(const DevCsr &M, const int *dict_slot, const unsigned *
     return 0;
 }
 
+// ---- value index (DevCsr::st_codes) ----
+__global__ void value_scan_kernel(const double *vals, long count, unsigned long long *table, int *overflow)
+{
+    const unsigned long long EMPTY = ~0ULL;
+    for (long k = blockIdx.x * (long)blockDim.x + threadIdx.x; k < count; k += (long)gridDim.x * blockDim.x) {
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(vals[k]);
+        if (bits == EMPTY) { *overflow = 1; continue; }                  // that NaN pattern is the sentinel
+        unsigned h = (unsigned)((bits * 0x9E3779B97F4A7C15ULL) >> 54);   // 10 bits
+        bool done = false;
+        for (int probe = 0; probe < 1024 && !done; ++probe, h = (h + 1) & 1023u) {
+            unsigned long long cur = table[h];
+            if (cur == bits) { done = true; break; }
+            if (cur == EMPTY) {
+                cur = atomicCAS(&table[h], EMPTY, bits);
+                if (cur == EMPTY || cur == bits) { done = true; break; }
+            }
+        }
+        if (!done) *overflow = 1;
+    }
+}
+// vals are [block][slot][256]; the code of (block, slot, t) goes to byte (slot & 7) of word [block][slot >> 3][t]
+__global__ void value_encode_kernel(const double *vals, long count, const double *dict, int ndict, unsigned char *codes,
+                                    int nu)
+{
+    const int nw = (nu + 7) >> 3;
+    for (long k = blockIdx.x * (long)blockDim.x + threadIdx.x; k < count; k += (long)gridDim.x * blockDim.x) {
+        const long long bits = __double_as_longlong(vals[k]);
+        int lo = 0, hi = ndict - 1, at = 0;
+        while (lo <= hi) {                                               // dict sorted by bit pattern
+            const int mid = (lo + hi) >> 1;
+            const long long d = __double_as_longlong(dict[mid]);
+            if (d == bits) { at = mid; break; }
+            if (d < bits) lo = mid + 1; else hi = mid - 1;
+        }
+        const long blk = k / ((long)nu * WG);
+        const int rem = (int)(k - blk * (long)nu * WG);
+        const int slot = rem / WG, t = rem - slot * WG;
+        codes[((blk * nw + (slot >> 3)) * WG + t) * 8 + (slot & 7)] = (unsigned char)at;
+    }
+}
+int launch_value_scan(const double *vals, long count, unsigned long long *table, int *overflow, hipStream_t st)
+{
+    hipLaunchKernelGGL(value_scan_kernel, dim3(8192), dim3(256), 0, st, vals, count, table, overflow);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "value scan launch", __FILE__, __LINE__);
+    return 0;
+}
+int launch_value_encode(const double *vals, long count, const double *dict_sorted, int ndict, unsigned char *codes, int nu,
+                        hipStream_t st)
+{
+    hipLaunchKernelGGL(value_encode_kernel, dim3(8192), dim3(256), 0, st, vals, count, dict_sorted, ndict, codes, nu);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "value encode launch", __FILE__, __LINE__);
+    return 0;
+}
+
 static int g_stencil_form = 1;
 void set_stencil_form(int on) { g_stencil_form = on; ++g_config_epoch; }
 bool stencil_enabled() { return g_stencil_form != 0; }
@@ -935,6 +1009,7 @@ static int launch_stencil_mode(const StreamArgs &a, const DevCsr &M, hipStream_t
     if (b.gscale == 0.0) b.gscale = 1.0;
     StencilArgs E;
     E.vals = M.st_vals; E.mask = M.st_mask; E.nu = M.st_nu; E.u0 = M.st_u0;
+    E.codes = (M.st_vi_on && M.st_codes) ? M.st_codes : nullptr; E.dict = M.st_dict; E.ndict = M.st_ndict;
     E.blk_lo = a.row_lo / WG; E.nblocks = nb; E.ncols = M.ncols;
     E.period_blocks = E.seg_blocks = 0;
     for (int u = 0; u < STENCIL_MAX; ++u) E.off[u] = M.st_off[u];

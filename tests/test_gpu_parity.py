@@ -909,3 +909,41 @@ def test_bsr_native_operator_application():
             got[on] = (ml.solve(g["b"], x0=g["x0"], tol=0.0, maxiter=4, residuals=res), np.array(res))
         _lib.lib().amg_set_bsr_spmv(1)
         assert np.array_equal(got[0][0], got[2][0]) and np.array_equal(got[0][1], got[2][1]), case
+
+
+def test_value_index_is_lossless_and_opt_in():
+    """amg_hier_value_index: a constant-coefficient stencil operator (2 distinct values + the padding zero)
+    gets one-byte codes into a dictionary; solves are bit-identical with it on and off; an operator with
+    variable coefficients is refused (returns 0) and keeps its values; nothing is indexed by default."""
+    import scipy.sparse as sp
+    from pyamg_amd import _lib
+    from pyamg_amd.aggregation import poisson as native, smoothed_aggregation_solver
+    L = _lib.lib()
+    A = native((40, 41, 42))
+    np.random.seed(0)
+    sm = ("chebyshev", {"degree": 2})
+    ml = smoothed_aggregation_solver(A, presmoother=sm, postsmoother=sm)
+    dev = ml.device_hierarchy()
+    rng = np.random.RandomState(9)
+    b = rng.rand(A.shape[0])
+    res0 = []
+    x0 = ml.solve(b, tol=0.0, maxiter=4, residuals=res0)
+    moved_plain = dev.cycle_bytes_moved("V")
+    nd = L.amg_hier_value_index(dev.h, 0, 1)
+    assert nd == 3                                            # 6.0, -1.0 and the 0.0 of the padded slots
+    assert dev.cycle_bytes_moved("V") < moved_plain
+    assert np.array_equal(dev.matvec(0, 0, b), A * b)
+    res1 = []
+    x1 = ml.solve(b, tol=0.0, maxiter=4, residuals=res1)
+    assert np.array_equal(x0, x1) and np.array_equal(res0, res1)
+    assert L.amg_hier_value_index(dev.h, 0, 0) == 0
+    assert dev.cycle_bytes_moved("V") == moved_plain
+    assert L.amg_hier_value_index(dev.h, 1, 1) == 0           # level 1 is not in stencil form
+    # variable coefficients: far more than 255 distinct values
+    W = sp.csr_matrix((rng.rand(A.nnz) + 1.0, A.indices, A.indptr), shape=A.shape)
+    W = sp.csr_matrix(W + W.T); W.sort_indices()
+    from pyamg_amd.util import _DeviceOperator
+    op = _DeviceOperator(W)
+    _lib.check(L.amg_hier_finalize(op.h))
+    assert L.amg_hier_operator_form(op.h, 0) == 2 and L.amg_hier_value_index(op.h, 0, 1) == 0
+    op.close()
