@@ -251,61 +251,70 @@ class multilevel_solver:
                 level.R = level.P.conj().T.asformat(level.P.format)   # level.P.H (multilevel.py:154-156)
 
     # ------------------------------------------------------------------ reporting
+    def _level_nnz(self):
+        return [int(level.A.nnz) for level in self.levels]
+
     def __repr__(self):
-        output = "multilevel_solver\n"
-        output += "Number of Levels:     %d\n" % len(self.levels)
-        output += "Operator Complexity: %6.3f\n" % self.operator_complexity()
-        output += "Grid Complexity:     %6.3f\n" % self.grid_complexity()
-        output += "Coarse Solver:        %s\n" % self.coarse_solver.name()
-        total_nnz = sum([level.A.nnz for level in self.levels])
-        output += "  level   unknowns     nonzeros\n"
-        for n, level in enumerate(self.levels):
-            A = level.A
-            output += "   %2d   %10d   %10d [%5.2f%%]\n" % (n, A.shape[1], A.nnz,
-                                                          (100 * float(A.nnz) / float(total_nnz)))
-        return output
+        """Same text as the reference prints (multilevel.py:158-176): header lines, then one row
+        per level with its share of the stored entries."""
+        nnz = self._level_nnz()
+        total = float(sum(nnz))
+        lines = ["multilevel_solver",
+                 "Number of Levels:     %d" % len(self.levels),
+                 "Operator Complexity: %6.3f" % self.operator_complexity(),
+                 "Grid Complexity:     %6.3f" % self.grid_complexity(),
+                 "Coarse Solver:        %s" % self.coarse_solver.name(),
+                 "  level   unknowns     nonzeros"]
+        for i, level in enumerate(self.levels):
+            lines.append("   %2d   %10d   %10d [%5.2f%%]" % (i, level.A.shape[1], nnz[i], 100 * nnz[i] / total))
+        return "\n".join(lines) + "\n"
+
+    def _level_visits(self, cycle):
+        """How many times one cycle of the given type arrives at each level.  V goes down once;
+        W arrives twice at every level below the first, except that the coarsest level is
+        solved once per arrival at the level above it; F arrives once as F and once as V."""
+        nlev = len(self.levels)
+        visits = [0] * nlev
+
+        def arrive(lvl, kind, times):
+            visits[lvl] += times
+            if lvl == nlev - 2:
+                visits[nlev - 1] += times
+            elif lvl < nlev - 2:
+                if kind == "V":
+                    arrive(lvl + 1, "V", times)
+                elif kind == "W":
+                    arrive(lvl + 1, "W", 2 * times)
+                else:
+                    arrive(lvl + 1, "F", times)
+                    arrive(lvl + 1, "V", times)
+        arrive(0, cycle, 1)
+        return visits
 
     def cycle_complexity(self, cycle="V"):
-        """multilevel.py:178-248"""
+        """Entries of the level operators touched by one cycle, relative to the finest operator:
+        every arrival at a level costs two passes over A (pre- and post-smoothing), the coarsest
+        level one (its solve) -- the values of multilevel.py:178-248."""
         cycle = str(cycle).upper()
-        nnz = [level.A.nnz for level in self.levels]
-
-        def V(level):
-            if len(self.levels) == 1:
-                return nnz[0]
-            elif level == len(self.levels) - 2:
-                return 2 * nnz[level] + nnz[level + 1]
-            return 2 * nnz[level] + V(level + 1)
-
-        def W(level):
-            if len(self.levels) == 1:
-                return nnz[0]
-            elif level == len(self.levels) - 2:
-                return 2 * nnz[level] + nnz[level + 1]
-            return 2 * nnz[level] + 2 * W(level + 1)
-
-        def F(level):
-            if len(self.levels) == 1:
-                return nnz[0]
-            elif level == len(self.levels) - 2:
-                return 2 * nnz[level] + nnz[level + 1]
-            return 2 * nnz[level] + F(level + 1) + V(level + 1)
-
-        if cycle == "V":
-            flops = V(0)
-        elif (cycle == "W") or (cycle == "AMLI"):
-            flops = W(0)
-        elif cycle == "F":
-            flops = F(0)
-        else:
+        kind = {"V": "V", "W": "W", "AMLI": "W", "F": "F"}.get(cycle)
+        if kind is None:
             raise TypeError("Unrecognized cycle type (%s)" % cycle)
-        return float(flops) / float(nnz[0])
+        nnz = self._level_nnz()
+        if len(nnz) == 1:
+            return 1.0
+        visits = self._level_visits(kind)
+        work = sum(2 * v * z for v, z in zip(visits[:-1], nnz[:-1])) + visits[-1] * nnz[-1]
+        return float(work) / float(nnz[0])
 
     def operator_complexity(self):
-        return sum([level.A.nnz for level in self.levels]) / float(self.levels[0].A.nnz)
+        """stored entries of all level operators over those of the finest (multilevel.py:250-259)"""
+        nnz = self._level_nnz()
+        return sum(nnz) / float(nnz[0])
 
     def grid_complexity(self):
-        return sum([level.A.shape[0] for level in self.levels]) / float(self.levels[0].A.shape[0])
+        """unknowns of all levels over those of the finest (multilevel.py:261-269)"""
+        sizes = [level.A.shape[0] for level in self.levels]
+        return sum(sizes) / float(sizes[0])
 
     # ------------------------------------------------------------------ device mirror
     def _invalidate_device(self):

@@ -21,42 +21,52 @@ __all__ = ["sor", "gauss_seidel", "jacobi", "polynomial", "jacobi_ne", "gauss_se
            "make_system", "schwarz", "schwarz_parameters"]
 
 
-def make_system(A, x, b, formats=None):
-    """relaxation.py:21-105"""
-    if formats is None:
-        pass
-    elif formats == ["csr"]:
-        if sparse.isspmatrix_csr(A):
-            pass
-        elif sparse.isspmatrix_bsr(A):
-            A = A.tocsr()
-        else:
-            warn("implicit conversion to CSR", sparse.SparseEfficiencyWarning)
-            A = sparse.csr_matrix(A)
-    else:
-        if sparse.isspmatrix(A) and A.format in formats:
-            pass
-        else:
-            A = sparse.csr_matrix(A).asformat(formats[0])
+_SWEEP_SIGNS = {"forward": (1,), "backward": (-1,), "symmetric": (1, -1)}
 
-    if not isinstance(x, np.ndarray):
-        raise ValueError("expected numpy array for argument x")
-    if not isinstance(b, np.ndarray):
-        raise ValueError("expected numpy array for argument b")
-    M, N = A.shape
-    if M != N:
-        raise ValueError("expected square matrix")
-    if x.shape not in [(M,), (M, 1)]:
-        raise ValueError("x has invalid dimensions")
-    if b.shape not in [(M,), (M, 1)]:
-        raise ValueError("b has invalid dimensions")
-    if A.dtype != x.dtype or A.dtype != b.dtype:
-        raise TypeError("arguments A, x, and b must have the same dtype")
-    if not x.flags.carray:
-        raise ValueError("x must be contiguous in memory")
-    x = np.ravel(x)
-    b = np.ravel(b)
-    return A, x, b
+
+def _sweep_ranges(sweep, count):
+    """The (start, stop, step) row ranges ONE iteration of a directional sweep visits, in order:
+    a symmetric sweep is a forward range followed by a backward one (relaxation.py:334-343)."""
+    signs = _SWEEP_SIGNS.get(sweep) if isinstance(sweep, str) else None
+    if signs is None:
+        raise ValueError("valid sweep directions are 'forward', 'backward', and 'symmetric'")
+    return [(0, count, 1) if s > 0 else (count - 1, -1, -1) for s in signs]
+
+
+def _to_accepted_format(A, formats):
+    """The storage conversions the reference's shims apply before validating (relaxation.py:66-83)."""
+    if formats is None:
+        return A
+    if sparse.isspmatrix(A) and A.format in formats:
+        return A
+    if formats == ["csr"]:
+        if sparse.isspmatrix_bsr(A):
+            return A.tocsr()
+        warn("implicit conversion to CSR", sparse.SparseEfficiencyWarning)
+        return sparse.csr_matrix(A)
+    return sparse.csr_matrix(A).asformat(formats[0])
+
+
+def make_system(A, x, b, formats=None):
+    """Validate (A, x, b) for a relaxation call and return them with x, b flattened -- the error
+    contract of relaxation.py:21-105 (exception types and messages are what
+    relaxation/tests/test_relaxation.py:52-102 pins), stated as a table of requirements."""
+    A = _to_accepted_format(A, formats)
+    rows, cols = A.shape
+    vec_shapes = ((rows,), (rows, 1))
+    requirements = (
+        (lambda: isinstance(x, np.ndarray), ValueError, "expected numpy array for argument x"),
+        (lambda: isinstance(b, np.ndarray), ValueError, "expected numpy array for argument b"),
+        (lambda: rows == cols, ValueError, "expected square matrix"),
+        (lambda: x.shape in vec_shapes, ValueError, "x has invalid dimensions"),
+        (lambda: b.shape in vec_shapes, ValueError, "b has invalid dimensions"),
+        (lambda: A.dtype == x.dtype == b.dtype, TypeError, "arguments A, x, and b must have the same dtype"),
+        (lambda: x.flags.carray, ValueError, "x must be contiguous in memory"),
+    )
+    for holds, exc, message in requirements:
+        if not holds():
+            raise exc(message)
+    return A, np.ravel(x), np.ravel(b)
 
 
 def _ptr(A):
@@ -83,48 +93,44 @@ def _bvec(b):
     return np.ascontiguousarray(b)
 
 
+def _square_blocksize(A):
+    """1 for CSR, R for BSR with square R x R blocks"""
+    if sparse.isspmatrix_csr(A):
+        return 1
+    R, C = A.blocksize
+    if R != C:
+        raise ValueError("BSR blocks must be square")
+    return R
+
+
 def sor(A, x, b, omega, iterations=1, sweep="forward"):
-    """relaxation.py:108-169"""
+    """Successive over-relaxation, x updated in place (relaxation.py:108-169): every iteration is a
+    Gauss-Seidel pass blended with the iterate it started from, x <- omega*x_gs + (1-omega)*x_start,
+    formed as two scalings and one addition."""
     A, x, b = make_system(A, x, b, formats=["csr", "bsr"])
-    x_old = np.empty_like(x)
-    for i in range(iterations):
-        x_old[:] = x
+    for _ in range(iterations):
+        start = x.copy()
         gauss_seidel(A, x, b, iterations=1, sweep=sweep)
-        x *= omega
-        x_old *= (1 - omega)
-        x += x_old
+        np.multiply(x, omega, out=x)
+        np.multiply(start, 1 - omega, out=start)
+        np.add(x, start, out=x)
 
 
 def gauss_seidel(A, x, b, iterations=1, sweep="forward"):
-    """relaxation.py:280-354"""
+    """Gauss-Seidel relaxation, x updated in place (relaxation.py:280-354 over
+    amg_core/relaxation.h:34-62 for CSR, :90-173 for BSR -- block rows are counted there)."""
     A, x, b = make_system(A, x, b, formats=["csr", "bsr"])
-    if sparse.isspmatrix_csr(A):
-        blocksize = 1
-    else:
-        R, C = A.blocksize
-        if R != C:
-            raise ValueError("BSR blocks must be square")
-        blocksize = R
-    if sweep == "forward":
-        row_start, row_stop, row_step = 0, int(len(x) / blocksize), 1
-    elif sweep == "backward":
-        row_start, row_stop, row_step = int(len(x) / blocksize) - 1, -1, -1
-    elif sweep == "symmetric":
-        for it in range(iterations):
-            gauss_seidel(A, x, b, iterations=1, sweep="forward")
-            gauss_seidel(A, x, b, iterations=1, sweep="backward")
-        return
-    else:
-        raise ValueError("valid sweep directions are 'forward', 'backward', and 'symmetric'")
+    bs = _square_blocksize(A)
+    ranges = _sweep_ranges(sweep, len(x) // bs)
     Ap, Aj = _ptr(A)
     b = _bvec(b)
-    if sparse.isspmatrix_csr(A):
-        for it in range(iterations):
-            amg_core.gauss_seidel(Ap, Aj, np.ascontiguousarray(A.data), x, b, row_start, row_stop, row_step)
-    else:
-        for it in range(iterations):
-            amg_core.bsr_gauss_seidel(Ap, Aj, np.ascontiguousarray(np.ravel(A.data)), x, b, row_start,
-                                      row_stop, row_step, R)
+    Ax = np.ascontiguousarray(np.ravel(A.data))
+    for _ in range(iterations):
+        for start, stop, step in ranges:
+            if bs == 1 and sparse.isspmatrix_csr(A):
+                amg_core.gauss_seidel(Ap, Aj, Ax, x, b, start, stop, step)
+            else:
+                amg_core.bsr_gauss_seidel(Ap, Aj, Ax, x, b, start, stop, step, bs)
 
 
 def jacobi(A, x, b, iterations=1, omega=1.0):
@@ -156,12 +162,7 @@ def block_jacobi(A, x, b, Dinv=None, blocksize=1, iterations=1, omega=1.0):
     """relaxation.py:430-506"""
     A, x, b = make_system(A, x, b, formats=["csr", "bsr"])
     A = A.tobsr(blocksize=(blocksize, blocksize))
-    if Dinv is None:
-        Dinv = get_block_diag(A, blocksize=blocksize, inv_flag=True)
-    elif Dinv.shape[0] != int(A.shape[0] / blocksize):
-        raise ValueError("Dinv and A have incompatible dimensions")
-    elif (Dinv.shape[1] != blocksize) or (Dinv.shape[2] != blocksize):
-        raise ValueError("Dinv and blocksize are incompatible")
+    Dinv = _block_inverse(A, blocksize, Dinv)
     sweep = slice(None)
     (row_start, row_stop, row_step) = sweep.indices(int(A.shape[0] / blocksize))
     if (row_stop - row_start) * row_step <= 0:
@@ -176,33 +177,32 @@ def block_jacobi(A, x, b, Dinv=None, blocksize=1, iterations=1, omega=1.0):
                               omega, blocksize)
 
 
+def _block_inverse(A, blocksize, Dinv):
+    """Dinv as handed in (shape-checked) or the inverted diagonal blocks of A (relaxation.py:473-479)."""
+    if Dinv is None:
+        return get_block_diag(A, blocksize=blocksize, inv_flag=True)
+    if Dinv.shape[0] != A.shape[0] // blocksize:
+        raise ValueError("Dinv and A have incompatible dimensions")
+    if Dinv.shape[1:] != (blocksize, blocksize):
+        raise ValueError("Dinv and blocksize are incompatible")
+    return Dinv
+
+
 def block_gauss_seidel(A, x, b, iterations=1, sweep="forward", blocksize=1, Dinv=None):
-    """relaxation.py:509-590"""
+    """Block Gauss-Seidel, x updated in place (relaxation.py:509-590 over relaxation.h:756-810):
+    A is re-blocked to (blocksize, blocksize), block rows are swept in order and each one is
+    solved with the stored inverse of its diagonal block."""
     A, x, b = make_system(A, x, b, formats=["csr", "bsr"])
     A = A.tobsr(blocksize=(blocksize, blocksize))
-    if Dinv is None:
-        Dinv = get_block_diag(A, blocksize=blocksize, inv_flag=True)
-    elif Dinv.shape[0] != int(A.shape[0] / blocksize):
-        raise ValueError("Dinv and A have incompatible dimensions")
-    elif (Dinv.shape[1] != blocksize) or (Dinv.shape[2] != blocksize):
-        raise ValueError("Dinv and blocksize are incompatible")
-    if sweep == "forward":
-        row_start, row_stop, row_step = 0, int(len(x) / blocksize), 1
-    elif sweep == "backward":
-        row_start, row_stop, row_step = int(len(x) / blocksize) - 1, -1, -1
-    elif sweep == "symmetric":
-        for it in range(iterations):
-            block_gauss_seidel(A, x, b, iterations=1, sweep="forward", blocksize=blocksize, Dinv=Dinv)
-            block_gauss_seidel(A, x, b, iterations=1, sweep="backward", blocksize=blocksize, Dinv=Dinv)
-        return
-    else:
-        raise ValueError("valid sweep directions are 'forward', 'backward', and 'symmetric'")
+    Dinv = _block_inverse(A, blocksize, Dinv)
+    ranges = _sweep_ranges(sweep, len(x) // blocksize)
     Ap, Aj = _ptr(A)
     b = _bvec(b)
-    for it in range(iterations):
-        amg_core.block_gauss_seidel(Ap, Aj, np.ascontiguousarray(np.ravel(A.data)), x, b,
-                                    np.ascontiguousarray(np.ravel(Dinv)), row_start, row_stop, row_step,
-                                    blocksize)
+    Ax = np.ascontiguousarray(np.ravel(A.data))
+    Dflat = np.ascontiguousarray(np.ravel(Dinv))
+    for _ in range(iterations):
+        for start, stop, step in ranges:
+            amg_core.block_gauss_seidel(Ap, Aj, Ax, x, b, Dflat, start, stop, step, blocksize)
 
 
 def polynomial(A, x, b, coefficients, iterations=1):
@@ -220,26 +220,17 @@ def polynomial(A, x, b, coefficients, iterations=1):
 
 
 def gauss_seidel_indexed(A, x, b, indices, iterations=1, sweep="forward"):
-    """relaxation.py:671-741"""
+    """Gauss-Seidel over the rows listed in `indices`, in list order (relaxation.py:671-741 over
+    relaxation.h:395-430); the sweep ranges count positions of the list."""
     A, x, b = make_system(A, x, b, formats=["csr"])
-    indices = np.asarray(indices, dtype="intc")
-    if sweep == "forward":
-        row_start, row_stop, row_step = 0, len(indices), 1
-    elif sweep == "backward":
-        row_start, row_stop, row_step = len(indices) - 1, -1, -1
-    elif sweep == "symmetric":
-        for it in range(iterations):
-            gauss_seidel_indexed(A, x, b, indices, iterations=1, sweep="forward")
-            gauss_seidel_indexed(A, x, b, indices, iterations=1, sweep="backward")
-        return
-    else:
-        raise ValueError("valid sweep directions are 'forward', 'backward', and 'symmetric'")
+    indices = np.ascontiguousarray(np.asarray(indices, dtype="intc"))
+    ranges = _sweep_ranges(sweep, len(indices))
     Ap, Aj = _ptr(A)
     b = _bvec(b)
-    indices = np.ascontiguousarray(indices)
-    for it in range(iterations):
-        amg_core.gauss_seidel_indexed(Ap, Aj, np.ascontiguousarray(A.data), x, b, indices, row_start,
-                                      row_stop, row_step)
+    Ax = np.ascontiguousarray(A.data)
+    for _ in range(iterations):
+        for start, stop, step in ranges:
+            amg_core.gauss_seidel_indexed(Ap, Aj, Ax, x, b, indices, start, stop, step)
 
 
 def jacobi_ne(A, x, b, iterations=1, omega=1.0):
@@ -259,56 +250,50 @@ def jacobi_ne(A, x, b, iterations=1, omega=1.0):
 
 
 def gauss_seidel_ne(A, x, b, iterations=1, sweep="forward", omega=1.0, Dinv=None):
-    """relaxation.py:821-908"""
+    """Gauss-Seidel on A A^H y = b with x = A^H y (Kaczmarz row projections), x updated in place
+    (relaxation.py:821-908 over relaxation.h:529-560)."""
     A, x, b = make_system(A, x, b, formats=["csr"])
     if Dinv is None:
         Dinv = np.ravel(get_diagonal(A, norm_eq=2, inv=True))
-    if sweep == "forward":
-        row_start, row_stop, row_step = 0, len(x), 1
-    elif sweep == "backward":
-        row_start, row_stop, row_step = len(x) - 1, -1, -1
-    elif sweep == "symmetric":
-        for it in range(iterations):
-            gauss_seidel_ne(A, x, b, iterations=1, sweep="forward", omega=omega, Dinv=Dinv)
-            gauss_seidel_ne(A, x, b, iterations=1, sweep="backward", omega=omega, Dinv=Dinv)
-        return
-    else:
-        raise ValueError("valid sweep directions are 'forward', 'backward', and 'symmetric'")
+    ranges = _sweep_ranges(sweep, len(x))
     Ap, Aj = _ptr(A)
     b = _bvec(b)
+    Ax = np.ascontiguousarray(A.data)
     Dinv = np.ascontiguousarray(Dinv, dtype=np.float64)
-    for i in range(iterations):
-        amg_core.gauss_seidel_ne(Ap, Aj, np.ascontiguousarray(A.data), x, b, row_start, row_stop, row_step,
-                                 Dinv, omega)
+    for _ in range(iterations):
+        for start, stop, step in ranges:
+            amg_core.gauss_seidel_ne(Ap, Aj, Ax, x, b, start, stop, step, Dinv, omega)
 
 
 def gauss_seidel_nr(A, x, b, iterations=1, sweep="forward", omega=1.0, Dinv=None):
-    """relaxation.py:911-997"""
+    """Gauss-Seidel on A^H A x = A^H b by columns of A, x updated in place (relaxation.py:911-997
+    over relaxation.h:594-625).  The kernel keeps r = b - A x current while it sweeps; the
+    reference forms r once per directional CALL, and its symmetric sweep is a forward call
+    followed by a backward call -- so r is re-formed before every direction of a symmetric sweep
+    and once for all iterations of a one-directional one."""
     A, x, b = make_system(A, x, b, formats=["csc"])
     if Dinv is None:
         Dinv = np.ravel(get_diagonal(A, norm_eq=1, inv=True))
-    if sweep == "forward":
-        col_start, col_stop, col_step = 0, len(x), 1
-    elif sweep == "backward":
-        col_start, col_stop, col_step = len(x) - 1, -1, -1
-    elif sweep == "symmetric":
-        for it in range(iterations):
-            gauss_seidel_nr(A, x, b, iterations=1, sweep="forward", omega=omega, Dinv=Dinv)
-            gauss_seidel_nr(A, x, b, iterations=1, sweep="backward", omega=omega, Dinv=Dinv)
-        return
-    else:
-        raise ValueError("valid sweep directions are 'forward', 'backward', and 'symmetric'")
-    # initial residual (relaxation.py:992).  scipy's csc_matvec adds the terms of each
-    # output entry in ascending column order -- the same order as a CSR row with sorted
-    # indices, so the device CSR kernel reproduces it bit for bit.
+    ranges = _sweep_ranges(sweep, len(x))
+    # scipy's csc_matvec adds the terms of each output entry in ascending column order -- the
+    # order of a CSR row with sorted indices, which the device CSR kernel reproduces bit for bit
     Acsr = A.tocsr()
     Acsr.sort_indices()
-    r = np.ascontiguousarray(b - _spmv(Acsr, x))
     Ap, Aj = _ptr(A)
+    Ax = np.ascontiguousarray(A.data)
     Dinv = np.ascontiguousarray(Dinv, dtype=np.float64)
-    for i in range(iterations):
-        amg_core.gauss_seidel_nr(Ap, Aj, np.ascontiguousarray(A.data), x, r, col_start, col_stop, col_step,
-                                 Dinv, omega)
+
+    def residual():
+        return np.ascontiguousarray(b - _spmv(Acsr, x))
+
+    if len(ranges) == 1:
+        (start, stop, step), r = ranges[0], residual()
+        for _ in range(iterations):
+            amg_core.gauss_seidel_nr(Ap, Aj, Ax, x, r, start, stop, step, Dinv, omega)
+        return
+    for _ in range(iterations):
+        for start, stop, step in ranges:
+            amg_core.gauss_seidel_nr(Ap, Aj, Ax, x, residual(), start, stop, step, Dinv, omega)
 
 
 def schwarz(A, x, b, iterations=1, subdomain=None, subdomain_ptr=None, inv_subblock=None,
@@ -321,25 +306,14 @@ def schwarz(A, x, b, iterations=1, subdomain=None, subdomain_ptr=None, inv_subbl
     (subdomain, subdomain_ptr, inv_subblock, inv_subblock_ptr) = \
         schwarz_parameters(A, subdomain, subdomain_ptr, inv_subblock, inv_subblock_ptr)
     nsd = subdomain_ptr.shape[0] - 1
-    if sweep == "forward":
-        row_start, row_stop, row_step = 0, nsd, 1
-    elif sweep == "backward":
-        row_start, row_stop, row_step = nsd - 1, -1, -1
-    elif sweep == "symmetric":
-        for _ in range(iterations):
-            schwarz(A, x, b, iterations=1, subdomain=subdomain, subdomain_ptr=subdomain_ptr,
-                    inv_subblock=inv_subblock, inv_subblock_ptr=inv_subblock_ptr, sweep="forward")
-            schwarz(A, x, b, iterations=1, subdomain=subdomain, subdomain_ptr=subdomain_ptr,
-                    inv_subblock=inv_subblock, inv_subblock_ptr=inv_subblock_ptr, sweep="backward")
-        return
-    else:
-        raise ValueError("valid sweep directions are 'forward', 'backward', and 'symmetric'")
+    ranges = _sweep_ranges(sweep, nsd)
     Ap, Aj = _ptr(A)
     b = _bvec(b)
     Ax = np.ascontiguousarray(A.data)
     for _ in range(iterations):
-        amg_core.overlapping_schwarz_csr(Ap, Aj, Ax, x, b, inv_subblock, inv_subblock_ptr, subdomain,
-                                         subdomain_ptr, nsd, A.shape[0], row_start, row_stop, row_step)
+        for start, stop, step in ranges:
+            amg_core.overlapping_schwarz_csr(Ap, Aj, Ax, x, b, inv_subblock, inv_subblock_ptr, subdomain,
+                                             subdomain_ptr, nsd, A.shape[0], start, stop, step)
 
 
 def schwarz_parameters(A, subdomain=None, subdomain_ptr=None, inv_subblock=None, inv_subblock_ptr=None):
