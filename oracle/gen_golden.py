@@ -270,11 +270,11 @@ def gen_hier(pyamg, name, A, build, pre, post, solve_kw, B=None, x0_random=False
     x0 = np.random.rand(n) if x0_random else None
     iterates = []
     res = []
-    x = ml.solve(b, x0=x0, residuals=res, callback=lambda xk: iterates.append(xk.copy()), **solve_kw)
+    x = ml.solve(b, x0=x0, residuals=res, callback=lambda xk: iterates.append(np.array(xk, copy=True)), **solve_kw)
     out = {}
     meta = {"name": name, "nlevels": len(ml.levels), "cycle": solve_kw.get("cycle", "V"),
             "tol": solve_kw.get("tol", 1e-5), "maxiter": solve_kw.get("maxiter", 100),
-            "levels": []}
+            "accel": solve_kw.get("accel"), "levels": []}
     pre_l = pre if isinstance(pre, list) else [pre]
     post_l = post if isinstance(post, list) else [post]
     for i, lvl in enumerate(ml.levels):
@@ -294,6 +294,9 @@ def gen_hier(pyamg, name, A, build, pre, post, solve_kw, B=None, x0_random=False
     out["x0"] = np.zeros(n) if x0 is None else x0
     out["x"] = np.asarray(x)
     out["residuals"] = np.array(res)
+    iterates = [np.asarray(v, dtype=np.float64) for v in iterates if np.ndim(v) == 1 and np.size(v) == n]
+    if not iterates:                       # Krylov callbacks that only report residual norms
+        iterates = [np.asarray(x)]
     out["x_iter1"] = iterates[0]
     out["x_iter2"] = iterates[1] if len(iterates) > 1 else iterates[0]
     out["meta_json"] = np.array(json.dumps(meta))

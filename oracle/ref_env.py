@@ -100,12 +100,17 @@ def _install_aliases():
     m = _fake("scipy.sparse.sputils", upcast=upcast, isscalarlike=isscalarlike)
     scipy.sparse.sputils = m
 
-    def make_system(A, M, x0, b):
-        from scipy.sparse.linalg import aslinearoperator
+    def make_system(A, M, x0, b, xtype=None):
+        # scipy <= 1.x's isolve.utils.make_system (the scipy helper, not reference code): linear operators,
+        # flat float vectors, identity preconditioner when M is None
+        from scipy.sparse.linalg import LinearOperator, aslinearoperator
         A_ = aslinearoperator(A)
-        b = np.asarray(b).reshape(-1)
-        x = np.zeros_like(b) if x0 is None else np.array(x0).reshape(-1)
-        M_ = aslinearoperator(M) if M is not None else None
+        b = np.asarray(b, dtype=np.result_type(A_.dtype, np.asarray(b).dtype, np.float64)).reshape(-1)
+        x = np.zeros_like(b) if x0 is None else np.array(x0, dtype=b.dtype).reshape(-1)
+        if M is None:
+            M_ = LinearOperator(A_.shape, matvec=lambda v: v, rmatvec=lambda v: v, dtype=b.dtype)
+        else:
+            M_ = aslinearoperator(M)
         return A_, M_, x, b, (lambda v: v)
     iso = _fake("scipy.sparse.linalg.isolve")
     isu = _fake("scipy.sparse.linalg.isolve.utils", make_system=make_system)

@@ -1790,9 +1790,12 @@ int amg_arnoldi(amg_hier *h, int lvl, const double *dinv, const double *v0, int 
         if (h->arn_dinv) hipFree(h->arn_dinv);
         if (h->arn_coef) hipFree(h->arn_coef);
         h->arn_V = h->arn_dinv = h->arn_coef = nullptr;
-        CHK(dev_alloc(&h->arn_V, (long)(maxiter + 1) * n, (long *)nullptr));
-        CHK(dev_alloc(&h->arn_dinv, n, (long *)nullptr));
-        CHK(dev_alloc(&h->arn_coef, maxiter + 8, (long *)nullptr));
+        h->dev_bytes -= h->arn_bytes;
+        h->arn_bytes = 0;
+        CHK(dev_alloc(&h->arn_V, (long)(maxiter + 1) * n, &h->arn_bytes));
+        CHK(dev_alloc(&h->arn_dinv, n, &h->arn_bytes));
+        CHK(dev_alloc(&h->arn_coef, maxiter + 8, &h->arn_bytes));
+        h->dev_bytes += h->arn_bytes;                   // counted while it lives (amg_arnoldi_free gives it back)
         h->arn_m = maxiter; h->arn_n = n;
     }
     if (!h->norm_scratch) CHK(dev_alloc(&h->norm_scratch, 1024 + 8, &h->dev_bytes));
@@ -1868,6 +1871,8 @@ void amg_arnoldi_free(amg_hier *h)
     if (h->arn_coef) hipFree(h->arn_coef);
     h->arn_V = h->arn_dinv = h->arn_coef = nullptr;
     h->arn_m = 0; h->arn_n = 0;
+    h->dev_bytes -= h->arn_bytes;
+    h->arn_bytes = 0;
 }
 
 // average device time (ms, hipEvents on the hierarchy stream) of one application of a stored

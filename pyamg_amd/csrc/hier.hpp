@@ -134,6 +134,7 @@ struct amg_hier {
     double *arn_coef = nullptr;
     int arn_m = 0;
     long arn_n = 0;
+    long arn_bytes = 0;               // HBM held by the workspace (part of dev_bytes while it lives)
     // hipGraph replay of the iteration (launch-bound hierarchies: small levels, level-scheduled GS)
     std::vector<amg::GraphEntry> graphs;
     int use_graphs = 1;

@@ -11,7 +11,7 @@ import itertools
 import numpy as np
 import scipy.sparse as sps
 
-__all__ = ["tet_diffusion", "poisson"]
+__all__ = ["tet_diffusion", "p1_diffusion", "kuhn_mesh", "anisotropy_tensor", "poisson"]
 
 from .aggregation import poisson  # noqa: E402,F401
 
@@ -24,10 +24,44 @@ def _rotation(theta, phi):
     return Rz.dot(Ry)
 
 
-def tet_diffusion(n, eps=(1.0, 0.1, 0.01), theta=np.pi / 6, phi=np.pi / 5, jitter=0.2, seed=0, blocksize=None):
-    """Stiffness matrix of -div(K grad u), P1 on tetrahedra, (n+2)^3 vertices with the boundary layer
-    eliminated -> n^3 unknowns (lexicographic, last axis fastest).  Returns CSR, or BSR(bs,bs) when
-    `blocksize` is given (n^3 must be divisible by it), as configuration C5 uses it."""
+def anisotropy_tensor(eps=(1.0, 0.1, 0.01), theta=np.pi / 6, phi=np.pi / 5):
+    """K = Q diag(eps) Q^T with Q the rotation about z by theta, then about y by phi"""
+    Q = _rotation(theta, phi)
+    return Q.dot(np.diag(eps)).dot(Q.T)
+
+
+def p1_diffusion(vertices, elements, K, chunk=2000000):
+    """Stiffness matrix of -div(K grad u) with P1 elements on the tetrahedra `elements` (rows of four
+    vertex ids) over `vertices` (n x 3): per element the barycentric gradients G_i, entries
+    |T| (K G_i).G_j, summed over the elements that share an edge.  CSR, sorted int32 indices."""
+    V = np.asarray(vertices, dtype=np.float64)
+    T = np.asarray(elements, dtype=np.int64)
+    nv = V.shape[0]
+    K = np.asarray(K, dtype=np.float64)
+    A = None
+    for lo in range(0, T.shape[0], chunk):                     # bounded temporaries on large meshes
+        Tc = T[lo:lo + chunk]
+        X = V[Tc]                                              # (ne, 4, 3)
+        E = X[:, 1:, :] - X[:, :1, :]
+        vol = np.abs(np.linalg.det(E)) / 6.0
+        G = np.zeros((Tc.shape[0], 4, 3))
+        G[:, 1:, :] = np.transpose(np.linalg.inv(E), (0, 2, 1))     # columns of E^-1 = gradients of lambda_1..3
+        G[:, 0, :] = -G[:, 1:, :].sum(axis=1)
+        loc = np.einsum("eik,ejk->eij", G.dot(K.T), G) * vol[:, None, None]
+        part = sps.coo_matrix((loc.ravel(), (np.repeat(Tc, 4, axis=1).ravel(), np.tile(Tc, (1, 4)).ravel())),
+                              shape=(nv, nv)).tocsr()
+        A = part if A is None else A + part
+    A.sum_duplicates()
+    A.sort_indices()
+    A.indices = A.indices.astype(np.intc)
+    A.indptr = A.indptr.astype(np.intc)
+    return A
+
+
+def kuhn_mesh(n, jitter=0.2, seed=0):
+    """(n+2)^3 vertices of the unit cube on a jittered grid (boundary vertices stay put), every cube cut into
+    6 tetrahedra along the diagonal (0,0,0)-(1,1,1) (Kuhn split: one per ordering of the axes).
+    -> vertices (nv x 3), elements (ne x 4), interior vertex ids (lexicographic, last axis fastest)"""
     m = n + 2
     rng = np.random.RandomState(seed)
     g = np.linspace(0.0, 1.0, m)
@@ -39,40 +73,27 @@ def tet_diffusion(n, eps=(1.0, 0.1, 0.01), theta=np.pi / 6, phi=np.pi / 5, jitte
     J[:, 0], J[:, -1] = 0.0, 0.0
     J[:, :, 0], J[:, :, -1] = 0.0, 0.0
     P = (P + J).reshape(-1, 3)
-    Q = _rotation(theta, phi)
-    K = Q.dot(np.diag(eps)).dot(Q.T)
     vid = np.arange(m ** 3).reshape(m, m, m)
-    c0 = vid[:-1, :-1, :-1].ravel()
     corner = {}
     for dx, dy, dz in itertools.product((0, 1), repeat=3):
         corner[(dx, dy, dz)] = vid[dx:m - 1 + dx, dy:m - 1 + dy, dz:m - 1 + dz].ravel()
-    rows, cols, vals = [], [], []
-    # Kuhn split: one tetrahedron per ordering of the axes, path (0,0,0) -> (1,1,1)
+    tets = []
     for perm in itertools.permutations(range(3)):
-        path = [(0, 0, 0)]
-        cur = [0, 0, 0]
+        path, cur = [(0, 0, 0)], [0, 0, 0]
         for ax in perm:
             cur = list(cur)
             cur[ax] = 1
             path.append(tuple(cur))
-        T = np.stack([corner[p] for p in path], axis=1)            # (ncubes, 4) vertex ids
-        V = P[T]                                                   # (ncubes, 4, 3)
-        E = V[:, 1:, :] - V[:, :1, :]                              # edge matrix rows
-        det = np.linalg.det(E)
-        Einv = np.linalg.inv(E)                                    # columns = gradients of lambda_1..3
-        G = np.zeros((T.shape[0], 4, 3))
-        G[:, 1:, :] = np.transpose(Einv, (0, 2, 1))
-        G[:, 0, :] = -G[:, 1:, :].sum(axis=1)
-        vol = np.abs(det) / 6.0
-        KG = G.dot(K.T)                                            # (ncubes, 4, 3)
-        loc = np.einsum("eik,ejk->eij", KG, G) * vol[:, None, None]
-        rows.append(np.repeat(T, 4, axis=1).ravel())
-        cols.append(np.tile(T, (1, 4)).ravel())
-        vals.append(loc.ravel())
-        del c0
-        c0 = None
-    A = sps.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(m ** 3, m ** 3)).tocsr()
-    interior = vid[1:-1, 1:-1, 1:-1].ravel()
+        tets.append(np.stack([corner[p] for p in path], axis=1))
+    return P, np.concatenate(tets, axis=0), vid[1:-1, 1:-1, 1:-1].ravel()
+
+
+def tet_diffusion(n, eps=(1.0, 0.1, 0.01), theta=np.pi / 6, phi=np.pi / 5, jitter=0.2, seed=0, blocksize=None):
+    """Stiffness matrix of -div(K grad u), P1 on tetrahedra, (n+2)^3 vertices with the boundary layer
+    eliminated -> n^3 unknowns (lexicographic, last axis fastest).  Returns CSR, or BSR(bs,bs) when
+    `blocksize` is given (n^3 must be divisible by it), as configuration C5 uses it."""
+    P, T, interior = kuhn_mesh(n, jitter, seed)
+    A = p1_diffusion(P, T, anisotropy_tensor(eps, theta, phi))
     A = A[interior][:, interior].tocsr()
     A.sum_duplicates()
     A.sort_indices()

@@ -14,7 +14,7 @@ import scipy.sparse as sparse
 from . import relaxation
 from .chebyshev import chebyshev_polynomial_coefficients
 from .util import (approximate_spectral_radius, approximate_spectral_radius_device, get_block_diag,
-                   get_diagonal, scale_rows, use_device_for)
+                   get_diagonal, release_device_operator, scale_rows, use_device_for)
 
 __all__ = ["change_smoothers", "rho_D_inv_A", "rho_block_D_inv_A"]
 
@@ -58,6 +58,10 @@ def change_smoothers(ml, presmoother, postsmoother):
             setattr(ml.levels[i], side, setup(ml.levels[i], **kwargs))
         for j in range(i + 1, len(ml.levels[:-1])):
             setattr(ml.levels[j], side, setup(ml.levels[j], **kwargs))
+    # the HBM copies of the level operators that served the setup-time estimates (util.device_operator)
+    # are not needed any more: the solve uploads its own mirror of the hierarchy
+    for lvl in ml.levels:
+        release_device_operator(lvl.A)
     if hasattr(ml, "_invalidate_device"):
         ml._invalidate_device()
 

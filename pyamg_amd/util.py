@@ -151,21 +151,27 @@ def _approximate_eigenvalues(A, tol, maxiter, symmetric=None, initial_guess=None
     return (Vects, Eigs, H, V, breakdown_flag)
 
 
+def _check_estimate_arguments(A, maxiter, restart):
+    """the argument checks of util/linalg.py:346-352, shared by the host and the device estimate"""
+    if maxiter < 1:
+        raise ValueError("expected maxiter > 0")
+    if restart < 0:
+        raise ValueError("expected restart >= 0")
+    if A.shape[0] != A.shape[1]:
+        raise ValueError("expected square A")
+
+
 def approximate_spectral_radius(A, tol=0.01, maxiter=15, restart=5, symmetric=None,
                                 initial_guess=None, return_vector=False):
     """util/linalg.py:282-416.  Consumes the global numpy RNG exactly like the
     reference (one rand(n,1) per call), so seeded runs give the same rho."""
+    if not hasattr(A, "rho") or return_vector:
+        _check_estimate_arguments(A, maxiter, restart)
     if (not hasattr(A, "rho")) and (not return_vector) and initial_guess is None and isspmatrix(A) \
             and use_device_for(A):
         A.rho = approximate_spectral_radius_device(A, None, tol, maxiter, restart)
         return A.rho
     if not hasattr(A, "rho") or return_vector:
-        if maxiter < 1:
-            raise ValueError("expected maxiter > 0")
-        if restart < 0:
-            raise ValueError("expected restart >= 0")
-        if A.shape[0] != A.shape[1]:
-            raise ValueError("expected square A")
         if initial_guess is None:
             v0 = np.random.rand(A.shape[1], 1)
         else:
@@ -237,6 +243,13 @@ class _DeviceOperator(object):
         _lib.check(self.L.amg_arnoldi_combine(self.h, _lib.dp(coef), len(coef), _lib.dp(v)))
         return v
 
+    def free_workspace(self):
+        if getattr(self, "h", None):
+            self.L.amg_arnoldi_free(self.h)
+
+    def device_bytes(self):
+        return int(self.L.amg_hier_device_bytes(self.h)) if getattr(self, "h", None) else 0
+
     def close(self):
         if getattr(self, "h", None):
             self.L.amg_hier_destroy(self.h)
@@ -279,6 +292,7 @@ def approximate_spectral_radius_device(A, dinv=None, tol=0.01, maxiter=15, resta
     """approximate_spectral_radius (util/linalg.py:282-416) of diag(dinv)*A (dinv None: A) with the
     Arnoldi iterations on the GPU.  Same restart logic and the same single np.random.rand(n, 1)
     draw as the reference; dots/norms are device reductions, so rho agrees to rounding, not bitwise."""
+    _check_estimate_arguments(A, maxiter, restart)
     op = device_operator(A)
     n = A.shape[0]
     v0 = np.random.rand(n, 1).ravel()
@@ -298,4 +312,5 @@ def approximate_spectral_radius_device(A, dinv=None, tol=0.01, maxiter=15, resta
                 raise NotImplementedError("complex Ritz vector in the device spectral-radius estimate")
             coef = coef.real
         v0 = op.combine(coef)
+    op.free_workspace()          # the Krylov basis ((maxiter + 1) n doubles) is only needed during the estimate
     return float(np.abs(ev[max_index]))

@@ -9,8 +9,19 @@ import scipy.sparse as sps
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def hier_cases():
+def _all_cases():
     return sorted(os.path.basename(p)[5:-4] for p in glob.glob(os.path.join(GOLDEN, "hier_*.npz")))
+
+
+def hier_cases():
+    """hierarchies solved by the stand-alone cycle iteration"""
+    return [c for c in _all_cases() if not c.startswith("accel_")]
+
+
+def accel_cases(method=None):
+    """hierarchies solved by the reference with Krylov acceleration (oracle/gen_golden_r2.py); the method is
+    the second word of the name: accel_<method>_..."""
+    return [c for c in _all_cases() if c.startswith("accel_") and (method is None or c.split("_")[1] == method)]
 
 
 def get_mat(z, key):
@@ -77,19 +88,42 @@ def load_kernels():
     return cases
 
 
-def history_tolerance(A, x, b, ref):
-    """Per-entry tolerance for comparing residual-norm histories.
-
-    north_star: 1e-12 relative.  A residual b - A*x evaluated in fp64 carries an
-    absolute rounding floor of ~eps*(|b| + |A||x|) whatever the summation order
-    (the reference's coarse solve and norm go through BLAS, order unspecified),
-    so once r_k approaches that floor a purely relative bound is meaningless:
-    tol_k = 1e-12 * r_k + 100*eps*(||b||_2 + ||A||_inf ||x||_2).
-    """
+def evaluation_floor(A, x, b):
+    """eps * (||b||_2 + ||A||_inf ||x||_2): the size of the rounding error any fp64 evaluation of b - A x carries,
+    whatever the summation order"""
     eps = np.finfo(np.float64).eps
     Ainf = abs(sps.csr_matrix(A)).sum(axis=1).max()
-    floor = 100 * eps * (np.linalg.norm(b) + Ainf * np.linalg.norm(x))
-    return 1e-12 * np.asarray(ref) + floor
+    return eps * (np.linalg.norm(b) + Ainf * np.linalg.norm(x))
+
+
+FLOOR_FACTOR = 0.25
+
+
+def history_tolerance(A, x, b, ref):
+    """Per-entry tolerance for comparing a residual-norm history with the reference's.
+
+    north_star: 1e-12 relative.  The reference's coarse solve and norms go through BLAS, whose summation order
+    is unspecified, so its iterates agree with a sequential-order evaluation only to rounding, and a residual
+    b - A x_k evaluated from such iterates differs by a fraction of evaluation_floor() in ABSOLUTE terms
+    however small r_k has become.  Measured over the 20 reference-built hierarchies (oracle vs reference):
+    worst |r_k - ref_k| = 0.052 floors.  Hence
+        tol_k = 1e-12 * ref_k + 0.25 * floor,
+    five times the worst case seen (round 1 used 100 floors).  Entries above 1e12 floors are additionally held
+    to the pure relative bound by assert_history()."""
+    return 1e-12 * np.asarray(ref) + FLOOR_FACTOR * evaluation_floor(A, x, b)
+
+
+def assert_history(res, ref, A, x, b):
+    """the comparison every history test makes: entry-wise tolerance above, and 1e-12 RELATIVE alone wherever
+    the residual is large enough for a relative statement to mean something (r_k > 1e12 floors)"""
+    res, ref = np.asarray(res, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    assert len(res) == len(ref), "history length %d, reference %d" % (len(res), len(ref))
+    tol = history_tolerance(A, x, b, ref)
+    d = np.abs(res - ref)
+    assert np.all(d <= tol), "worst |res - ref| / tol = %g" % np.max(d / tol)
+    big = ref > 1e12 * evaluation_floor(A, x, b)
+    assert np.all(d[big] <= 1e-12 * ref[big]), "relative deviation %g on a large residual" % np.max(d[big] / ref[big])
+    return tol
 
 
 def smoother_spec(d):
