@@ -69,6 +69,17 @@ def host_lib():
         L.amgsetup_smooth_prolongator.argtypes = [C.c_int, C.c_int, lp, ip, dp, dp, C.c_double, lp, ip, dp,
                                                   lp, ip, dp]
         L.amgsetup_smooth_prolongator.restype = C.c_int64
+        L.amgsetup_bsr_matmat_count.argtypes = [C.c_int, lp, ip, lp, ip, lp]
+        L.amgsetup_bsr_matmat_count.restype = C.c_int64
+        L.amgsetup_bsr_matmat_fill.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, lp, ip, dp, lp, ip, dp, lp, ip, dp]
+        L.amgsetup_bsr_matmat_fill.restype = None
+        L.amgsetup_bsr_transpose.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, lp, ip, dp, lp, ip, dp]
+        L.amgsetup_bsr_transpose.restype = None
+        L.amgsetup_smooth_prolongator_block.argtypes = [C.c_int, C.c_int, C.c_int, lp, ip, dp, dp, C.c_double, ip, dp, lp, ip,
+                                                        dp, ip]
+        L.amgsetup_smooth_prolongator_block.restype = C.c_int64
+        L.amgsetup_kuhn_p1_diffusion.argtypes = [C.c_int, dp, dp, lp, ip, dp]
+        L.amgsetup_kuhn_p1_diffusion.restype = C.c_int64
         L.amgsetup_greedy_coloring.argtypes = [C.c_int, ip, ip, ip]
         L.amgsetup_greedy_coloring.restype = C.c_int
         L.amgsetup_extract_subblocks.argtypes = [ip, ip, dp, dp, ip, ip, ip, C.c_int, C.c_int]
@@ -218,57 +229,64 @@ def fit_candidates(AggOp, B, tol=1e-10):
     BS = K1 * K2
     Bb = B.reshape(-1, K1, K2)
     # copy blocks: Qx[ii] = B block of fine node Ai[ii]   (smoothed_aggregation.h:341-351)
-    Qx = Bb[Ai].copy()
-    R = np.zeros((N_coarse, K2, K2), dtype=B.dtype)
-    if K1 == 1 and K2 == 1:
-        # scalar fast path (one candidate, scalar unknowns)
-        q = np.empty(nnz, dtype=np.float64)
-        Rv = np.zeros(N_coarse, dtype=np.float64)
-        Bv = np.ascontiguousarray(B.ravel(), dtype=np.float64)
-        Ap32 = np.ascontiguousarray(Ap, dtype=np.intc)
-        Ai32 = np.ascontiguousarray(Ai, dtype=np.intc)
-        host_lib().amgsetup_fit_candidates_scalar(N_coarse, _ip(Ap32), _ip(Ai32), _dp(Bv), _dp(q), _dp(Rv),
-                                                  float(tol))
-        R[:, 0, 0] = Rv
-        Qx = q.reshape(-1, 1, 1)
-    else:
-        # general case: modified Gram-Schmidt per aggregate, batched over the aggregates that have the
-        # same number of members; every sum runs over the rows in storage order, one row at a time,
-        # exactly as the reference's scalar loops do (smoothed_aggregation.h:367-452)
-        counts = np.diff(Ap)
-        for m in np.unique(counts):
-            if m == 0:
-                continue
-            aggs = np.nonzero(counts == m)[0]
-            pos = (Ap[aggs][:, None] + np.arange(m)[None, :]).astype(np.int64)      # (ng, m)
-            blk = Qx[pos].reshape(len(aggs), m * K1, K2).copy()
-            nrow = m * K1
-            for bj in range(K2):
-                norm_j = np.zeros(len(aggs))
-                for rr in range(nrow):
-                    norm_j = norm_j + blk[:, rr, bj] * blk[:, rr, bj]
-                norm_j = np.sqrt(norm_j)
-                threshold_j = tol * norm_j
-                for bi in range(bj):
-                    dot_prod = np.zeros(len(aggs))
-                    for rr in range(nrow):
-                        dot_prod = dot_prod + blk[:, rr, bi] * blk[:, rr, bj]
-                    blk[:, :, bj] = blk[:, :, bj] - dot_prod[:, None] * blk[:, :, bi]
-                    R[aggs, bi, bj] = dot_prod
-                norm_j = np.zeros(len(aggs))
-                for rr in range(nrow):
-                    norm_j = norm_j + blk[:, rr, bj] * blk[:, rr, bj]
-                norm_j = np.sqrt(norm_j)
-                ok = norm_j > threshold_j
-                scale = np.zeros(len(aggs))
-                scale[ok] = 1.0 / norm_j[ok]
-                R[aggs, bj, bj] = np.where(ok, norm_j, 0.0)
-                blk[:, :, bj] = blk[:, :, bj] * scale[:, None]
-            Qx[pos] = blk.reshape(len(aggs), m, K1, K2)
+    Qx, R = _aggregate_qr(Bb[Ai], Ap, N_coarse, K1, K2, tol)
     Q = bsr_matrix((Qx.swapaxes(1, 2).copy(), Ai, Ap), shape=(K2 * N_coarse, K1 * N_fine))
     Q = Q.T.tobsr()
     R = R.reshape(-1, K2)
     return Q, R
+
+
+def _aggregate_qr(Qx, Ap, N_coarse, K1, K2, tol):
+    """Per-aggregate modified Gram-Schmidt of the candidate blocks Qx (one K1 x K2 block per member, members of
+    aggregate j at Ap[j]:Ap[j+1]) -> (Q blocks, R (N_coarse, K2, K2)); smoothed_aggregation.h:341-452."""
+    Qx = np.array(Qx, dtype=np.float64)
+    nnz = Qx.shape[0]
+    R = np.zeros((N_coarse, K2, K2), dtype=np.float64)
+    if K1 == 1 and K2 == 1:
+        # scalar fast path (one candidate, scalar unknowns)
+        q = np.empty(nnz, dtype=np.float64)
+        Rv = np.zeros(N_coarse, dtype=np.float64)
+        Bv = np.ascontiguousarray(Qx.ravel(), dtype=np.float64)
+        Ap32 = np.ascontiguousarray(Ap, dtype=np.intc)
+        Ai32 = np.arange(nnz, dtype=np.intc)
+        host_lib().amgsetup_fit_candidates_scalar(N_coarse, _ip(Ap32), _ip(Ai32), _dp(Bv), _dp(q), _dp(Rv),
+                                                  float(tol))
+        R[:, 0, 0] = Rv
+        return q.reshape(-1, 1, 1), R
+    # general case: modified Gram-Schmidt per aggregate, batched over the aggregates that have the
+    # same number of members; every sum runs over the rows in storage order, one row at a time,
+    # exactly as the reference's scalar loops do (smoothed_aggregation.h:367-452)
+    counts = np.diff(Ap)
+    for m in np.unique(counts):
+        if m == 0:
+            continue
+        aggs = np.nonzero(counts == m)[0]
+        pos = (np.asarray(Ap)[aggs][:, None] + np.arange(m)[None, :]).astype(np.int64)      # (ng, m)
+        blk = Qx[pos].reshape(len(aggs), m * K1, K2).copy()
+        nrow = m * K1
+        for bj in range(K2):
+            norm_j = np.zeros(len(aggs))
+            for rr in range(nrow):
+                norm_j = norm_j + blk[:, rr, bj] * blk[:, rr, bj]
+            norm_j = np.sqrt(norm_j)
+            threshold_j = tol * norm_j
+            for bi in range(bj):
+                dot_prod = np.zeros(len(aggs))
+                for rr in range(nrow):
+                    dot_prod = dot_prod + blk[:, rr, bi] * blk[:, rr, bj]
+                blk[:, :, bj] = blk[:, :, bj] - dot_prod[:, None] * blk[:, :, bi]
+                R[aggs, bi, bj] = dot_prod
+            norm_j = np.zeros(len(aggs))
+            for rr in range(nrow):
+                norm_j = norm_j + blk[:, rr, bj] * blk[:, rr, bj]
+            norm_j = np.sqrt(norm_j)
+            ok = norm_j > threshold_j
+            scale = np.zeros(len(aggs))
+            scale[ok] = 1.0 / norm_j[ok]
+            R[aggs, bj, bj] = np.where(ok, norm_j, 0.0)
+            blk[:, :, bj] = blk[:, :, bj] * scale[:, None]
+        Qx[pos] = blk.reshape(len(aggs), m, K1, K2)
+    return Qx, R
 
 
 # --------------------------------------------------------------------------- prolongation smoothing
@@ -381,7 +399,7 @@ def _improve(method, A, B):
                 L.amgsetup_block_gauss_seidel(_ip(Ap), _ip(Aj), _dp(Ax), _dp(x), _dp(b), _dp(Dinv), 0, nb, 1, bs)
     else:
         raise NotImplementedError("improve_candidates=%r on this matrix is outside the restated setup" % (fn,))
-    for j in range(B.shape[1]):
+    def relax_column(j):
         x = np.ascontiguousarray(B[:, j], dtype=np.float64).copy()
         for it in range(its):
             if sw in ("forward", "symmetric"):
@@ -389,6 +407,15 @@ def _improve(method, A, B):
             if sw in ("backward", "symmetric"):
                 sweep(x, True)
         out[:, j] = x
+
+    if B.shape[1] > 1 and n > 100000:
+        # the candidates are relaxed independently (each sweep is sequential): one host thread per column
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(B.shape[1], 8)) as pool:
+            list(pool.map(relax_column, range(B.shape[1])))
+    else:
+        for j in range(B.shape[1]):
+            relax_column(j)
     return out
 
 
@@ -496,6 +523,11 @@ def _as_bsr11(arrs, shape):
 def _scalar_fast_path_ok(A, B, strength_l, aggregate_l, smooth_l):
     if not (isspmatrix_csr(A) or (isspmatrix_bsr(A) and A.blocksize == (1, 1))):
         return False
+    return _default_options(B, strength_l, aggregate_l, smooth_l)
+
+
+def _default_options(B, strength_l, aggregate_l, smooth_l):
+    """one candidate, symmetric strength with theta = 0, standard aggregation, one Jacobi smoothing step"""
     if B.shape[1] != 1:
         return False
     fn, kw = unpack_arg(strength_l)
@@ -588,6 +620,117 @@ def _extend_scalar(levels, smooth_l, keep, rho_fn):
     levels[-1].B = Bc.reshape(-1, 1)
 
 
+def _block_fast_path_ok(A, B, strength_l, aggregate_l, smooth_l):
+    """square-block BSR operator (any number of candidates), default strength / aggregation / smoothing"""
+    if not (isspmatrix_bsr(A) and A.blocksize[0] == A.blocksize[1] and 1 < A.blocksize[0] <= 16):
+        return False
+    return _default_options(np.empty((1, 1)), strength_l, aggregate_l, smooth_l)
+
+
+def _bsr_matmat(Aa, Ba, n_brow, R, N, Cc):
+    """C = A*B for BSR arrays with R x N and N x Cc blocks: scipy's bsr_matmat arithmetic and block order"""
+    (Ap, Aj, Ax), (Bp, Bj, Bx) = Aa, Ba
+    L = host_lib()
+    Cp = np.empty(n_brow + 1, dtype=np.int64)
+    nb = L.amgsetup_bsr_matmat_count(n_brow, _lp(Ap), _ip(Aj), _lp(Bp), _ip(Bj), _lp(Cp))
+    Cj = np.empty(nb, dtype=np.intc)
+    Cx = np.empty(nb * R * Cc, dtype=np.float64)
+    L.amgsetup_bsr_matmat_fill(n_brow, R, N, Cc, _lp(Ap), _ip(Aj), _dp(Ax), _lp(Bp), _ip(Bj), _dp(Bx), _lp(Cp), _ip(Cj), _dp(Cx))
+    return Cp, Cj, Cx
+
+
+def _extend_block(levels, smooth_l, keep, rho_fn):
+    """extend_hierarchy for a BSR(bs, bs) operator (BASELINE configuration C5: 3x3 blocks, the default bs
+    candidates) on flat arrays with the host helpers -- the arithmetic and the stored block order of the generic
+    scipy path (bsr_matmat, bsr_minus_bsr, bsr_transpose), row-parallel and sized for 5*10^7 unknowns."""
+    A = levels[-1].A
+    B = np.asarray(levels[-1].B, dtype=np.float64)
+    L = host_lib()
+    bs = A.blocksize[0]
+    K = B.shape[1]
+    n = A.shape[0]
+    nb = n // bs
+    verbose = os.environ.get("AMG_SETUP_VERBOSE", "0") != "0"
+    _t = [time.perf_counter()]
+
+    def lap(what):
+        if verbose:
+            now = time.perf_counter()
+            print("[setup] level %d (%d rows, bs %d) %-22s %6.2fs" % (len(levels) - 1, n, bs, what, now - _t[0]), flush=True)
+            _t[0] = now
+    Ap = np.ascontiguousarray(A.indptr, dtype=np.int64)
+    Ap32 = np.ascontiguousarray(A.indptr, dtype=np.intc)
+    Aj = np.ascontiguousarray(A.indices, dtype=np.intc)
+    Ax = np.ascontiguousarray(A.data.reshape(-1), dtype=np.float64)
+    # strength with theta = 0 keeps every block (strength.py:283-287); the aggregation reads the block pattern
+    agg = np.empty(nb, dtype=np.intc)
+    cpts = np.empty(nb, dtype=np.intc)
+    n_agg = L.amgsetup_standard_aggregation(nb, _ip(Ap32), _ip(Aj), _ip(agg), _ip(cpts))
+    del cpts
+    lap("aggregation")
+    if n_agg == 0:
+        raise ValueError("aggregation produced no aggregates")
+    # tentative prolongator: per-aggregate QR of the candidates (fit_candidates' arithmetic), as one
+    # bs x K block per aggregated node
+    Tx, Bc = _fit_candidates_flat(agg, n_agg, B, bs)
+    lap("tentative prolongator")
+    fn, kw = unpack_arg(smooth_l)
+    omega = kw.get("omega", 4.0 / 3.0)
+    D_inv = get_diagonal(A, inv=True)
+    rho = rho_fn(A, D_inv)
+    lap("rho(D^-1 A)")
+    w = omega / rho
+    Pp = np.empty(nb + 1, dtype=np.int64)
+    xs = C.c_int(0)
+    inull, dnull = C.POINTER(C.c_int)(), C.POINTER(C.c_double)()
+    pb = L.amgsetup_smooth_prolongator_block(nb, bs, K, _lp(Ap), _ip(Aj), _dp(Ax), _dp(D_inv), float(w), _ip(agg), _dp(Tx),
+                                             _lp(Pp), inull, dnull, C.byref(xs))
+    Pj = np.empty(pb, dtype=np.intc)
+    Px = np.empty(pb * bs * K, dtype=np.float64)
+    L.amgsetup_smooth_prolongator_block(nb, bs, K, _lp(Ap), _ip(Aj), _dp(Ax), _dp(D_inv), float(w), _ip(agg), _dp(Tx),
+                                        _lp(Pp), _ip(Pj), _dp(Px), C.byref(xs))
+    del Tx
+    lap("smoothed prolongator")
+    Rp = np.empty(n_agg + 1, dtype=np.int64)
+    Rj = np.empty(pb, dtype=np.intc)
+    Rx = np.empty(pb * bs * K, dtype=np.float64)
+    L.amgsetup_bsr_transpose(nb, n_agg, bs, K, _lp(Pp), _ip(Pj), _dp(Px), _lp(Rp), _ip(Rj), _dp(Rx))
+    lap("R = P^T")
+    RA = _bsr_matmat((Rp, Rj, Rx), (Ap, Aj, Ax), n_agg, K, bs, bs)
+    lap("R*A")
+    Ac = _bsr_matmat(RA, (Pp, Pj, Px), n_agg, K, bs, K)
+    del RA
+    lap("(R*A)*P")
+    if max(Pp[-1], Ac[0][-1]) >= 2 ** 31:
+        raise ValueError("operator exceeds int32 indices")
+    P = bsr_matrix((Px.reshape(-1, bs, K), Pj, Pp.astype(np.intc)), shape=(n, n_agg * K), copy=False)
+    R = bsr_matrix((Rx.reshape(-1, K, bs), Rj, Rp.astype(np.intc)), shape=(n_agg * K, n), copy=False)
+    Anew = bsr_matrix((Ac[2].reshape(-1, K, K), Ac[1], Ac[0].astype(np.intc)), shape=(n_agg * K, n_agg * K), copy=False)
+    if keep:
+        levels[-1].AggOp = agg
+    levels[-1].P = P
+    levels[-1].R = R
+    levels.append(multilevel_solver.level())
+    Anew.symmetry = A.symmetry
+    levels[-1].A = Anew
+    levels[-1].B = Bc
+
+
+def _fit_candidates_flat(agg, n_agg, B, K1, tol=1e-10):
+    """fit_candidates (tentative.py:19-166) on the aggregate id of every node instead of AggOp:
+    -> (Tx: (n_nodes, K1, K2) blocks of the tentative prolongator, zero for unaggregated nodes; R: (n_agg*K2, K2))."""
+    n_nodes = len(agg)
+    K2 = B.shape[1]
+    member = np.nonzero(agg >= 0)[0]
+    order = member[np.argsort(agg[member], kind="stable")]          # CSC order of AggOp: by aggregate, ascending node
+    counts = np.bincount(agg[member], minlength=n_agg)
+    Ap = np.concatenate(([0], np.cumsum(counts)))
+    Qx, R = _aggregate_qr(B.reshape(-1, K1, K2)[order], Ap, n_agg, K1, K2, tol)
+    Tx = np.zeros((n_nodes, K1, K2), dtype=np.float64)
+    Tx[order] = Qx
+    return np.ascontiguousarray(Tx.reshape(-1)), R.reshape(-1, K2)
+
+
 def _rho_D_inv_A_host(A, D_inv):
     """approximate_spectral_radius(scale_rows(A, D_inv)) as the reference does it (smooth.py:169-171);
     operators beyond util.DEVICE_RHO_MIN_ROWS run the Arnoldi iterations on the GPU."""
@@ -609,6 +752,8 @@ def extend_hierarchy(levels, strength, aggregate, smooth, improve_candidates, ke
     li = len(levels) - 1
     if not keep and _scalar_fast_path_ok(A, B, strength[li], aggregate[li], smooth[li]):
         return _extend_scalar(levels, smooth[li], keep, rho_fn or _rho_D_inv_A_host)
+    if not keep and _block_fast_path_ok(A, B, strength[li], aggregate[li], smooth[li]):
+        return _extend_block(levels, smooth[li], keep, rho_fn or _rho_D_inv_A_host)
 
     fn, kwargs = unpack_arg(strength[len(levels) - 1])
     if fn == "symmetric":

@@ -187,22 +187,9 @@ int launch_combine(double *out, const double *V, const double *coef_dev, int m, 
 // x = M b with M given transposed (Mt[k*n+i] = M[i][k]); sequential sum per row
 int launch_dense_apply(const double *Mt, const double *b, double *x, int n, hipStream_t st);
 
-// ---------------------------------------------------------------- BSR kernels (one thread per block row)
+// ---------------------------------------------------------------- BSR kernels
 enum BlockMode { BM_BSR_JACOBI, BM_BLOCK_JACOBI, BM_BSR_GS, BM_BLOCK_GS,
                  BM_SPMV };   // operator application straight from the blocks (scipy bsr_matvec order); epilogue = smode
-struct BlockArgs {
-    const int *Ap; const int *Aj; const double *Ax;   // BSR arrays (blocks row-major bs x bs)
-    int bs;
-    const int *rows;        // block rows to process (list) or null -> first + t*step
-    int first, step, count;
-    int intra_reverse;      // point-BSR kernels: reverse intra-block order (row_step < 0)
-    const double *xin;      // vector read for off-diagonal products (temp for Jacobi, x for GS)
-    double *xout;
-    const double *b;
-    const double *Dinv;
-    double omega;
-};
-int launch_block(BlockMode m, const BlockArgs &a, hipStream_t st);
 
 // streamed variant over a contiguous range of block rows of a (possibly level-permuted) BSR operator
 struct BsrStreamArgs {
@@ -221,7 +208,9 @@ struct BsrStreamArgs {
     int smode;
     const double *v2;
     double c0, gscale;
+    double *out2;           // SM_RESIDUAL_SUMSQ: one partial sum of squares per workgroup
 };
+int bsr_stream_blocks(const BsrStreamArgs &a, long nblocks_hint);   // workgroups launch_bsr_stream will use
 bool bsr_spmv_supports(StreamMode mode);
 bool bsr_spmv_enabled(int bs);
 void set_bsr_spmv(int on);

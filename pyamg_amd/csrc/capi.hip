@@ -139,21 +139,6 @@ int gs_csr_common(const int *Ap, int Ap_size, const int *Aj, const double *Ax, d
     return dx.to_host(x, sizeof(double) * (size_t)x_size);
 }
 
-int run_block_levels(const Schedule &S, const DevBsr &Ab, BlockMode mode, const double *Dinv, double *x,
-                     const double *b, int intra_reverse)
-{
-    BlockArgs a;
-    std::memset(&a, 0, sizeof(a));
-    a.Ap = Ab.Ap; a.Aj = Ab.Aj; a.Ax = Ab.Ax; a.bs = Ab.bs;
-    a.xin = x; a.xout = x; a.b = b; a.Dinv = Dinv; a.omega = 1.0; a.intra_reverse = intra_reverse;
-    for (int l = 0; l < S.nlevels(); ++l) {
-        a.rows = S.rows + S.level_ptr[l];
-        a.count = S.level_ptr[l + 1] - S.level_ptr[l];
-        CHK(launch_block(mode, a, nullptr));
-    }
-    return 0;
-}
-
 }  // namespace
 
 extern "C" {
@@ -201,13 +186,23 @@ int amgcore_bsr_gauss_seidel_f64(const int Ap[], int Ap_size, const int Aj[], in
     if (tasks.empty()) return 0;
     if (blocksize == 1) return gs_csr_common(Ap, Ap_size, Aj, Ax, x, x_size, b, b_size, tasks, true);
     SchedHolder sh;
-    CHK(build_block_schedule(Ap, Aj, nb, tasks.data(), (int)tasks.size(), sh.S, nullptr));
-    BsrHolder bh;
-    CHK(upload_bsr(bh.M, nb, blocksize, Ap, Aj, Ax, nullptr));
+    CHK(build_block_schedule(Ap, Aj, nb, tasks.data(), (int)tasks.size(), sh.S, nullptr, Ax, blocksize));
     DBuf dx, db;
     CHK(dx.from_host(x, sizeof(double) * (size_t)x_size));
     CHK(db.from_host(b, sizeof(double) * (size_t)b_size));
-    CHK(run_block_levels(sh.S, bh.M, BM_BSR_GS, nullptr, dx.d(), db.d(), row_step < 0));
+    // the task list is already in sweep order: levels ascending; a backward sweep reverses the order inside a block
+    {
+        Schedule &S = sh.S;
+        BsrStreamArgs a;
+        std::memset(&a, 0, sizeof(a));
+        a.Ap = S.Gb.Ap; a.Aj = S.Gb.Aj; a.Ax = S.Gb.Ax; a.bs = blocksize; a.rowmap = S.rows;
+        a.intra_reverse = row_step < 0 ? 1 : 0;
+        a.xin = dx.d(); a.xout = dx.d(); a.b = db.d(); a.omega = 1.0;
+        for (int l = 0; l < S.nlevels(); ++l) {
+            a.brow_lo = S.level_ptr[l]; a.brow_hi = S.level_ptr[l + 1];
+            CHK(launch_bsr_stream(BM_BSR_GS, a, 0, nullptr));
+        }
+    }
     AMG_HIP(hipDeviceSynchronize());
     return dx.to_host(x, sizeof(double) * (size_t)x_size);
 }
@@ -267,8 +262,8 @@ int amgcore_bsr_jacobi_f64(const int Ap[], int Ap_size, const int Aj[], int Aj_s
     std::vector<int> rows;
     CHK(sweep_rows(row_start, row_stop, row_step, std::min(nb, std::min(std::min(x_size, b_size), temp_size) / blocksize), rows));
     if (rows.empty()) return 0;
-    BsrHolder bh;
-    CHK(upload_bsr(bh.M, nb, blocksize, Ap, Aj, Ax, nullptr));
+    SchedHolder sh;          // the listed block rows, copied in list order: one streamed slice
+    CHK(build_block_schedule(Ap, Aj, nb, rows.data(), (int)rows.size(), sh.S, nullptr, Ax, blocksize, true));
     DBuf dx, db, dt;
     CHK(dx.from_host(x, sizeof(double) * (size_t)x_size));
     CHK(db.from_host(b, sizeof(double) * (size_t)b_size));
@@ -276,12 +271,7 @@ int amgcore_bsr_jacobi_f64(const int Ap[], int Ap_size, const int Aj[], int Aj_s
     long ncopy = (long)std::abs(row_stop - row_start) * blocksize;     // relaxation.h:303-305
     if (ncopy > std::min(x_size, temp_size)) { set_error("temp/x too short"); return AMG_EINVAL; }
     AMG_HIP(hipMemcpy(dt.p, dx.p, sizeof(double) * (size_t)ncopy, hipMemcpyDeviceToDevice));
-    BlockArgs a;
-    std::memset(&a, 0, sizeof(a));
-    a.Ap = bh.M.Ap; a.Aj = bh.M.Aj; a.Ax = bh.M.Ax; a.bs = blocksize;
-    a.first = row_start; a.step = row_step; a.count = (int)rows.size();
-    a.xin = dt.d(); a.xout = dx.d(); a.b = db.d(); a.omega = omega[0];
-    CHK(launch_block(BM_BSR_JACOBI, a, nullptr));
+    CHK(sweep_block_schedule(sh.S, BM_BSR_JACOBI, nullptr, dt.d(), dx.d(), db.d(), omega[0], false, nullptr));
     AMG_HIP(hipDeviceSynchronize());
     CHK(dx.to_host(x, sizeof(double) * (size_t)x_size));
     return dt.to_host(temp, sizeof(double) * (size_t)temp_size);
@@ -302,8 +292,8 @@ int amgcore_block_jacobi_f64(const int Ap[], int Ap_size, const int Aj[], int Aj
     CHK(sweep_rows(row_start, row_stop, row_step, std::min(nb, std::min(std::min(x_size, b_size), temp_size) / blocksize), rows));
     if (rows.empty()) return 0;
     if ((long)nb * blocksize * blocksize > Tx_size) { set_error("Dinv too short"); return AMG_EINVAL; }
-    BsrHolder bh;
-    CHK(upload_bsr(bh.M, nb, blocksize, Ap, Aj, Ax, nullptr));
+    SchedHolder sh;
+    CHK(build_block_schedule(Ap, Aj, nb, rows.data(), (int)rows.size(), sh.S, nullptr, Ax, blocksize, true));
     DBuf dx, db, dt, dd, dr;
     CHK(dx.from_host(x, sizeof(double) * (size_t)x_size));
     CHK(db.from_host(b, sizeof(double) * (size_t)b_size));
@@ -313,12 +303,7 @@ int amgcore_block_jacobi_f64(const int Ap[], int Ap_size, const int Aj[], int Aj
     for (int r : rows)
         AMG_HIP(hipMemcpyAsync(dt.d() + (long)r * blocksize, dx.d() + (long)r * blocksize,
                                sizeof(double) * (size_t)blocksize, hipMemcpyDeviceToDevice, nullptr));
-    BlockArgs a;
-    std::memset(&a, 0, sizeof(a));
-    a.Ap = bh.M.Ap; a.Aj = bh.M.Aj; a.Ax = bh.M.Ax; a.bs = blocksize;
-    a.first = row_start; a.step = row_step; a.count = (int)rows.size();
-    a.xin = dt.d(); a.xout = dx.d(); a.b = db.d(); a.Dinv = dd.d(); a.omega = omega[0];
-    CHK(launch_block(BM_BLOCK_JACOBI, a, nullptr));
+    CHK(sweep_block_schedule(sh.S, BM_BLOCK_JACOBI, dd.d(), dt.d(), dx.d(), db.d(), omega[0], false, nullptr));
     AMG_HIP(hipDeviceSynchronize());
     CHK(dx.to_host(x, sizeof(double) * (size_t)x_size));
     return dt.to_host(temp, sizeof(double) * (size_t)temp_size);
@@ -338,14 +323,12 @@ int amgcore_block_gauss_seidel_f64(const int Ap[], int Ap_size, const int Aj[], 
     if (tasks.empty()) return 0;
     if ((long)nb * blocksize * blocksize > Tx_size) { set_error("Dinv too short"); return AMG_EINVAL; }
     SchedHolder sh;
-    CHK(build_block_schedule(Ap, Aj, nb, tasks.data(), (int)tasks.size(), sh.S, nullptr));
-    BsrHolder bh;
-    CHK(upload_bsr(bh.M, nb, blocksize, Ap, Aj, Ax, nullptr));
+    CHK(build_block_schedule(Ap, Aj, nb, tasks.data(), (int)tasks.size(), sh.S, nullptr, Ax, blocksize));
     DBuf dx, db, dd;
     CHK(dx.from_host(x, sizeof(double) * (size_t)x_size));
     CHK(db.from_host(b, sizeof(double) * (size_t)b_size));
     CHK(dd.from_host(Tx, sizeof(double) * (size_t)Tx_size));
-    CHK(run_block_levels(sh.S, bh.M, BM_BLOCK_GS, dd.d(), dx.d(), db.d(), 0));
+    CHK(sweep_block_schedule(sh.S, BM_BLOCK_GS, dd.d(), dx.d(), dx.d(), db.d(), 1.0, false, nullptr));
     AMG_HIP(hipDeviceSynchronize());
     return dx.to_host(x, sizeof(double) * (size_t)x_size);
 }

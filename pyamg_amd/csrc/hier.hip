@@ -440,11 +440,22 @@ int build_csr_schedule(const int *Ap, const int *Aj, const double *Ax, int n, co
 }
 
 int build_block_schedule(const int *Ap, const int *Aj, int nb, const int *tasks, int ntasks,
-                         Schedule &S, hipStream_t st, const double *Ax, int bs)
+                         Schedule &S, hipStream_t st, const double *Ax, int bs, bool independent)
 {
     (void)st;
     std::vector<int> order;
-    CHK(build_levels(nb, Ap, Aj, tasks, ntasks, S.level_ptr, order));
+    if (independent) {
+        // Jacobi-type passes: the listed block rows do not depend on each other -- one level, in list order
+        S.level_ptr.assign({0, ntasks});
+        order.resize((size_t)ntasks);
+        for (int t = 0; t < ntasks; ++t) order[(size_t)t] = t;
+        for (int t = 0; t < ntasks; ++t) {
+            const int i = tasks ? tasks[t] : t;
+            if (i < 0 || i >= nb) { set_error("schedule: row index out of range"); return AMG_EINVAL; }
+        }
+    } else {
+        CHK(build_levels(nb, Ap, Aj, tasks, ntasks, S.level_ptr, order));
+    }
     S.ntasks = ntasks;
     std::vector<int> rows((size_t)ntasks);
     for (int k = 0; k < ntasks; ++k) rows[k] = tasks ? tasks[order[k]] : order[k];
@@ -483,18 +494,34 @@ static StreamArgs base_args(const DevCsr &M)
 }
 
 // the storage form an operator application runs from: stencil, offset-pattern or plain CSR
+static BsrStreamArgs block_spmv_args(const DevBsr &B, StreamMode mode, const StreamArgs &a)
+{
+    BsrStreamArgs q;
+    std::memset(&q, 0, sizeof(q));
+    q.Ap = B.Ap; q.Aj = B.Aj; q.Ax = B.Ax; q.bs = B.bs;
+    q.brow_lo = 0; q.brow_hi = B.nbrows;
+    q.xin = a.xg; q.xout = a.out; q.b = a.b; q.v2 = a.v2; q.c0 = a.c0; q.out2 = a.out2;
+    q.gscale = (a.gscale == 0.0) ? 1.0 : a.gscale;
+    q.smode = (int)mode;
+    return q;
+}
+
+// an operator kept by its square blocks only (no expanded CSR copy) must be applied from them
+static bool applies_from_blocks(const DevCsr &M, StreamMode mode, const StreamArgs &a)
+{
+    if (!(M.blk && M.blk->Ap)) return false;
+    if (!M.Ap) return true;
+    return bsr_spmv_enabled(M.blk->bs) && bsr_spmv_supports(mode) && a.row_lo == 0 && a.row_hi == M.nrows;
+}
+
 int apply_operator(const DevCsr &M, StreamMode mode, const StreamArgs &a, hipStream_t st)
 {
-    if (M.blk && M.blk->Ap && bsr_spmv_enabled(M.blk->bs) && bsr_spmv_supports(mode) && a.row_lo == 0 && a.row_hi == M.nrows) {
-        const DevBsr &B = *M.blk;
-        BsrStreamArgs q;
-        std::memset(&q, 0, sizeof(q));
-        q.Ap = B.Ap; q.Aj = B.Aj; q.Ax = B.Ax; q.bs = B.bs;
-        q.brow_lo = 0; q.brow_hi = B.nbrows;
-        q.xin = a.xg; q.xout = a.out; q.b = a.b; q.v2 = a.v2; q.c0 = a.c0;
-        q.gscale = (a.gscale == 0.0) ? 1.0 : a.gscale;
-        q.smode = (int)mode;
-        return launch_bsr_stream(BM_SPMV, q, B.nblocks, st);
+    if (applies_from_blocks(M, mode, a)) {
+        if (!bsr_spmv_supports(mode) || a.row_lo != 0 || a.row_hi != M.nrows) {
+            set_error("this operator is stored by blocks only: the requested application needs its scalar expansion");
+            return AMG_ENOTIMPL;
+        }
+        return launch_bsr_stream(BM_SPMV, block_spmv_args(*M.blk, mode, a), M.blk->nblocks, st);
     }
     if (M.st_vals && stencil_enabled() && pattern_supports(mode)) return launch_stencil(mode, a, M, st);
     if (M.pat && pattern_supports(mode)) return launch_pattern(mode, a, M, st);
@@ -549,36 +576,33 @@ int gs_sweep_csr(const Schedule &S, bool bsr1, double *x, const double *b, bool 
     return 0;
 }
 
+// one directional pass over the block rows of a schedule built WITH values (Schedule::Gb: the rows copied in level
+// order, so that every level is one contiguous slice streamed by bsr_stream_kernel); xin != x for Jacobi-type
+// passes (the operand vector is then the frozen copy), omega for the Jacobi blends
+int sweep_block_schedule(const Schedule &S, BlockMode mode, const double *Dinv, const double *xin, double *x, const double *b,
+                         double omega, bool reverse, hipStream_t st)
+{
+    if (!S.Gb.Ap) { set_error("block schedule holds no operator copy"); return AMG_ESTATE; }
+    const int nl = S.nlevels();
+    BsrStreamArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.Ap = S.Gb.Ap; a.Aj = S.Gb.Aj; a.Ax = S.Gb.Ax; a.bs = S.Gb.bs;
+    a.rowmap = S.rows; a.intra_reverse = reverse ? 1 : 0;
+    a.xin = xin; a.xout = x; a.b = b; a.Dinv = Dinv; a.omega = omega;
+    for (int q = 0; q < nl; ++q) {
+        int l = reverse ? nl - 1 - q : q;
+        a.brow_lo = S.level_ptr[l];
+        a.brow_hi = S.level_ptr[l + 1];
+        CHK(launch_bsr_stream(mode, a, (long)S.Gb.nblocks * (a.brow_hi - a.brow_lo) / (S.ntasks ? S.ntasks : 1), st));
+    }
+    return 0;
+}
+
 static int gs_sweep_block(const Schedule &S, const DevBsr &Ab, BlockMode mode, const double *Dinv,
                           double *x, const double *b, bool reverse, hipStream_t st)
 {
-    const int nl = S.nlevels();
-    if (S.Gb.Ap) {
-        BsrStreamArgs a;
-        std::memset(&a, 0, sizeof(a));
-        a.Ap = S.Gb.Ap; a.Aj = S.Gb.Aj; a.Ax = S.Gb.Ax; a.bs = S.Gb.bs;
-        a.rowmap = S.rows; a.intra_reverse = reverse ? 1 : 0;
-        a.xin = x; a.xout = x; a.b = b; a.Dinv = Dinv; a.omega = 1.0;
-        for (int q = 0; q < nl; ++q) {
-            int l = reverse ? nl - 1 - q : q;
-            a.brow_lo = S.level_ptr[l];
-            a.brow_hi = S.level_ptr[l + 1];
-            CHK(launch_bsr_stream(mode, a, (long)S.Gb.nblocks * (a.brow_hi - a.brow_lo) / (S.ntasks ? S.ntasks : 1), st));
-        }
-        return 0;
-    }
-    BlockArgs a;
-    std::memset(&a, 0, sizeof(a));
-    a.Ap = Ab.Ap; a.Aj = Ab.Aj; a.Ax = Ab.Ax; a.bs = Ab.bs;
-    a.xin = x; a.xout = x; a.b = b; a.Dinv = Dinv; a.omega = 1.0;
-    a.intra_reverse = reverse ? 1 : 0;
-    for (int q = 0; q < nl; ++q) {
-        int l = reverse ? nl - 1 - q : q;
-        a.rows = S.rows + S.level_ptr[l];
-        a.count = S.level_ptr[l + 1] - S.level_ptr[l];
-        CHK(launch_block(mode, a, st));
-    }
-    return 0;
+    (void)Ab;
+    return sweep_block_schedule(S, mode, Dinv, x, x, b, 1.0, reverse, st);
 }
 
 static int bsr_stream_all(const DevBsr &Ab, BlockMode mode, const double *Dinv, const double *xin, double *xout,
@@ -884,6 +908,13 @@ static int residual_norm_to(amg_hier *h, double *slot)
     a.out = keep ? L0.r : nullptr;
     h->r_kept = keep;
     const bool stencil = L0.A.st_vals && stencil_enabled();
+    if (applies_from_blocks(L0.A, SM_RESIDUAL_SUMSQ, a)) {
+        const BsrStreamArgs q = block_spmv_args(*L0.A.blk, SM_RESIDUAL_SUMSQ, a);
+        const int nbq = bsr_stream_blocks(q, L0.A.blk->nblocks);
+        if (nbq > h->sumsq_cap) { set_error("sumsq partial buffer too small"); return AMG_ESTATE; }
+        CHK(launch_bsr_stream(BM_SPMV, q, L0.A.blk->nblocks, h->stream));
+        return launch_sum_sqrt(h->sumsq_partials, nbq, h->sumsq_partials + h->sumsq_cap, slot, h->stream);
+    }
     const int nb = stencil ? stencil_blocks(a, L0.A) : stream_blocks(a);
     if (nb > h->sumsq_cap) { set_error("sumsq partial buffer too small"); return AMG_ESTATE; }
     if (stencil) CHK(launch_stencil(SM_RESIDUAL_SUMSQ, a, L0.A, h->stream));
@@ -1112,7 +1143,17 @@ int amg_hier_set_matrix(amg_hier *h, int lvl, int which, int fmt, int nrows, int
         CHK(upload_csr(M, nrows, ncols, Ap, Aj, Ax, &h->dev_bytes));
         if (which == AMG_MAT_A) CHK(try_patterns(M, Ap, Aj, &h->dev_bytes));
         CHK(build_index16(M, Ap, &h->dev_bytes));
+    } else if (which == AMG_MAT_A && R == C && bsr_spmv_enabled(R)) {
+        // a level operator with square blocks that every application streams from the blocks themselves (8 B per
+        // entry + 4 B per block): no scalar expansion -- at 3x3 blocks and 5*10^7 rows it would hold more than
+        // 2^31 entries and cost 12 B per entry.  The block copy is uploaded below.
+        M.nrows = nrows; M.ncols = ncols;
+        M.nnz = (long)Ap[nrows / R] * R * C;
     } else {
+        if ((double)Ap[nrows / R] * R * C > 2147483647.0) {
+            set_error("the scalar expansion of this BSR operator exceeds int32 entries");
+            return AMG_EINVAL;
+        }
         std::vector<int> cp, cj;
         std::vector<double> cx;
         expand_bsr(nrows / R, R, C, Ap, Aj, Ax, cp, cj, cx);
@@ -1315,6 +1356,7 @@ static int need_schedule(amg_hier *h, Level &L, Smoother &s)
         CHK(schwarz_levels(n, ap.data(), aj.data(), s.hSj.data(), s.hSp.data(), tasks, s.sw_level_ptr, order));
         if (s.nsd) AMG_HIP(hipMemcpy(s.sw_order, order.data(), sizeof(int) * order.size(), hipMemcpyHostToDevice));
     } else if (s.kind == AMG_SM_GAUSS_SEIDEL_INDEXED) {
+        if (!L.A.Ap) { set_error("gauss_seidel_indexed needs the scalar form of the level operator (BSR level kept by blocks only)"); return AMG_ENOTIMPL; }
         std::vector<int> ap((size_t)n + 1), aj((size_t)L.A.nnz);
         std::vector<double> ax((size_t)L.A.nnz);
         AMG_HIP(hipMemcpy(ap.data(), L.A.Ap, sizeof(int) * ap.size(), hipMemcpyDeviceToHost));
@@ -1379,6 +1421,8 @@ int amg_hier_finalize(amg_hier *h)
     {
         StreamArgs a0 = base_args(h->lv[0].A);
         long need = std::max(stream_blocks(a0), stencil_blocks(a0, h->lv[0].A)) + 8;
+        if (h->lv[0].A.blk && h->lv[0].A.blk->Ap)
+            need = std::max(need, (long)bsr_stream_blocks(block_spmv_args(*h->lv[0].A.blk, SM_RESIDUAL_SUMSQ, a0), h->lv[0].A.blk->nblocks) + 8);
         if (need > h->sumsq_cap) {
             if (h->sumsq_partials) hipFree(h->sumsq_partials);
             h->sumsq_partials = nullptr;
@@ -1609,6 +1653,11 @@ int amg_hier_matvec(amg_hier *h, int lvl, int which, const double *x, double *y)
 // algorithmic bytes, SURVEY.md 8(d): bytes_spmv(M) = 12 nnz + 4 (rows+1) + 8 cols + 8 rows
 static double bytes_spmv(const DevCsr &M)
 {
+    if (M.blk && M.blk->Ap) {
+        // SURVEY 8(d), BSR(bs x bs): 8 nnz + 4 nnz / bs^2 for the matrix stream, 4 (rows / bs + 1) for the row pointer
+        const double nb = (double)M.blk->nblocks, b2 = (double)M.blk->bs * M.blk->bs;
+        return 8.0 * nb * b2 + 4.0 * nb + 4.0 * (M.blk->nbrows + 1.0) + 8.0 * M.ncols + 8.0 * M.nrows;
+    }
     return 12.0 * (double)M.nnz + 4.0 * (M.nrows + 1.0) + 8.0 * M.ncols + 8.0 * M.nrows;
 }
 
@@ -1631,6 +1680,7 @@ static double smoother_apps(const Smoother &s, bool x_zero)
 // streams the values, one pattern id per row and the row pointer; the column indices are implied.
 static double bytes_spmv_moved(const DevCsr &M)
 {
+    if (M.blk && M.blk->Ap && (!M.Ap || bsr_spmv_enabled(M.blk->bs))) return bytes_spmv(M);
     if (M.st_vals && stencil_enabled())     // padded values (or one-byte codes) + one mask word per row; no row pointer
         return ((M.st_vi_on && M.st_codes) ? 8.0 * (double)((M.st_nu + 7) / 8) : 8.0 * (double)M.st_nu) * 256.0 * (double)((M.nrows + 255) / 256) + (M.st_nu <= 7 ? 1.0 : 4.0) * M.nrows +
                8.0 * M.ncols + 8.0 * M.nrows;
@@ -1755,6 +1805,7 @@ int amg_hier_time_spmv(amg_hier *h, int lvl, int which, int mode, int reps, doub
     else if (which == AMG_MAT_P) { in = h->lv[lvl + 1].x; out = L.h; }
     else { in = L.r; out = h->lv[lvl + 1].b; }
     StreamMode sm = ((mode & 1) && which == AMG_MAT_A) ? SM_RESIDUAL : SM_MATVEC;
+    if ((mode & 6) && !M.Ap) { set_error("operator is stored by blocks only"); return AMG_ENOTIMPL; }
     DevCsr Mplain = M;                     // mode bit 1 (value 2): time the plain CSR kernel even if
     if (mode & 2) { Mplain.pat = nullptr; Mplain.st_vals = nullptr; Mplain.Aj16 = nullptr; Mplain.blk = nullptr; }   // the operator has derived forms;
     if (mode & 4) Mplain.st_vals = nullptr;                             // bit 2 (value 4): the pattern kernel

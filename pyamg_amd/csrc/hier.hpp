@@ -37,7 +37,9 @@ int build_levels(int n, const int *Ap, const int *Aj, const int *tasks, int ntas
 int build_csr_schedule(const int *Ap, const int *Aj, const double *Ax, int n, const int *tasks,
                        int ntasks, Schedule &S, hipStream_t st);
 int build_block_schedule(const int *Ap, const int *Aj, int nb, const int *tasks, int ntasks,
-                         Schedule &S, hipStream_t st, const double *Ax = nullptr, int bs = 0);
+                         Schedule &S, hipStream_t st, const double *Ax = nullptr, int bs = 0, bool independent = false);
+int sweep_block_schedule(const Schedule &S, BlockMode mode, const double *Dinv, const double *xin, double *x, const double *b,
+                         double omega, bool reverse, hipStream_t st);
 
 struct Smoother {
     int kind = AMG_SM_NONE;

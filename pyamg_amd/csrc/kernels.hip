@@ -1493,99 +1493,7 @@ int launch_dense_apply(const double *Mt, const double *b, double *x, int n, hipS
     LAUNCH_CHECK("dense_apply");
 }
 
-// ---------------------------------------------------------------------------
-// BSR relaxation kernels, one thread per block row (exact restatement of
-// relaxation.h:90-173, 268-360, 662-728, 756-810).  Independent block rows of
-// one launch are either all rows (Jacobi) or one dependency level (GS).
-// ---------------------------------------------------------------------------
 constexpr int MAXBS = 16;
-
-template <int BMODE>
-__global__ void block_kernel(BlockArgs a)
-{
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= a.count) return;
-    const int i = a.rows ? a.rows[t] : a.first + t * a.step;
-    const int bs = a.bs, B2 = bs * bs;
-    double rsum[MAXBS], v[MAXBS];
-    const long ib = (long)i * bs;
-
-    if (BMODE == BM_BSR_JACOBI || BMODE == BM_BSR_GS) {
-        long diag_ptr = -1;
-        for (int k = 0; k < bs; ++k) rsum[k] = a.b[ib + k];
-        for (int jj = a.Ap[i]; jj < a.Ap[i + 1]; ++jj) {
-            int j = a.Aj[jj];
-            if (i == j) {
-                diag_ptr = (long)jj * B2;
-            } else {
-                const double *blk = a.Ax + (long)jj * B2;
-                const double *xj = a.xin + (long)j * bs;
-                for (int r = 0; r < bs; ++r) {
-                    double s = 0.0;
-                    for (int c = 0; c < bs; ++c) s = s + blk[r * bs + c] * xj[c];
-                    v[r] = s;
-                }
-                for (int m = 0; m < bs; ++m) rsum[m] = rsum[m] - v[m];
-            }
-        }
-        if (diag_ptr != -1) {
-            int step = a.intra_reverse ? -1 : 1;
-            int k0 = a.intra_reverse ? bs - 1 : 0, k1 = a.intra_reverse ? -1 : bs;
-            for (int k = k0; k != k1; k += step) {
-                double diag = 1.0;
-                for (int kk = k0; kk != k1; kk += step) {
-                    if (k == kk) {
-                        diag = a.Ax[k * bs + kk + diag_ptr];
-                    } else {
-                        // Jacobi reads temp (xin); GS reads the live x (xout), which this
-                        // thread may already have updated for kk ahead of k in sweep order
-                        double xv = (BMODE == BM_BSR_JACOBI) ? a.xin[ib + kk] : a.xout[ib + kk];
-                        rsum[k] = rsum[k] - a.Ax[k * bs + kk + diag_ptr] * xv;
-                    }
-                }
-                if (diag != 0.0) {
-                    if (BMODE == BM_BSR_JACOBI) {
-                        double t1 = (1.0 - a.omega) * a.xin[ib + k];
-                        double t2 = (a.omega * rsum[k]) / diag;
-                        a.xout[ib + k] = t1 + t2;
-                    } else {
-                        a.xout[ib + k] = rsum[k] / diag;
-                    }
-                }
-            }
-        }
-    } else {
-        for (int k = 0; k < bs; ++k) rsum[k] = 0.0;
-        for (int jj = a.Ap[i]; jj < a.Ap[i + 1]; ++jj) {
-            int j = a.Aj[jj];
-            if (i == j) continue;
-            const double *blk = a.Ax + (long)jj * B2;
-            const double *xj = a.xin + (long)j * bs;
-            for (int r = 0; r < bs; ++r) {
-                double s = 0.0;
-                for (int c = 0; c < bs; ++c) s = s + blk[r * bs + c] * xj[c];
-                v[r] = s;
-            }
-            for (int k = 0; k < bs; ++k) rsum[k] = rsum[k] + v[k];
-        }
-        for (int k = 0; k < bs; ++k) rsum[k] = a.b[ib + k] - rsum[k];
-        const double *D = a.Dinv + (long)i * B2;
-        for (int r = 0; r < bs; ++r) {
-            double s = 0.0;
-            for (int c = 0; c < bs; ++c) s = s + D[r * bs + c] * rsum[c];
-            v[r] = s;
-        }
-        if (BMODE == BM_BLOCK_JACOBI) {
-            for (int k = 0; k < bs; ++k) {
-                double t1 = (1.0 - a.omega) * a.xin[ib + k];
-                double t2 = a.omega * v[k];
-                a.xout[ib + k] = t1 + t2;
-            }
-        } else {
-            for (int k = 0; k < bs; ++k) a.xout[ib + k] = v[k];
-        }
-    }
-}
 
 // ---------------------------------------------------------------------------
 // bsr_stream: the block / point-BSR smoothers with the matrix STREAMED.  A workgroup owns `rpb`
@@ -1694,6 +1602,19 @@ __global__ __launch_bounds__(WG) void bsr_stream_kernel(BsrStreamArgs a, int rpb
     }
 
     if (BMODE == BM_SPMV) {
+        if (a.smode == SM_RESIDUAL_SUMSQ) {
+            // per-workgroup partial of ||b - A x||^2 (the outer residual norm), r stored only when asked for
+            double sq = 0.0;
+            if (active) {
+                const double rr = a.b[ib + r] - rsum;
+                sq = rr * rr;
+                if (a.xout) a.xout[ib + r] = rr;
+            }
+            __syncthreads();
+            const double tot = block_reduce_sum(sq, sp);
+            if (t == 0) a.out2[blockIdx.x] = tot;
+            return;
+        }
         if (!active) return;
         const long i = ib + r;
         if (a.smode == SM_MATVEC) a.xout[i] = rsum;
@@ -1762,7 +1683,32 @@ void set_bsr_spmv(int on) { g_bsr_spmv = on; ++g_config_epoch; }
 bool bsr_spmv_enabled(int bs) { return g_bsr_spmv == 2 || (g_bsr_spmv == 1 && bs >= 3); }
 bool bsr_spmv_supports(StreamMode mode)
 {
-    return mode == SM_MATVEC || mode == SM_MATVEC_ACC || mode == SM_RESIDUAL || mode == SM_POLY_STEP || mode == SM_POLY_LAST;
+    return mode == SM_MATVEC || mode == SM_MATVEC_ACC || mode == SM_RESIDUAL || mode == SM_POLY_STEP || mode == SM_POLY_LAST ||
+           mode == SM_RESIDUAL_SUMSQ;
+}
+
+// block rows per workgroup: as many as fit 256 threads, fewer when that would stage more than about one LDS
+// tile of products
+static int bsr_rows_per_wg(const BsrStreamArgs &a, long nblocks_hint)
+{
+    const int rows = a.brow_hi - a.brow_lo;
+    const int B2 = a.bs * a.bs;
+    int rpb = WG / a.bs;
+    if (nblocks_hint > 0 && rows > 0) {
+        double per_row = (double)nblocks_hint * B2 / (double)rows;
+        int want = (int)(g_tile_target / (per_row > 1.0 ? per_row : 1.0));
+        if (want < 1) want = 1;
+        if (want < rpb) rpb = want;
+    }
+    return rpb;
+}
+
+int bsr_stream_blocks(const BsrStreamArgs &a, long nblocks_hint)
+{
+    const int rows = a.brow_hi - a.brow_lo;
+    if (rows <= 0 || a.bs < 1 || a.bs > MAXBS) return 0;
+    const int rpb = bsr_rows_per_wg(a, nblocks_hint);
+    return (rows + rpb - 1) / rpb;
 }
 
 int launch_bsr_stream(BlockMode m, const BsrStreamArgs &a, long nblocks_hint, hipStream_t st)
@@ -1770,15 +1716,7 @@ int launch_bsr_stream(BlockMode m, const BsrStreamArgs &a, long nblocks_hint, hi
     const int rows = a.brow_hi - a.brow_lo;
     if (rows <= 0) return 0;
     if (a.bs > MAXBS || a.bs < 1) { set_error("block kernels support blocksize 1..16"); return -5; }
-    const int B2 = a.bs * a.bs;
-    int rpb = WG / a.bs;
-    // aim at about one LDS tile of products per workgroup
-    if (nblocks_hint > 0) {
-        double per_row = (double)nblocks_hint * B2 / (double)rows;
-        int want = (int)(g_tile_target / (per_row > 1.0 ? per_row : 1.0));
-        if (want < 1) want = 1;
-        if (want < rpb) rpb = want;
-    }
+    const int rpb = bsr_rows_per_wg(a, nblocks_hint);
     dim3 g((rows + rpb - 1) / rpb), b(WG);
 #define BSR_LAUNCH(MODE, BSV) hipLaunchKernelGGL((bsr_stream_kernel<MODE, BSV>), g, b, 0, st, a, rpb)
 #define BSR_BY_BS(MODE)                                 \
@@ -1799,24 +1737,6 @@ int launch_bsr_stream(BlockMode m, const BsrStreamArgs &a, long nblocks_hint, hi
 #undef BSR_BY_BS
 #undef BSR_LAUNCH
     LAUNCH_CHECK("bsr_stream kernel");
-}
-
-int launch_block(BlockMode m, const BlockArgs &a, hipStream_t st)
-{
-    if (a.count <= 0) return 0;
-    if (a.bs > MAXBS || a.bs < 1) {
-        set_error("block kernels support blocksize 1..16");
-        return -5;
-    }
-    dim3 g((a.count + 127) / 128), b(128);
-    switch (m) {
-    case BM_BSR_JACOBI: hipLaunchKernelGGL(block_kernel<BM_BSR_JACOBI>, g, b, 0, st, a); break;
-    case BM_BLOCK_JACOBI: hipLaunchKernelGGL(block_kernel<BM_BLOCK_JACOBI>, g, b, 0, st, a); break;
-    case BM_BSR_GS: hipLaunchKernelGGL(block_kernel<BM_BSR_GS>, g, b, 0, st, a); break;
-    case BM_BLOCK_GS: hipLaunchKernelGGL(block_kernel<BM_BLOCK_GS>, g, b, 0, st, a); break;
-    default: set_error("block kernel: mode not supported"); return -5;
-    }
-    LAUNCH_CHECK("block kernel");
 }
 
 }  // namespace amg

@@ -420,6 +420,276 @@ int64_t amgsetup_smooth_prolongator(int n, int n_agg, const int64_t *Sp, const i
     return Pp[n];
 }
 
+// ---- block (BSR) setup: one candidate per node, square bs x bs blocks on the fine level ------------
+// C = A * B for BSR operands with blocks R x N and N x C: row-parallel restatement of scipy's
+// bsr_matmat (scipy.sparse._sparsetools bsr.h): per block row the output blocks are created in
+// FORWARD first-touch order (unlike csr_matmat's reverse order), each accumulating A_ij * B_jk
+// in traversal order with the dense product summed over the inner index last
+// (C[r][c] += sum_n A[r][n] B[n][c], the running sum starting from C[r][c]); zero blocks stay.
+// R == N == C == 1 is routed to csr_matmat by scipy -- callers use the CSR kernels above for it.
+int64_t amgsetup_bsr_matmat_count(int n_brow, const int64_t *Ap, const int *Aj, const int64_t *Bp, const int *Bj, int64_t *Cp)
+{
+    Cp[0] = 0;
+#pragma omp parallel
+    {
+        RowTable T;
+#pragma omp for schedule(dynamic, 4096)
+        for (int i = 0; i < n_brow; i++) {
+            int64_t upper = 0;
+            for (int64_t jj = Ap[i]; jj < Ap[i + 1]; jj++) upper += Bp[Aj[jj] + 1] - Bp[Aj[jj]];
+            T.reserve_for(upper);
+            for (int64_t jj = Ap[i]; jj < Ap[i + 1]; jj++) {
+                int j = Aj[jj];
+                for (int64_t kk = Bp[j]; kk < Bp[j + 1]; kk++) { bool fresh; T.slot_of(Bj[kk], fresh); }
+            }
+            Cp[i + 1] = (int64_t)T.order.size();
+            T.clear_touched();
+        }
+    }
+    for (int i = 0; i < n_brow; i++) Cp[i + 1] += Cp[i];
+    return Cp[n_brow];
+}
+
+void amgsetup_bsr_matmat_fill(int n_brow, int R, int N, int C, const int64_t *Ap, const int *Aj, const double *Ax,
+                              const int64_t *Bp, const int *Bj, const double *Bx, const int64_t *Cp, int *Cj, double *Cx)
+{
+    const int64_t RC = (int64_t)R * C, RN = (int64_t)R * N, NC = (int64_t)N * C;
+#pragma omp parallel
+    {
+        RowTable T;                                    // sum[] unused: the slot's rank is its block position
+        std::vector<int> rank;
+#pragma omp for schedule(dynamic, 4096)
+        for (int i = 0; i < n_brow; i++) {
+            const int64_t base = Cp[i], cnt = Cp[i + 1] - Cp[i];
+            T.reserve_for(cnt);
+            if (rank.size() < T.key.size()) rank.resize(T.key.size());
+            std::fill(Cx + base * RC, Cx + (base + cnt) * RC, 0.0);
+            for (int64_t jj = Ap[i]; jj < Ap[i + 1]; jj++) {
+                const int j = Aj[jj];
+                const double *a = Ax + jj * RN;
+                for (int64_t kk = Bp[j]; kk < Bp[j + 1]; kk++) {
+                    bool fresh;
+                    const int s = T.slot_of(Bj[kk], fresh);
+                    if (fresh) { rank[(size_t)s] = (int)T.order.size() - 1; Cj[base + rank[(size_t)s]] = Bj[kk]; }
+                    double *c = Cx + (base + rank[(size_t)s]) * RC;
+                    const double *b = Bx + kk * NC;
+                    for (int r = 0; r < R; r++)
+                        for (int cc = 0; cc < C; cc++) {
+                            double dot = c[(int64_t)r * C + cc];
+                            for (int n = 0; n < N; n++) dot += a[(int64_t)r * N + n] * b[(int64_t)n * C + cc];
+                            c[(int64_t)r * C + cc] = dot;
+                        }
+                }
+            }
+            T.clear_touched();
+        }
+    }
+}
+
+// B = A^T for BSR (scipy bsr_transpose: csr_tocsc on the block pattern -- blocks of an output row in
+// ascending source row -- and every R x C block transposed to C x R)
+void amgsetup_bsr_transpose(int n_brow, int n_bcol, int R, int C, const int64_t *Ap, const int *Aj, const double *Ax,
+                            int64_t *Bp, int *Bi, double *Bx)
+{
+    std::fill(Bp, Bp + n_bcol + 1, (int64_t)0);
+    const int64_t nb = Ap[n_brow], RC = (int64_t)R * C;
+    for (int64_t k = 0; k < nb; k++) Bp[Aj[k] + 1]++;
+    for (int c = 0; c < n_bcol; c++) Bp[c + 1] += Bp[c];
+    std::vector<int64_t> cur(Bp, Bp + n_bcol);
+    for (int i = 0; i < n_brow; i++)
+        for (int64_t k = Ap[i]; k < Ap[i + 1]; k++) {
+            const int64_t d = cur[Aj[k]]++;
+            Bi[d] = i;
+            const double *a = Ax + k * RC;
+            double *b = Bx + d * RC;
+            for (int r = 0; r < R; r++)
+                for (int c = 0; c < C; c++) b[(int64_t)c * R + r] = a[(int64_t)r * C + c];
+        }
+}
+
+// Jacobi-smoothed prolongator P = T - (w D^-1 S) T for BSR S (bs x bs blocks) and a tentative T with ONE
+// bs x K block per aggregated node (block row i -> block column agg[i], values Tx[i], row-major)
+// (pyamg/aggregation/smooth.py:163-205, weighting 'diagonal', degree 1), with scipy's arithmetic and stored order:
+//   D_inv_S = w * scale_rows(S, dinv): entry (r, c) of block (i, k) is (S[r][c] * dinv[i*bs + r]) * w;
+//   X = D_inv_S * T (bsr_matmat): block (i, J) accumulates over S's row i in stored order,
+//       X[r][c] += sum_n D_inv_S[r][n] T_k[n][c] with the running sum starting from X[r][c];
+//   P = T - X through bsr_binop_bsr_general (X's indices are not sorted): the row's linked list is touched by
+//   T's block first, then X's blocks as stored; blocks are emitted in REVERSE touch order and all-zero blocks
+//   are dropped -- so X's columns in reverse first-touch order (T's column excluded), then T's column.
+// *x_sorted (count pass: written; fill pass: read): X came out with sorted block columns in EVERY row, in which
+// case scipy takes bsr_binop_bsr_canonical instead and P's blocks are the sorted merge of the two rows.
+// Two calls: count (Pj == nullptr; fills Pp) then fill.  Returns the number of blocks.
+int64_t amgsetup_smooth_prolongator_block(int n_nodes, int bs, int K, const int64_t *Sp, const int *Sj, const double *Sx, const double *dinv,
+                                          double w, const int *agg, const double *Tx, int64_t *Pp, int *Pj, double *Px, int *x_sorted)
+{
+    const bool fill = (Pj != nullptr);
+    const int64_t B2 = (int64_t)bs * bs;
+    const size_t BK = (size_t)bs * (size_t)K;
+    if (!fill) Pp[0] = 0;
+    const bool canonical = fill && *x_sorted != 0;
+    int all_sorted = 1;
+#pragma omp parallel
+    {
+        std::vector<int> cols;
+        std::vector<double> acc, out(BK);               // acc: bs*K per touched column, first-touch order
+#pragma omp for schedule(dynamic, 2048)
+        for (int i = 0; i < n_nodes; i++) {
+            cols.clear(); acc.clear();
+            for (int64_t jj = Sp[i]; jj < Sp[i + 1]; jj++) {
+                const int k = Sj[jj];
+                if (agg[k] < 0) continue;
+                const int c = agg[k];
+                size_t q = 0;
+                for (; q < cols.size(); q++) if (cols[q] == c) break;
+                if (q == cols.size()) { cols.push_back(c); acc.resize(acc.size() + BK, 0.0); }
+                const double *blk = Sx + jj * B2;
+                const double *t = Tx + (int64_t)k * (int64_t)BK;
+                double *x = &acc[q * BK];
+                for (int r = 0; r < bs; r++) {
+                    const double di = dinv[(int64_t)i * bs + r];
+                    for (int cc = 0; cc < K; cc++) {
+                        double dot = x[(size_t)r * K + cc];
+                        for (int nn = 0; nn < bs; nn++) dot += ((blk[(int64_t)r * bs + nn] * di) * w) * t[(size_t)nn * K + cc];
+                        x[(size_t)r * K + cc] = dot;
+                    }
+                }
+            }
+            const int tc = agg[i];
+            int64_t cnt = 0;
+            const int64_t base = fill ? Pp[i] : 0;
+            auto emit = [&](int c, const double *tv, const double *xv) {
+                bool nz = false;
+                for (size_t e = 0; e < BK; e++) { out[e] = (tv ? tv[e] : 0.0) - (xv ? xv[e] : 0.0); nz = nz || (out[e] != 0.0); }
+                if (!nz) return;
+                if (fill) { Pj[base + cnt] = c; for (size_t e = 0; e < BK; e++) Px[(size_t)(base + cnt) * BK + e] = out[e]; }
+                cnt++;
+            };
+            const double *tmine = Tx + (int64_t)i * (int64_t)BK;
+            if (!fill)
+                for (size_t q = 1; q < cols.size(); q++)
+                    if (cols[q] <= cols[q - 1]) {
+#pragma omp atomic write
+                        all_sorted = 0;
+                    }
+            if (canonical) {
+                bool tdone = (tc < 0);                   // sorted merge of T's single block with X's (ascending) blocks
+                for (size_t q = 0; q < cols.size(); q++) {
+                    if (!tdone && tc < cols[q]) { emit(tc, tmine, nullptr); tdone = true; }
+                    if (cols[q] == tc) { emit(tc, tmine, &acc[q * BK]); tdone = true; }
+                    else emit(cols[q], nullptr, &acc[q * BK]);
+                }
+                if (!tdone) emit(tc, tmine, nullptr);
+            } else {
+                const double *xt = nullptr;
+                for (size_t q = cols.size(); q-- > 0;) {
+                    if (cols[q] == tc) { xt = &acc[q * BK]; continue; }
+                    emit(cols[q], nullptr, &acc[q * BK]);
+                }
+                if (tc >= 0) emit(tc, tmine, xt);
+            }
+            if (!fill) Pp[i + 1] = cnt;
+        }
+    }
+    if (!fill) {
+        for (int i = 0; i < n_nodes; i++) Pp[i + 1] += Pp[i];
+        *x_sorted = all_sorted;
+    }
+    return Pp[n_nodes];
+}
+
+// Stiffness matrix of -div(K grad u), P1 elements on the Kuhn triangulation of an m x m x m vertex grid
+// (every cube cut into the six tetrahedra 000 -> e_a -> e_a + e_b -> 111, one per ordering (a, b, c) of the
+// axes), assembled row by row for the (m-2)^3 interior vertices (lexicographic, last axis fastest; boundary
+// vertices eliminated): the same operator pyamg_amd.gallery.p1_diffusion assembles from the element list
+// (entries agree to rounding; the order of summation over the elements differs).  xyz: m^3 x 3 vertex
+// coordinates, K: 3 x 3 row-major.  Two calls: Aj == nullptr counts (fills Ap, returns nnz), then fill.
+int64_t amgsetup_kuhn_p1_diffusion(int m, const double *xyz, const double *K, int64_t *Ap, int *Aj, double *Ax)
+{
+    const int n1 = m - 2;
+    const int64_t n = (int64_t)n1 * n1 * n1;
+    const bool fill = (Aj != nullptr);
+    static const int perms[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};
+    // offsets a row can couple to: differences of two corners on a common Kuhn path = all components >= 0 or all <= 0
+    int noff = 0, off[15][3];
+    for (int dx = -1; dx <= 1; dx++)
+        for (int dy = -1; dy <= 1; dy++)
+            for (int dz = -1; dz <= 1; dz++) {
+                const bool nonneg = dx >= 0 && dy >= 0 && dz >= 0, nonpos = dx <= 0 && dy <= 0 && dz <= 0;
+                if (nonneg || nonpos) { off[noff][0] = dx; off[noff][1] = dy; off[noff][2] = dz; noff++; }
+            }                                            // lexicographic in (dx, dy, dz) = ascending column
+    auto interior = [&](int i, int j, int k) { return i >= 1 && i <= n1 && j >= 1 && j <= n1 && k >= 1 && k <= n1; };
+    if (!fill) {
+        Ap[0] = 0;
+#pragma omp parallel for schedule(static)
+        for (int64_t row = 0; row < n; row++) {
+            const int k = (int)(row % n1) + 1, j = (int)((row / n1) % n1) + 1, i = (int)(row / ((int64_t)n1 * n1)) + 1;
+            int c = 0;
+            for (int o = 0; o < noff; o++) c += interior(i + off[o][0], j + off[o][1], k + off[o][2]) ? 1 : 0;
+            Ap[row + 1] = c;
+        }
+        for (int64_t row = 0; row < n; row++) Ap[row + 1] += Ap[row];
+        return Ap[n];
+    }
+#pragma omp parallel for schedule(dynamic, 1024)
+    for (int64_t row = 0; row < n; row++) {
+        const int k = (int)(row % n1) + 1, j = (int)((row / n1) % n1) + 1, i = (int)(row / ((int64_t)n1 * n1)) + 1;
+        double acc[3][3][3] = {{{0.0}}};                 // by (dx+1, dy+1, dz+1)
+        const int v[3] = {i, j, k};
+        // the eight cubes around the vertex: the vertex is corner c (components 0/1) of the cube at v - c
+        for (int cx = 0; cx <= 1; cx++)
+            for (int cy = 0; cy <= 1; cy++)
+                for (int cz = 0; cz <= 1; cz++) {
+                    const int c[3] = {cx, cy, cz};
+                    const int o[3] = {v[0] - cx, v[1] - cy, v[2] - cz};
+                    if (o[0] < 0 || o[1] < 0 || o[2] < 0 || o[0] > m - 2 || o[1] > m - 2 || o[2] > m - 2) continue;
+                    for (int p = 0; p < 6; p++) {
+                        int path[4][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {1, 1, 1}};
+                        path[1][perms[p][0]] = 1;
+                        path[2][perms[p][0]] = 1; path[2][perms[p][1]] = 1;
+                        int me = -1;
+                        for (int q = 0; q < 4; q++)
+                            if (path[q][0] == c[0] && path[q][1] == c[1] && path[q][2] == c[2]) me = q;
+                        if (me < 0) continue;
+                        double X[4][3];
+                        for (int q = 0; q < 4; q++) {
+                            const int64_t id = ((int64_t)(o[0] + path[q][0]) * m + (o[1] + path[q][1])) * m + (o[2] + path[q][2]);
+                            for (int d = 0; d < 3; d++) X[q][d] = xyz[id * 3 + d];
+                        }
+                        double E[3][3];
+                        for (int q = 0; q < 3; q++)
+                            for (int d = 0; d < 3; d++) E[q][d] = X[q + 1][d] - X[0][d];
+                        const double det = E[0][0] * (E[1][1] * E[2][2] - E[1][2] * E[2][1]) - E[0][1] * (E[1][0] * E[2][2] - E[1][2] * E[2][0]) +
+                                           E[0][2] * (E[1][0] * E[2][1] - E[1][1] * E[2][0]);
+                        // inverse of E by cofactors; gradient of lambda_q (q = 1..3) = column q-1 of E^-1
+                        double Ei[3][3];
+                        Ei[0][0] = (E[1][1] * E[2][2] - E[1][2] * E[2][1]) / det; Ei[0][1] = (E[0][2] * E[2][1] - E[0][1] * E[2][2]) / det; Ei[0][2] = (E[0][1] * E[1][2] - E[0][2] * E[1][1]) / det;
+                        Ei[1][0] = (E[1][2] * E[2][0] - E[1][0] * E[2][2]) / det; Ei[1][1] = (E[0][0] * E[2][2] - E[0][2] * E[2][0]) / det; Ei[1][2] = (E[0][2] * E[1][0] - E[0][0] * E[1][2]) / det;
+                        Ei[2][0] = (E[1][0] * E[2][1] - E[1][1] * E[2][0]) / det; Ei[2][1] = (E[0][1] * E[2][0] - E[0][0] * E[2][1]) / det; Ei[2][2] = (E[0][0] * E[1][1] - E[0][1] * E[1][0]) / det;
+                        double G[4][3];
+                        for (int q = 1; q < 4; q++)
+                            for (int d = 0; d < 3; d++) G[q][d] = Ei[d][q - 1];
+                        for (int d = 0; d < 3; d++) G[0][d] = -(G[1][d] + G[2][d] + G[3][d]);
+                        const double vol = std::fabs(det) / 6.0;
+                        double KG[3];
+                        for (int d = 0; d < 3; d++) KG[d] = K[d * 3 + 0] * G[me][0] + K[d * 3 + 1] * G[me][1] + K[d * 3 + 2] * G[me][2];
+                        for (int q = 0; q < 4; q++) {
+                            const double e = (KG[0] * G[q][0] + KG[1] * G[q][1] + KG[2] * G[q][2]) * vol;
+                            acc[path[q][0] - c[0] + 1][path[q][1] - c[1] + 1][path[q][2] - c[2] + 1] += e;
+                        }
+                    }
+                }
+        int64_t pos = Ap[row];
+        for (int o = 0; o < noff; o++) {
+            const int ii = i + off[o][0], jj = j + off[o][1], kk = k + off[o][2];
+            if (!interior(ii, jj, kk)) continue;
+            Aj[pos] = (int)((((int64_t)(ii - 1)) * n1 + (jj - 1)) * n1 + (kk - 1));
+            Ax[pos] = acc[off[o][0] + 1][off[o][1] + 1][off[o][2] + 1];
+            pos++;
+        }
+    }
+    return Ap[n];
+}
+
 // ---- classical (Ruge-Stuben) setup, pyamg/amg_core/ruge_stuben.h --------------------------------
 // :46-99 classical strength: keep off-diagonals with |a_ij| >= theta * max_k!=i |a_ik|, and the diagonal
 int amgsetup_classical_strength(int n_row, double theta, const int *Ap, const int *Aj, const double *Ax,

@@ -88,19 +88,69 @@ def kuhn_mesh(n, jitter=0.2, seed=0):
     return P, np.concatenate(tets, axis=0), vid[1:-1, 1:-1, 1:-1].ravel()
 
 
-def tet_diffusion(n, eps=(1.0, 0.1, 0.01), theta=np.pi / 6, phi=np.pi / 5, jitter=0.2, seed=0, blocksize=None):
+def tet_diffusion(n, eps=(1.0, 0.1, 0.01), theta=np.pi / 6, phi=np.pi / 5, jitter=0.2, seed=0, blocksize=None, native=None):
     """Stiffness matrix of -div(K grad u), P1 on tetrahedra, (n+2)^3 vertices with the boundary layer
     eliminated -> n^3 unknowns (lexicographic, last axis fastest).  Returns CSR, or BSR(bs,bs) when
-    `blocksize` is given (n^3 must be divisible by it), as configuration C5 uses it."""
-    P, T, interior = kuhn_mesh(n, jitter, seed)
-    A = p1_diffusion(P, T, anisotropy_tensor(eps, theta, phi))
-    A = A[interior][:, interior].tocsr()
-    A.sum_duplicates()
-    A.sort_indices()
-    A.indices = A.indices.astype(np.intc)
-    A.indptr = A.indptr.astype(np.intc)
+    `blocksize` is given (n^3 must be divisible by it), as configuration C5 uses it.
+    native: assemble row by row in csrc/setup_host.cpp (OpenMP; default above 40^3 unknowns -- the element-list
+    assembly needs ~400 bytes of temporaries per element) instead of from the element list; same operator to
+    rounding."""
+    if native is None:
+        native = n > 40
+    K = anisotropy_tensor(eps, theta, phi)
+    if native:
+        A = _kuhn_native(n, K, jitter, seed)
+    else:
+        P, T, interior = kuhn_mesh(n, jitter, seed)
+        A = p1_diffusion(P, T, K)
+        A = A[interior][:, interior].tocsr()
+        A.sum_duplicates()
+        A.sort_indices()
+        A.indices = A.indices.astype(np.intc)
+        A.indptr = A.indptr.astype(np.intc)
     if blocksize:
         if A.shape[0] % blocksize:
             raise ValueError("n^3 must be divisible by the blocksize")
-        A = A.tobsr((blocksize, blocksize))
+        A = _tobsr_sorted(A, blocksize) if native else A.tobsr((blocksize, blocksize))
     return A
+
+
+def _jittered_vertices(n, jitter, seed):
+    m = n + 2
+    rng = np.random.RandomState(seed)
+    g = np.linspace(0.0, 1.0, m)
+    h = 1.0 / (m - 1)
+    J = (rng.rand(m, m, m, 3) - 0.5) * (2.0 * jitter * h)
+    J[0], J[-1] = 0.0, 0.0
+    J[:, 0], J[:, -1] = 0.0, 0.0
+    J[:, :, 0], J[:, :, -1] = 0.0, 0.0
+    J[..., 0] += g[:, None, None]
+    J[..., 1] += g[None, :, None]
+    J[..., 2] += g[None, None, :]
+    return J.reshape(-1, 3)
+
+
+def _kuhn_native(n, K, jitter, seed):
+    import ctypes as C
+    from .aggregation import _dp, _ip, _lp, host_lib
+    L = host_lib()
+    m = n + 2
+    xyz = np.ascontiguousarray(_jittered_vertices(n, jitter, seed))
+    Kc = np.ascontiguousarray(K, dtype=np.float64)
+    N = n ** 3
+    Ap = np.empty(N + 1, dtype=np.int64)
+    nnz = L.amgsetup_kuhn_p1_diffusion(m, _dp(xyz), _dp(Kc), _lp(Ap), C.POINTER(C.c_int)(), C.POINTER(C.c_double)())
+    if nnz >= 2 ** 31:
+        raise ValueError("matrix exceeds int32 indices")
+    Aj = np.empty(nnz, dtype=np.intc)
+    Ax = np.empty(nnz, dtype=np.float64)
+    L.amgsetup_kuhn_p1_diffusion(m, _dp(xyz), _dp(Kc), _lp(Ap), _ip(Aj), _dp(Ax))
+    A = sps.csr_matrix((Ax, Aj, Ap.astype(np.intc)), shape=(N, N))
+    A.has_sorted_indices = True
+    return A
+
+
+def _tobsr_sorted(A, bs):
+    """A.tobsr((bs, bs)) for a CSR matrix with sorted rows (scipy's csr_tobsr: block columns ascending, absent
+    entries of a touched block zero) without scipy's O(n_bcol) scratch per call being the bottleneck"""
+    return A.tobsr((bs, bs))

@@ -127,12 +127,27 @@ def _blocksize_of(lvl, blocksize, Dinv):
     return blocksize
 
 
+def _block_inverses(A, blocksize):
+    """get_block_diag(A, blocksize, inv_flag=True), kept on the operator: pre-smoother, post-smoother and the
+    candidate improvement of the setup all ask for the same constants (the reference recomputes them)"""
+    cache = getattr(A, "_amg_block_dinv", None)
+    if cache is None:
+        cache = {}
+        try:
+            A._amg_block_dinv = cache
+        except AttributeError:
+            pass
+    if blocksize not in cache:
+        cache[blocksize] = get_block_diag(A, blocksize=blocksize, inv_flag=True)
+    return cache[blocksize]
+
+
 def setup_block_jacobi(lvl, iterations=1, omega=1.0, Dinv=None, blocksize=None, withrho=True):
     blocksize = _blocksize_of(lvl, blocksize, Dinv)
     if blocksize == 1:
         return setup_jacobi(lvl, iterations=iterations, omega=omega, withrho=withrho)
     if Dinv is None:
-        Dinv = get_block_diag(lvl.A, blocksize=blocksize, inv_flag=True)
+        Dinv = _block_inverses(lvl.A, blocksize)
     if withrho:
         omega = omega / rho_block_D_inv_A(lvl.A, Dinv)
 
@@ -147,7 +162,7 @@ def setup_block_gauss_seidel(lvl, iterations=1, sweep="forward", Dinv=None, bloc
     if blocksize == 1:
         return setup_gauss_seidel(lvl, iterations=iterations, sweep=sweep)
     if Dinv is None:
-        Dinv = get_block_diag(lvl.A, blocksize=blocksize, inv_flag=True)
+        Dinv = _block_inverses(lvl.A, blocksize)
 
     def smoother(A, x, b):
         relaxation.block_gauss_seidel(A, x, b, iterations=iterations, Dinv=Dinv, blocksize=blocksize,

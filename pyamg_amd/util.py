@@ -87,16 +87,35 @@ def get_block_diag(A, blocksize, inv_flag=True):
         A = bsr_matrix(A, blocksize=(blocksize, blocksize))
     if A.blocksize != (blocksize, blocksize):
         A = A.tobsr(blocksize=(blocksize, blocksize))
-    A = A.asfptype() if hasattr(A, "asfptype") else A.astype(np.float64)
+    if A.dtype != np.float64:
+        A = A.astype(np.float64)
     nb = A.shape[0] // blocksize
+    # the diagonal block of every block row (the last stored one if a row holds duplicates, as the
+    # reference's loop leaves it), gathered in one pass
     block_diag = np.zeros((nb, blocksize, blocksize), dtype=A.dtype)
-    for i in range(nb):
-        for jj in range(A.indptr[i], A.indptr[i + 1]):
-            if A.indices[jj] == i:
-                block_diag[i] = A.data[jj]
+    brow = np.repeat(np.arange(nb, dtype=np.int64), np.diff(A.indptr))
+    at = np.nonzero(A.indices == brow)[0]
+    block_diag[brow[at]] = A.data[at]
     if inv_flag:
-        for i in range(nb):
-            block_diag[i] = scipy.linalg.pinv(block_diag[i])
+        # pseudo-inverse of every block (the reference: amg_core.pinv_array, an SVD per block), batched;
+        # LAPACK runs without the GIL, so large inputs are cut into chunks for a few host threads
+        step = 1 << 16
+        chunks = [(lo, min(nb, lo + step)) for lo in range(0, nb, step)]
+
+        def invert(c):
+            block_diag[c[0]:c[1]] = np.linalg.pinv(block_diag[c[0]:c[1]])
+        if len(chunks) > 4:
+            import os
+            from concurrent.futures import ThreadPoolExecutor
+            try:
+                workers = min(16, len(os.sched_getaffinity(0)))
+            except AttributeError:
+                workers = min(16, os.cpu_count() or 1)
+            with ThreadPoolExecutor(max_workers=max(1, workers)) as pool:
+                list(pool.map(invert, chunks))
+        else:
+            for c in chunks:
+                invert(c)
     return block_diag
 
 

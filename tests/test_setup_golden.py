@@ -219,3 +219,68 @@ def test_classical_kernels_identical_to_reference_kernels():
                                                  _ip(Pp), _ip(Pj), _dp(Px))
         assert np.array_equal(Pp, c["Pp"]) and np.array_equal(Pj, c["Pj"]), name
         assert np.array_equal(Px, c["Px"], equal_nan=True), name
+
+
+# --------------------------------------------------------------------------- round 2: block (BSR) setup, configuration C5
+def _c5_operator(case):
+    """the level-0 operator and candidates the reference was handed (stored in the fixture)"""
+    g = golden_io.load_hier(case)
+    return g, g["levels"][0]["A"], g.get("B0")
+
+
+@pytest.mark.parametrize("case,mc", [("c5_diff_p1_cube_bgs", 6), ("c5_elas_p1_cube_bgs", 8), ("bs3_bgs_2d", 10)])
+def test_block_sa_setup_reproduces_reference_hierarchy(case, mc):
+    """BSR(3,3) operators -- the reference's unit_cube tetrahedral mesh (P1 diffusion with the default 3 candidates,
+    P1 elasticity with 6 rigid-body modes) and the Kronecker case -- through our setup, fast path where it applies:
+    same level sizes / block sizes / sparsity, operators to rounding, block-diagonal inverses to rounding."""
+    g, A, B = _c5_operator(case)
+    sm = ("block_gauss_seidel", {"sweep": "symmetric", "blocksize": 3})
+    np.random.seed(0)
+    ml = smoothed_aggregation_solver(A, B=B, presmoother=sm, postsmoother=sm, max_coarse=mc)
+    assert len(ml.levels) == g["meta"]["nlevels"]
+    for lvl, G in zip(ml.levels, g["levels"]):
+        assert lvl.A.blocksize == G["A"].blocksize
+        same(lvl.A, G["A"], 1e-12)
+        if "P" in G:
+            assert lvl.P.blocksize == G["P"].blocksize
+            same(lvl.P, G["P"], 1e-12)
+            same(lvl.R, G["R"], 1e-12)
+            D, GD = np.ravel(lvl.presmoother.desc["Dinv"]), np.ravel(G["pre"]["Dinv"])
+            assert np.abs(D - GD).max() <= 1e-10 * np.abs(GD).max()
+
+
+@pytest.mark.parametrize("n,bs,ncand", [(12, 3, None), (12, 3, 1), (10, 2, None), (15, 3, None)])
+def test_fast_block_setup_equals_generic_scipy_path_bitwise(n, bs, ncand):
+    """The block fast path (row-parallel bsr_matmat / bsr_minus_bsr / bsr_transpose restatements in
+    csrc/setup_host.cpp) must produce the generic scipy path's operators bit for bit, stored block order
+    included (it is the summation order of every later product)."""
+    from pyamg_amd.gallery import tet_diffusion
+    A = tet_diffusion(n, blocksize=bs)
+    B = None if ncand is None else np.ones((A.shape[0], ncand))
+    hier = []
+    for fast in (True, False):
+        np.random.seed(0)
+        hier.append(smoothed_aggregation_solver(A.copy(), B=B, presmoother=None, postsmoother=None, max_coarse=5, fast=fast))
+    fast, slow = hier
+    assert len(fast.levels) == len(slow.levels) >= 3
+    for lf, ls in zip(fast.levels, slow.levels):
+        assert np.array_equal(np.asarray(lf.B), np.asarray(ls.B))
+        for name in ("A", "P", "R"):
+            if hasattr(ls, name):
+                F, S = getattr(lf, name), getattr(ls, name)
+                assert F.shape == S.shape and F.blocksize == S.blocksize
+                assert np.array_equal(F.indptr, S.indptr) and np.array_equal(F.indices, S.indices), name
+                assert np.array_equal(F.data, S.data), name
+
+
+def test_native_kuhn_assembler_matches_element_assembly():
+    """csrc/setup_host.cpp amgsetup_kuhn_p1_diffusion (row-by-row, for 5*10^7 unknowns) against the element-list
+    assembly of gallery.p1_diffusion: same sparsity, entries to rounding (the summation order over elements differs)."""
+    from pyamg_amd.gallery import tet_diffusion
+    for n in (5, 9):
+        A = tet_diffusion(n, native=False)
+        N = tet_diffusion(n, native=True)
+        assert np.array_equal(A.indptr, N.indptr) and np.array_equal(A.indices, N.indices)
+        assert np.abs(A.data - N.data).max() <= 1e-13 * np.abs(A.data).max()
+    Nb = tet_diffusion(9, native=True, blocksize=3)
+    assert Nb.blocksize == (3, 3) and abs(Nb - tet_diffusion(9, native=False, blocksize=3)).max() <= 1e-13 * abs(Nb).max()
