@@ -282,6 +282,44 @@ int amg_dev_dot(const double *x, const double *y, long n, double *scratch, doubl
 int amg_dev_dense_apply(const double *Mt, const double *b, double *x, int n, void *stream);
 int amg_dev_gather(double *out, const double *in, const int *idx, long n, void *stream);
 
+/* ------------------------------------------------------------------------ */
+/* 4. Row-partitioned hierarchies: one process per GPU of a node, every level */
+/*    cut into contiguous row blocks, halos pushed GPU-to-GPU over xGMI, one   */
+/*    8-byte all-reduce per residual norm.  The reference   */
+/*    has no distributed path; the arithmetic contract is the single-GPU cycle  */
+/*    (pyamg/multilevel.py:316-548): every row keeps its stored summation order.*/
+/* ------------------------------------------------------------------------ */
+typedef struct amg_comm amg_comm;
+/* transport 0 = "peer": arenas in fine-grained HBM mapped into every rank through HIP IPC; a hand-off is a kernel
+ * that stores into the consumer's arena plus a system-scope flag, the consumer polls the flag from a one-wave kernel
+ * with a wall-clock budget -- all on the hierarchy's stream, capturable in a hipGraph.
+ * transport 1 = "rccl": grouped ncclSend / ncclRecv and ncclAllReduce on the same stream (librccl dlopen-ed). */
+amg_comm *amg_comm_create(int rank, int world, int device, int transport);
+void amg_comm_destroy(amg_comm *c);
+/* declare an exchange plan: counts[dst * world + src] doubles travel from src to dst per exchange (identical matrix
+ * on every rank).  Returns the channel id (>= 0). */
+int amg_comm_add_channel(amg_comm *c, const int *counts);
+/* fix the layout and allocate; peer transport: handle_out[64] = this rank's IPC handle, to be all-gathered */
+int amg_comm_commit(amg_comm *c, unsigned char *handle_out);
+/* peer transport: map the other ranks' arenas; handles = world x 64 bytes in rank order */
+int amg_comm_connect(amg_comm *c, const unsigned char *handles);
+/* rccl transport: rank 0 draws a 128-byte unique id (libpath NULL: "librccl.so"), every rank joins with it */
+int amg_comm_rccl_unique_id(const char *libpath, unsigned char *id_out);
+int amg_comm_rccl_init(amg_comm *c, const char *libpath, const unsigned char *id);
+/* stand-alone use on device pointers: dst_halo <- the peers' entries (v[send_idx[k]] on their side, send_idx NULL =
+ * identity); *result = sqrt(sum over ranks of *partial), added in rank order */
+int amg_comm_exchange(amg_comm *c, int channel, const double *v, const int *send_idx, double *dst_halo, void *stream);
+int amg_comm_allreduce_sqrt(amg_comm *c, int channel, const double *partial, double *result, void *stream);
+/* peer transport: non-zero (with an error message) if some wait ran out of its budget */
+int amg_comm_check(amg_comm *c);
+/* Attach a communicator BEFORE the operators are set: level operators are then the rank's rows with columns
+ * renumbered [owned | halo]; reduce_channel = a channel with count 1 between every pair of ranks (itself included). */
+int amg_hier_set_comm(amg_hier *h, amg_comm *comm, int reduce_channel);
+int amg_hier_set_partition(amg_hier *h, int lvl, int n_own, int n_halo, int channel, const int *send_idx, int i0, int i1);
+int amg_hier_set_gather(amg_hier *h, int lvl, int channel, int rows);
+int amg_hier_set_coarse_gather(amg_hier *h, int channel, int lo);
+int amg_hier_comm_check(amg_hier *h);
+
 /* Setup-time helper (hierarchy construction, not the cycle): Arnoldi iteration on
  * M = diag(dinv) * A_lvl (dinv NULL: M = A_lvl) as in pyamg/util/linalg.py:173-279, used for
  * the spectral-radius estimates behind omega and the Chebyshev bounds.  H is

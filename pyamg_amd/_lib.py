@@ -103,6 +103,19 @@ def lib():
         "amg_dev_dot": [V, V, C.c_long, V, V, V],
         "amg_dev_dense_apply": [V, V, V, I, V],
         "amg_dev_gather": [V, V, V, C.c_long, V],
+        "amg_comm_add_channel": [V, c_int_p],
+        "amg_comm_commit": [V, V],
+        "amg_comm_connect": [V, V],
+        "amg_comm_rccl_unique_id": [C.c_char_p, V],
+        "amg_comm_rccl_init": [V, C.c_char_p, V],
+        "amg_comm_exchange": [V, I, V, V, V, V],
+        "amg_comm_allreduce_sqrt": [V, I, V, V, V],
+        "amg_comm_check": [V],
+        "amg_hier_set_comm": [V, V, I],
+        "amg_hier_set_partition": [V, I, I, I, I, c_int_p, I, I],
+        "amg_hier_set_gather": [V, I, I, I],
+        "amg_hier_set_coarse_gather": [V, I, I],
+        "amg_hier_comm_check": [V],
         "amg_arnoldi": [V, I, c_dbl_p, c_dbl_p, I, D, c_dbl_p, c_int_p, c_int_p],
         "amg_arnoldi_combine": [V, c_dbl_p, I, c_dbl_p],
     }
@@ -138,6 +151,10 @@ def lib():
     L.amg_hier_dev_x.restype = V
     L.amg_hier_dev_b.argtypes = [V]
     L.amg_hier_dev_b.restype = V
+    L.amg_comm_create.argtypes = [I, I, I, I]
+    L.amg_comm_create.restype = V
+    L.amg_comm_destroy.argtypes = [V]
+    L.amg_comm_destroy.restype = None
     L.amg_mat_create.argtypes = [I, I, I, c_int_p, c_int_p, c_dbl_p]
     L.amg_mat_create.restype = V
     L.amg_mat_destroy.argtypes = [V]

@@ -536,15 +536,6 @@ int spmv(const DevCsr &M, StreamMode mode, const double *xg, const double *b, co
     return apply_operator(M, mode, a, st);
 }
 
-// products a_ij * (gscale * xg_j): the polynomial smoother gathers h = c0*r straight from r
-static int spmv_scaled(const DevCsr &M, StreamMode mode, const double *xg, double gscale, const double *b,
-                       const double *v2, double *out, double c0, hipStream_t st)
-{
-    StreamArgs a = base_args(M);
-    a.xg = xg; a.b = b; a.v2 = v2; a.out = out; a.c0 = c0; a.gscale = gscale;
-    return apply_operator(M, mode, a, st);
-}
-
 // one directional sweep of a scheduled (CSR flavour) Gauss-Seidel
 int gs_sweep_csr(const Schedule &S, bool bsr1, double *x, const double *b, bool reverse,
                  hipStream_t st)
@@ -620,6 +611,49 @@ static int bsr_stream_all(const DevBsr &Ab, BlockMode mode, const double *Dinv, 
 
 using namespace amg;
 
+// ------------------------------------------------------------------ row-partitioned levels
+// refresh the halo part of v (a level-lvl vector of n_own + n_halo entries) from its owners
+static int exchange(amg_hier *h, Level &L, double *v)
+{
+    if (!h->comm || L.part.channel < 0) return 0;
+    double *halo = v + L.part.n_own;
+    CHK(comm_exchange_begin(h->comm, L.part.channel, v, L.part.send_idx, halo, h->stream));
+    return comm_exchange_end(h->comm, L.part.channel, halo, h->stream);
+}
+
+// A_l applied with xg as the gathered operand.  On a partitioned level the halo of xg is refreshed first; when the
+// level has a large halo-free row window, that window is computed while the halo is in flight.
+static int level_apply(amg_hier *h, Level &L, StreamMode mode, const double *xg, double gscale, const double *b,
+                       const double *v2, double *out, double c0)
+{
+    hipStream_t st = h->stream;
+    StreamArgs a = base_args(L.A);
+    a.xg = xg; a.b = b; a.v2 = v2; a.out = out; a.c0 = c0; a.gscale = gscale;
+    if (!h->comm || L.part.channel < 0) return apply_operator(L.A, mode, a, st);
+    double *v = const_cast<double *>(xg);          // every gathered vector is a level work vector
+    if (!(h->overlap && L.part.overlap)) {
+        CHK(exchange(h, L, v));
+        return apply_operator(L.A, mode, a, st);
+    }
+    double *halo = v + L.part.n_own;
+    CHK(comm_exchange_begin(h->comm, L.part.channel, v, L.part.send_idx, halo, st));
+    a.row_lo = L.part.i0; a.row_hi = L.part.i1;
+    CHK(apply_operator(L.A, mode, a, st));
+    CHK(comm_exchange_end(h->comm, L.part.channel, halo, st));
+    if (L.part.i0 > 0) { a.row_lo = 0; a.row_hi = L.part.i0; CHK(apply_operator(L.A, mode, a, st)); }
+    if (L.part.i1 < L.A.nrows) { a.row_lo = L.part.i1; a.row_hi = L.A.nrows; CHK(apply_operator(L.A, mode, a, st)); }
+    return 0;
+}
+
+// sqrt of the sum over ALL ranks of the squares of v[0..n) into *slot (single GPU: the plain 2-norm)
+static int global_norm(amg_hier *h, const double *v, long n, double *slot)
+{
+    if (!h->comm) return launch_norm2(v, n, h->norm_scratch, slot, h->stream);
+    double *partial = h->norm_scratch + 1031;
+    CHK(launch_dot(v, v, n, h->norm_scratch, partial, h->stream));
+    return comm_allreduce_sqrt(h->comm, h->reduce_channel, partial, slot, h->stream);
+}
+
 // ------------------------------------------------------------------ relaxation on a level
 // x may be swapped with the level's alternate buffer (Jacobi writes out of place).
 static int relax(amg_hier *h, Level &L, Smoother &s, double *&x, double *&xalt, const double *b,
@@ -639,7 +673,7 @@ static int relax(amg_hier *h, Level &L, Smoother &s, double *&x, double *&xalt, 
                 AMG_HIP(hipMemcpyAsync(xalt, x, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st));
                 CHK(bsr_stream_all(L.Ab, BM_BSR_JACOBI, nullptr, xalt, x, b, s.omega, st));
             } else {
-                CHK(spmv(L.A, bsr ? SM_JACOBI_BSR1 : SM_JACOBI, x, b, x, xalt, nullptr, s.omega, st));
+                CHK(level_apply(h, L, bsr ? SM_JACOBI_BSR1 : SM_JACOBI, x, 0.0, b, x, xalt, s.omega));
                 std::swap(x, xalt);
             }
         }
@@ -650,6 +684,9 @@ static int relax(amg_hier *h, Level &L, Smoother &s, double *&x, double *&xalt, 
         // relaxation.py:280-354 (gauss_seidel), :108-169 (sor), :671-741 (indexed)
         const bool point_block = bsr && L.R > 1 && s.kind != AMG_SM_GAUSS_SEIDEL_INDEXED;
         auto sweep_once = [&](bool reverse) -> int {
+            // partitioned level: HYBRID sweep -- the halo is refreshed once per directional sweep and frozen during
+            // it (Gauss-Seidel inside a rank, Jacobi across ranks: BASELINE configuration C4)
+            CHK(exchange(h, L, x));
             if (point_block)
                 return gs_sweep_block(*s.sched, L.Ab, BM_BSR_GS, nullptr, x, b, reverse, st);
             return gs_sweep_csr(*s.sched, bsr && s.kind != AMG_SM_GAUSS_SEIDEL_INDEXED, x, b, reverse, st);
@@ -683,26 +720,34 @@ static int relax(amg_hier *h, Level &L, Smoother &s, double *&x, double *&xalt, 
             } else if (r_ready && it == 0) {
                 r = L.r;                       // b - A x of this very x, left there by residual_norm_to
             } else {
-                CHK(spmv(L.A, SM_RESIDUAL, x, b, nullptr, L.r, nullptr, 0.0, st));
+                CHK(level_apply(h, L, SM_RESIDUAL, x, 0.0, b, nullptr, L.r, 0.0));
                 r = L.r;
             }
             if (nc == 1) {
                 CHK(launch_axpy_scaled(x, r, s.coef[0], n, st));
             } else if (nc == 2) {
-                CHK(spmv_scaled(L.A, SM_POLY_LAST, r, s.coef[0], r, x, x, s.coef[1], st));
+                CHK(level_apply(h, L, SM_POLY_LAST, r, s.coef[0], r, x, x, s.coef[1]));
             } else {
                 double *hh = L.h, *hn = L.h2;
-                CHK(spmv_scaled(L.A, SM_POLY_STEP, r, s.coef[0], r, nullptr, hh, s.coef[1], st));
+                CHK(level_apply(h, L, SM_POLY_STEP, r, s.coef[0], r, nullptr, hh, s.coef[1]));
                 for (int c = 2; c < nc - 1; ++c) {
-                    CHK(spmv(L.A, SM_POLY_STEP, hh, r, nullptr, hn, nullptr, s.coef[c], st));
+                    CHK(level_apply(h, L, SM_POLY_STEP, hh, 0.0, r, nullptr, hn, s.coef[c]));
                     std::swap(hh, hn);
                 }
-                CHK(spmv(L.A, SM_POLY_LAST, hh, r, x, x, nullptr, s.coef[nc - 1], st));
+                CHK(level_apply(h, L, SM_POLY_LAST, hh, 0.0, r, x, x, s.coef[nc - 1]));
             }
             x_zero = false;
         }
         return 0;
     }
+    default:
+        break;
+    }
+    if (h->comm && L.part.channel >= 0) {
+        set_error("this smoother has no row-partitioned form (offered: jacobi, polynomial, gauss_seidel / indexed as hybrid sweeps)");
+        return AMG_ENOTIMPL;
+    }
+    switch (s.kind) {
     case AMG_SM_GAUSS_SEIDEL_NE: {
         // relaxation.py:821-908 (Kaczmarz sweep over the rows)
         const std::vector<int> &lp = s.sw_level_ptr;
@@ -810,7 +855,15 @@ static int coarse_solve(amg_hier *h, const double *b, double *&x, double *&xalt)
         AMG_HIP(hipMemsetAsync(x, 0, sizeof(double) * (size_t)n, h->stream));
         return 0;
     }
+    if (h->coarse_kind == 1 && h->comm && h->coarse_gather_channel >= 0) {
+        CHK(comm_exchange_begin(h->comm, h->coarse_gather_channel, b, h->coarse_gather_idx, h->coarse_full_b, h->stream));
+        CHK(comm_exchange_end(h->comm, h->coarse_gather_channel, h->coarse_full_b, h->stream));
+        CHK(launch_dense_apply(h->coarse_Mt, h->coarse_full_b, h->coarse_full_x, h->coarse_n, h->stream));
+        AMG_HIP(hipMemcpyAsync(x, h->coarse_full_x + h->coarse_lo, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, h->stream));
+        return 0;
+    }
     if (h->coarse_kind == 1) return launch_dense_apply(h->coarse_Mt, b, x, n, h->stream);
+    if (h->comm && L.part.channel >= 0) { set_error("relaxation as coarse solver has no row-partitioned form"); return AMG_ENOTIMPL; }
     AMG_HIP(hipMemsetAsync(x, 0, sizeof(double) * (size_t)n, h->stream));   // multilevel.py:675
     return relax(h, L, h->coarse_sm, x, xalt, b, true);
 }
@@ -825,8 +878,16 @@ static int cycle(amg_hier *h, int lvl, double *&x, double *&xalt, const double *
     const int nc = Lc.A.nrows;
 
     CHK(relax(h, L, L.sm[AMG_PRE], x, xalt, b, x_zero, r_ready));                          // :494
-    CHK(spmv(L.A, SM_RESIDUAL, x, b, nullptr, L.r, nullptr, 0.0, st));                     // :496
-    CHK(spmv(L.Rm, SM_MATVEC, L.r, nullptr, nullptr, Lc.b, nullptr, 0.0, st));             // :498
+    CHK(level_apply(h, L, SM_RESIDUAL, x, 0.0, b, nullptr, L.r, 0.0));                     // :496
+    CHK(exchange(h, L, L.r));                                                              // R gathers fine residuals
+    if (h->comm && L.part.gather_channel >= 0) {
+        // entering the replicated levels: every rank restricts its slice of the coarse rows, all ranks gather
+        CHK(spmv(L.Rm, SM_MATVEC, L.r, nullptr, nullptr, L.part.rslice, nullptr, 0.0, st));
+        CHK(comm_exchange_begin(h->comm, L.part.gather_channel, L.part.rslice, L.part.gather_idx, Lc.b, st));
+        CHK(comm_exchange_end(h->comm, L.part.gather_channel, Lc.b, st));
+    } else {
+        CHK(spmv(L.Rm, SM_MATVEC, L.r, nullptr, nullptr, Lc.b, nullptr, 0.0, st));         // :498
+    }
     AMG_HIP(hipMemsetAsync(Lc.x, 0, sizeof(double) * (size_t)nc, st));                     // :499
 
     if (lvl == h->nlevels - 2) {
@@ -839,6 +900,9 @@ static int cycle(amg_hier *h, int lvl, double *&x, double *&xalt, const double *
     } else if (cyc == AMG_CYCLE_F) {
         CHK(cycle(h, lvl + 1, Lc.x, Lc.xalt, Lc.b, cyc, true));                            // :509-511
         CHK(cycle(h, lvl + 1, Lc.x, Lc.xalt, Lc.b, AMG_CYCLE_V, false));
+    } else if (h->comm) {
+        set_error("AMLI cycles have no row-partitioned form");
+        return AMG_ENOTIMPL;
     } else {
         // AMLI (multilevel.py:512-540): two coarse cycles from an all-ones guess, A-orthogonalised
         // and combined with optimal step lengths.  The inner products come back to the host
@@ -881,6 +945,7 @@ static int cycle(amg_hier *h, int lvl, double *&x, double *&xalt, const double *
         }
     }
 
+    CHK(exchange(h, Lc, Lc.x));                                                            // P gathers coarse corrections
     CHK(spmv(L.P, SM_MATVEC_ACC, Lc.x, nullptr, nullptr, x, nullptr, 0.0, st));            // :544
     CHK(relax(h, L, L.sm[AMG_POST], x, xalt, b, false));                                   // :545
     return 0;
@@ -905,6 +970,13 @@ static int residual_norm_to(amg_hier *h, double *slot)
     a.xg = L0.x; a.b = L0.b; a.out2 = h->sumsq_partials;
     const bool keep = h->keep_residual && h->nlevels > 1 && L0.sm[AMG_PRE].kind == AMG_SM_POLYNOMIAL &&
                       L0.sm[AMG_PRE].iterations >= 1;
+    if (h->comm) {
+        // partitioned: r = b - A x over the owned rows (halo of x refreshed, interior rows overlapped), then the
+        // all-reduced norm; r stays in L0.r for a polynomial pre-smoother as on one GPU
+        CHK(level_apply(h, L0, SM_RESIDUAL, L0.x, 0.0, L0.b, nullptr, L0.r, 0.0));
+        h->r_kept = keep;
+        return global_norm(h, L0.r, L0.A.nrows, slot);
+    }
     a.out = keep ? L0.r : nullptr;
     h->r_kept = keep;
     const bool stencil = L0.A.st_vals && stencil_enabled();
@@ -1085,10 +1157,16 @@ void amg_hier_destroy(amg_hier *h)
         if (L.sched_csr && L.sched_csr.use_count() == 1) L.sched_csr->release();
         if (L.sched_blk && L.sched_blk.use_count() == 1) L.sched_blk->release();
         free_csr(L.A); free_csr(L.P); free_csr(L.Rm); free_bsr(L.Ab);
+        if (L.part.send_idx) hipFree(L.part.send_idx);
+        if (L.part.gather_idx) hipFree(L.part.gather_idx);
+        if (L.part.rslice) hipFree(L.part.rslice);
         for (double *p : {L.x, L.xalt, L.b, L.r, L.h, L.h2, L.amli[0], L.amli[1], L.amli[2], L.amli[3]}) if (p) hipFree(p);
     }
     free_smoother(h->coarse_sm);
     if (h->coarse_Mt) hipFree(h->coarse_Mt);
+    if (h->coarse_gather_idx) hipFree(h->coarse_gather_idx);
+    if (h->coarse_full_b) hipFree(h->coarse_full_b);
+    if (h->coarse_full_x) hipFree(h->coarse_full_x);
     if (h->arn_V) hipFree(h->arn_V);
     if (h->arn_dinv) hipFree(h->arn_dinv);
     if (h->arn_coef) hipFree(h->arn_coef);
@@ -1160,7 +1238,7 @@ int amg_hier_set_matrix(amg_hier *h, int lvl, int which, int fmt, int nrows, int
         CHK(upload_csr(M, nrows, ncols, cp.data(), cj.data(), cx.data(), &h->dev_bytes));
     }
     if (which == AMG_MAT_A) {
-        if (nrows != ncols) { set_error("A must be square"); return AMG_EINVAL; }
+        if (nrows != ncols && !(h->comm && ncols > nrows)) { set_error("A must be square (row-partitioned: owned rows x [owned | halo] columns)"); return AMG_EINVAL; }
         L.fmt = fmt; L.R = R; L.C = C; L.hasA = true;
         free_bsr(L.Ab);
         if (fmt == AMG_FMT_BSR && R == C && R > 1) {
@@ -1388,6 +1466,97 @@ static int need_schedule(amg_hier *h, Level &L, Smoother &s)
     return 0;
 }
 
+/* ---- row-partitioned hierarchies (one process per GPU): see hier.hpp Partition, comm.hpp ---- */
+int amg_hier_set_comm(amg_hier *h, amg_comm *comm, int reduce_channel)
+{
+    ENTER(h);
+    if (!comm || comm->device != h->device) { set_error("communicator missing or on another device"); return AMG_EINVAL; }
+    if (reduce_channel < 0 || reduce_channel >= (int)comm->ch.size()) { set_error("bad all-reduce channel"); return AMG_EINVAL; }
+    h->comm = comm;
+    h->reduce_channel = reduce_channel;
+    h->finalized = false;
+    return 0;
+}
+
+/* Level lvl of this rank: n_own owned entries followed by n_halo halo entries; `channel` is the exchange plan whose
+ * receive side fills the halo (-1: the level needs no exchange: a replicated level, or one rank), send_idx (host,
+ * the channel's send total) lists the owned entries the peers need, grouped by destination rank; rows [i0, i1) of
+ * the local A read no halo entry. */
+int amg_hier_set_partition(amg_hier *h, int lvl, int n_own, int n_halo, int channel, const int *send_idx, int i0, int i1)
+{
+    ENTER(h);
+    if (!h->comm) { set_error("amg_hier_set_comm first"); return AMG_ESTATE; }
+    if (lvl < 0 || lvl >= h->nlevels || n_own < 0 || n_halo < 0) { set_error("bad partition"); return AMG_EINVAL; }
+    Partition &P = h->lv[lvl].part;
+    if (P.send_idx) { hipFree(P.send_idx); P.send_idx = nullptr; }
+    P.n_own = n_own; P.n_halo = n_halo; P.channel = channel;
+    if (channel >= 0) {
+        if (channel >= (int)h->comm->ch.size()) { set_error("bad channel"); return AMG_EINVAL; }
+        const Channel &C = h->comm->ch[(size_t)channel];
+        if (C.recv_total != n_halo) { set_error("channel does not deliver this level's halo"); return AMG_EINVAL; }
+        for (int k = 0; k < C.send_total; ++k)
+            if (send_idx[k] < 0 || send_idx[k] >= n_own) { set_error("send index outside the owned range"); return AMG_EINVAL; }
+        CHK(dev_alloc(&P.send_idx, C.send_total, &h->dev_bytes));
+        if (C.send_total) AMG_HIP(hipMemcpy(P.send_idx, send_idx, sizeof(int) * (size_t)C.send_total, hipMemcpyHostToDevice));
+    }
+    if (i0 < 0 || i1 > n_own || i1 < i0) { i0 = 0; i1 = 0; }
+    P.i0 = i0; P.i1 = i1;
+    P.overlap = channel >= 0 && n_halo > 0 && (double)(i1 - i0) >= 0.5 * (double)std::max(n_own, 1);
+    h->finalized = false;
+    return 0;
+}
+
+/* Level lvl is the last partitioned level: its restriction R computes `rows` coarse entries (this rank's slice) and
+ * `channel` (every rank receives every rank's slice, its own included) assembles the whole coarse right-hand side
+ * on every rank. */
+int amg_hier_set_gather(amg_hier *h, int lvl, int channel, int rows)
+{
+    ENTER(h);
+    if (!h->comm) { set_error("amg_hier_set_comm first"); return AMG_ESTATE; }
+    if (lvl < 0 || lvl >= h->nlevels - 1 || channel < 0 || channel >= (int)h->comm->ch.size() || rows < 0) { set_error("bad gather"); return AMG_EINVAL; }
+    Partition &P = h->lv[lvl].part;
+    const Channel &C = h->comm->ch[(size_t)channel];
+    if (C.send_total != rows * h->comm->world) { set_error("gather channel does not send this rank's slice to every rank"); return AMG_EINVAL; }
+    if (P.gather_idx) hipFree(P.gather_idx);
+    if (P.rslice) hipFree(P.rslice);
+    P.gather_idx = nullptr; P.rslice = nullptr;
+    std::vector<int> idx((size_t)C.send_total);
+    for (int k = 0; k < C.send_total; ++k) idx[(size_t)k] = rows ? k % rows : 0;
+    CHK(dev_alloc(&P.gather_idx, C.send_total, &h->dev_bytes));
+    if (C.send_total) AMG_HIP(hipMemcpy(P.gather_idx, idx.data(), sizeof(int) * idx.size(), hipMemcpyHostToDevice));
+    CHK(dev_alloc(&P.rslice, rows, &h->dev_bytes));
+    P.gather_channel = channel; P.gather_rows = rows;
+    h->finalized = false;
+    return 0;
+}
+
+/* The coarsest level is partitioned too and the coarse solver is a dense operator: `channel` gathers every rank's
+ * slice of the coarse right-hand side on every rank; this rank's slice starts at entry `lo` of the whole vector. */
+int amg_hier_set_coarse_gather(amg_hier *h, int channel, int lo)
+{
+    ENTER(h);
+    if (!h->comm || channel < 0 || channel >= (int)h->comm->ch.size()) { set_error("bad coarse gather"); return AMG_EINVAL; }
+    const Channel &C = h->comm->ch[(size_t)channel];
+    const int rows = h->comm->world ? C.send_total / h->comm->world : 0;
+    std::vector<int> idx((size_t)C.send_total);
+    for (int k = 0; k < C.send_total; ++k) idx[(size_t)k] = rows ? k % rows : 0;
+    if (h->coarse_gather_idx) hipFree(h->coarse_gather_idx);
+    h->coarse_gather_idx = nullptr;
+    CHK(dev_alloc(&h->coarse_gather_idx, C.send_total, &h->dev_bytes));
+    if (C.send_total) AMG_HIP(hipMemcpy(h->coarse_gather_idx, idx.data(), sizeof(int) * idx.size(), hipMemcpyHostToDevice));
+    h->coarse_gather_channel = channel;
+    h->coarse_lo = lo;
+    h->finalized = false;
+    return 0;
+}
+
+/* after a partitioned solve: non-zero (and an error message) if a peer never delivered */
+int amg_hier_comm_check(amg_hier *h)
+{
+    ENTER(h);
+    return h->comm ? comm_check(h->comm) : 0;
+}
+
 int amg_hier_finalize(amg_hier *h)
 {
     ENTER(h);
@@ -1397,13 +1566,18 @@ int amg_hier_finalize(amg_hier *h)
         if (l < h->nlevels - 1) {
             if (!L.hasP || !L.hasR) { set_error("level " + std::to_string(l) + " lacks P or R"); return AMG_ESTATE; }
             Level &Lc = h->lv[l + 1];
-            if (!Lc.hasA || L.P.nrows != L.A.nrows || L.P.ncols != Lc.A.nrows || L.Rm.nrows != Lc.A.nrows ||
-                L.Rm.ncols != L.A.nrows) {
+            const int r_rows = (h->comm && L.part.gather_channel >= 0) ? L.part.gather_rows : Lc.A.nrows;
+            if (!Lc.hasA || L.P.nrows != L.A.nrows || L.P.ncols != Lc.A.ncols || L.Rm.nrows != r_rows ||
+                L.Rm.ncols != L.A.ncols) {
                 set_error("operator shapes of level " + std::to_string(l) + " are inconsistent");
                 return AMG_EINVAL;
             }
         }
-        const long n = L.A.nrows;
+        if (h->comm && (L.part.n_own != L.A.nrows || L.part.n_own + L.part.n_halo != L.A.ncols)) {
+            set_error("level " + std::to_string(l) + ": partition does not match the local operator");
+            return AMG_EINVAL;
+        }
+        const long n = L.A.ncols;                 // [owned | halo] on a partitioned level, = nrows otherwise
         double **vecs[] = {&L.x, &L.xalt, &L.b, &L.r, &L.h, &L.h2};
         for (double **p : vecs)
             if (!*p) CHK(dev_alloc(p, n, &h->dev_bytes));
@@ -1413,11 +1587,23 @@ int amg_hier_finalize(amg_hier *h)
         }
     }
     if (h->coarse_kind == 2) CHK(need_schedule(h, h->lv[h->nlevels - 1], h->coarse_sm));
-    if (h->coarse_kind == 1 && h->coarse_n != h->lv[h->nlevels - 1].A.nrows) {
+    if (h->coarse_kind == 1 && h->comm && h->coarse_gather_channel >= 0) {
+        if (!h->coarse_full_b) CHK(dev_alloc(&h->coarse_full_b, h->coarse_n, &h->dev_bytes));
+        if (!h->coarse_full_x) CHK(dev_alloc(&h->coarse_full_x, h->coarse_n, &h->dev_bytes));
+        if (h->coarse_lo < 0 || h->coarse_lo + h->lv[h->nlevels - 1].A.nrows > h->coarse_n) {
+            set_error("coarse slice outside the dense operator");
+            return AMG_EINVAL;
+        }
+    } else if (h->coarse_kind == 1 && h->coarse_n != h->lv[h->nlevels - 1].A.nrows) {
         set_error("coarse dense operator has the wrong size");
         return AMG_EINVAL;
     }
     if (!h->norm_scratch) CHK(dev_alloc(&h->norm_scratch, 1024 + 8, &h->dev_bytes));
+    if (h->comm) {
+        if (h->reduce_channel < 0) { set_error("partitioned hierarchy without an all-reduce channel"); return AMG_ESTATE; }
+        const char *env = getenv("AMG_DIST_OVERLAP");
+        if (env) h->overlap = atoi(env);
+    }
     {
         StreamArgs a0 = base_args(h->lv[0].A);
         long need = std::max(stream_blocks(a0), stencil_blocks(a0, h->lv[0].A)) + 8;
@@ -1434,6 +1620,7 @@ int amg_hier_finalize(amg_hier *h)
     {
         const char *env = getenv("AMG_HIP_GRAPHS");
         if (env) h->use_graphs = atoi(env);
+        if (h->comm && h->comm->transport == 1) h->use_graphs = 0;      // library calls inside the iteration: run eagerly
     }
     h->finalized = true;
     return 0;
@@ -1483,7 +1670,7 @@ int amg_hier_solve(amg_hier *h, const double *b, double *x, double tol, int maxi
 
     // tol *= norm(b)  (multilevel.py:427-429)
     double normb = 0.0;
-    CHK(launch_norm2(L0.b, L0.A.nrows, h->norm_scratch, h->res_dev + maxiter + 1, st));
+    CHK(global_norm(h, L0.b, L0.A.nrows, h->res_dev + maxiter + 1));
     AMG_HIP(hipMemcpyAsync(&normb, h->res_dev + maxiter + 1, sizeof(double), hipMemcpyDeviceToHost, st));
     CHK(residual_norm_to(h, h->res_dev));                                         // :450
     AMG_HIP(hipMemcpyAsync(&residuals[0], h->res_dev, sizeof(double), hipMemcpyDeviceToHost, st));
@@ -1526,6 +1713,7 @@ int amg_hier_pcg(amg_hier *h, const double *b, double *x, double tol, int maxite
     if (!h->finalized) { set_error("hierarchy not finalised"); return AMG_ESTATE; }
     if (!b || !x || !residuals || !nres || !info || maxiter < 1) { set_error("bad pcg arguments"); return AMG_EINVAL; }
     if (cyc == AMG_CYCLE_AMLI) { set_error("AMLI cycles require fgmres or no acceleration"); return AMG_EINVAL; }
+    if (h->comm) { set_error("the device PCG has no row-partitioned form yet"); return AMG_ENOTIMPL; }
     Level &L0 = h->lv[0];
     hipStream_t st = h->stream;
     const long n = L0.A.nrows;
@@ -1636,7 +1824,7 @@ int amg_hier_matvec(amg_hier *h, int lvl, int which, const double *x, double *y)
     if (lvl < 0 || lvl >= h->nlevels || which < 0 || which > 2) { set_error("bad level/which"); return AMG_EINVAL; }
     Level &L = h->lv[lvl];
     const DevCsr &M = (which == AMG_MAT_A) ? L.A : (which == AMG_MAT_P ? L.P : L.Rm);
-    if (!M.Ap) { set_error("operator not set"); return AMG_ESTATE; }
+    if (!M.Ap && !(M.blk && M.blk->Ap)) { set_error("operator not set"); return AMG_ESTATE; }
     double *dx = nullptr, *dy = nullptr;
     CHK(dev_alloc(&dx, M.ncols, (long *)nullptr));
     CHK(dev_alloc(&dy, M.nrows, (long *)nullptr));
@@ -1798,7 +1986,7 @@ int amg_hier_time_spmv(amg_hier *h, int lvl, int which, int mode, int reps, doub
     if (lvl < 0 || lvl >= h->nlevels || reps < 1 || !ms) { set_error("bad arguments"); return AMG_EINVAL; }
     Level &L = h->lv[lvl];
     const DevCsr &M = (which == AMG_MAT_A) ? L.A : (which == AMG_MAT_P ? L.P : L.Rm);
-    if (!M.Ap) { set_error("operator not set"); return AMG_ESTATE; }
+    if (!M.Ap && !(M.blk && M.blk->Ap)) { set_error("operator not set"); return AMG_ESTATE; }
     // vectors: A: x -> r ; P: coarse x -> h ; R: r -> coarse b
     const double *in; double *out;
     if (which == AMG_MAT_A) { in = L.x; out = L.r; }

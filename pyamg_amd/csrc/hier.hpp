@@ -2,6 +2,7 @@
 #pragma once
 #include "amg_dev.hpp"
 #include "../../include/amgcore_hip.h"
+#include "comm.hpp"
 
 #include <memory>
 
@@ -66,8 +67,27 @@ struct Smoother {
     DevCsr aux[2];
 };
 
+// A level of a ROW-PARTITIONED hierarchy (one process per GPU): this rank owns n_own consecutive entries of the
+// level's vector space; its vectors are [owned | halo], the halo being the off-rank entries its rows of A_l, R_l
+// and P_{l-1} gather, grouped by owner.  Local operators keep their rows' stored order and only renumber columns,
+// so every row sum is the single-GPU one.
+struct Partition {
+    int n_own = 0, n_halo = 0;
+    int channel = -1;              // halo exchange plan (comm.hpp); -1: nothing to exchange on this level
+    int *send_idx = nullptr;       // device: owned entries the peers need, grouped by destination rank
+    int i0 = 0, i1 = 0;            // rows [i0, i1) of A read no halo entry: they run while the halo is in flight
+    bool overlap = false;
+    // entering the replicated part of the hierarchy: R computes this rank's slice of the coarse right-hand side,
+    // all ranks gather the slices
+    int gather_channel = -1;
+    int gather_rows = 0;
+    int *gather_idx = nullptr;     // device: (0..gather_rows) repeated once per rank
+    double *rslice = nullptr;
+};
+
 struct Level {
     int fmt = AMG_FMT_CSR, R = 1, C = 1;   // container of A in the reference hierarchy
+    Partition part;
     DevCsr A, P, Rm;
     DevBsr Ab;                             // A's own blocks when fmt == BSR and R == C > 1
     bool hasA = false, hasP = false, hasR = false;
@@ -146,4 +166,13 @@ struct amg_hier {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double last_ms = 0.0;
     long dev_bytes = 0;
+    // row-partitioned mode (amg_hier_set_comm): not owned
+    amg_comm *comm = nullptr;
+    int reduce_channel = -1;                     // 1 x 1 channel for the residual-norm all-reduce
+    // a PARTITIONED coarsest level with a dense coarse solver: all ranks gather the right-hand side, apply the
+    // dense operator redundantly (bit-identical everywhere) and keep their slice of the result
+    int coarse_gather_channel = -1, coarse_lo = 0;
+    int *coarse_gather_idx = nullptr;
+    double *coarse_full_b = nullptr, *coarse_full_x = nullptr;
+    int overlap = 1;                             // interior rows while the halo is in flight
 };

@@ -213,6 +213,13 @@ class DistributedSolver(object):
         self.lv = []
         self.keep_residual = _os.environ.get("AMG_KEEP_RESIDUAL", "1") != "0"
         self._r_kept = False
+        # Engine: with the HIP backend the whole partitioned cycle runs in libamgcore_hip.so (hier.hip with a
+        # communicator, comm.hip): transport "peer" = IPC-mapped arenas, GPU-to-GPU pushes and flag kernels on the
+        # hierarchy's stream (graph-capturable); "rccl" = grouped ncclSend/ncclRecv + ncclAllReduce from C++.
+        # "python" keeps the cycle in this file with torch.distributed collectives (what the CPU tests drive).
+        want = _os.environ.get("AMG_DIST_TRANSPORT", "peer" if isinstance(backend, HipBackend) else "python")
+        self.transport = want if isinstance(backend, HipBackend) else "python"
+        self.native = None
         self._build(levels, coarse_dense)
 
     # ------------------------------------------------------------------ setup
@@ -276,8 +283,10 @@ class DistributedSolver(object):
             lv.recv_counts = [int(v) for v in recv_counts]
             lv.send_counts = [int(v) for v in send_counts]
             lv.n_send = int(send_counts.sum())
-            lv.send_idx = self.be.ivec(send_idx) if lv.n_send else None
-            lv.sendbuf = self.be.vec(lv.n_send)
+            lv.send_idx_host = np.ascontiguousarray(send_idx, dtype=np.intc)
+            native = self.transport != "python"
+            lv.send_idx = self.be.ivec(send_idx) if (lv.n_send and not native) else None
+            lv.sendbuf = self.be.vec(lv.n_send) if not native else None
             lv.halo_ids = H
             lv.comm = (lv.n_halo + lv.n_send) > 0
             if W > 1:
@@ -293,6 +302,9 @@ class DistributedSolver(object):
             out[m] = cols[m] - lo
             out[~m] = self.lv[l].n_own + np.searchsorted(halos[l], cols[~m])
             return out
+        if self.transport != "python":
+            self._build_native(levels, coarse_dense, loc, own, rrows, renum)
+            return
         for l, L in enumerate(levels):
             lv = self.lv[l]
             n_ext = lv.n_own + lv.n_halo
@@ -355,6 +367,186 @@ class DistributedSolver(object):
             self.coarse_full_x = self.be.vec(nc)
         self.nnz_coarse = int(levels[-1]["A"].nnz)
         self.acc = self.be.vec(1)
+
+    # ------------------------------------------------------------------ native engine (C++ cycle + exchange)
+    @staticmethod
+    def _halo_free_window(Ap, Ajl, n_own):
+        """largest run of rows [i0, i1) that read no halo column (they can run while the halo is in flight)"""
+        hal = np.nonzero(Ajl >= n_own)[0]
+        if not len(hal):
+            return 0, n_own
+        rows_h = np.unique(np.searchsorted(Ap, hal, side="right") - 1)
+        gaps = np.diff(np.concatenate(([-1], rows_h, [n_own])))
+        k = int(np.argmax(gaps))
+        i0 = int(rows_h[k - 1]) + 1 if k > 0 else 0
+        i1 = int(rows_h[k]) if k < len(rows_h) else n_own
+        return i0, i1
+
+    def _build_native(self, levels, coarse_dense, loc, own, rrows, renum):
+        from . import _lib
+        from .multilevel import _desc_struct
+        torch, dist = self.torch, self.dist
+        Lb = _lib.lib()
+        W, r, nl, fr = self.world, self.rank, self.nlevels, self.first_rep
+        be = self.be
+        comm = Lb.amg_comm_create(r, W, be.device, 1 if self.transport == "rccl" else 0)
+        if not comm:
+            raise _lib.AmgError(Lb.amg_last_error().decode())
+        self._comm = comm
+
+        def gather_rows(row):
+            """every rank's row of a count matrix -> W x W (dst-major), identical on all ranks"""
+            row = np.asarray(row, dtype=np.int64)
+            if W == 1:
+                return row.reshape(1, 1)
+            out = [torch.zeros(W, dtype=torch.int64) for _ in range(W)]
+            dist.all_gather(out, torch.from_numpy(row.copy()), group=self.host_group)
+            return np.stack([t.numpy() for t in out])
+
+        def add_channel(matrix):
+            m = np.ascontiguousarray(matrix, dtype=np.intc)
+            ch = Lb.amg_comm_add_channel(comm, _lib.ip(m))
+            if ch < 0:
+                raise _lib.AmgError(Lb.amg_last_error().decode())
+            return ch
+        halo_ch = [-1] * nl
+        for l in range(nl):
+            lv = self.lv[l]
+            if W > 1 and lv.comm:
+                halo_ch[l] = add_channel(gather_rows(lv.recv_counts))
+        gather_ch, gather_rows_n = -1, 0
+        if W > 1 and 1 <= fr <= nl - 1:
+            sizes = np.diff(self.bounds[fr]).astype(np.int64)             # slice of every source rank
+            gather_ch = add_channel(np.tile(sizes[None, :], (W, 1)))
+            gather_rows_n = int(sizes[r])
+        coarse_ch = -1
+        if W > 1 and fr > nl - 1 and coarse_dense is not None:
+            sizes = np.diff(self.bounds[-1]).astype(np.int64)             # the coarsest level is partitioned too
+            coarse_ch = add_channel(np.tile(sizes[None, :], (W, 1)))
+        reduce_ch = add_channel(np.ones((W, W), dtype=np.int64))
+        handle = np.zeros(64, dtype=np.uint8)
+        _lib.check(Lb.amg_comm_commit(comm, handle.ctypes.data))
+        if self.transport == "rccl":
+            import os as _os
+            libpath = _os.environ.get("AMG_RCCL_LIB") or _os.path.join(_os.path.dirname(torch.__file__), "lib", "librccl.so")
+            if not _os.path.exists(libpath):
+                libpath = "librccl.so"
+            uid = np.zeros(128, dtype=np.uint8)
+            if r == 0:
+                _lib.check(Lb.amg_comm_rccl_unique_id(libpath.encode(), uid.ctypes.data))
+            if W > 1:
+                t = torch.from_numpy(uid)
+                dist.broadcast(t, src=0, group=self.host_group)
+                uid = t.numpy()
+            _lib.check(Lb.amg_comm_rccl_init(comm, libpath.encode(), uid.ctypes.data))
+        else:
+            if W > 1:
+                out = [torch.zeros(64, dtype=torch.uint8) for _ in range(W)]
+                dist.all_gather(out, torch.from_numpy(handle.copy()), group=self.host_group)
+                handles = np.concatenate([t.numpy() for t in out])
+            else:
+                handles = handle
+            handles = np.ascontiguousarray(handles, dtype=np.uint8)
+            _lib.check(Lb.amg_comm_connect(comm, handles.ctypes.data))
+            if W > 1:
+                dist.barrier(group=self.host_group)          # every arena is mapped everywhere before anybody pushes
+        h = Lb.amg_hier_create(nl, be.device)
+        if not h:
+            raise _lib.AmgError(Lb.amg_last_error().decode())
+        self._h = h
+        _lib.check(Lb.amg_hier_set_comm(h, comm, reduce_ch))
+        keep = []
+
+        def set_mat(l, which, nrows, ncols, Ap, Aj, Ax, bsr11):
+            Ap = np.ascontiguousarray(Ap, dtype=np.intc)
+            Aj = np.ascontiguousarray(Aj, dtype=np.intc)
+            Ax = np.ascontiguousarray(Ax, dtype=np.float64)
+            _lib.check(Lb.amg_hier_set_matrix(h, l, which, 1 if bsr11 else 0, int(nrows), int(ncols), 1, 1,
+                                              Ap.ctypes.data, Aj.ctypes.data, Ax.ctypes.data, 0))
+        for l, L in enumerate(levels):
+            lv = self.lv[l]
+            n_ext = lv.n_own + lv.n_halo
+            Ap, Aj, Ax = loc[l]["A"]
+            Ajl = renum(Aj, l)
+            set_mat(l, 0, lv.n_own, n_ext, Ap, Ajl, Ax, loc[l]["bsr"])
+            i0, i1 = self._halo_free_window(Ap, Ajl, lv.n_own) if lv.n_halo else (0, lv.n_own)
+            lv.i0, lv.i1 = i0, i1
+            _lib.check(Lb.amg_hier_set_partition(h, l, lv.n_own, lv.n_halo, halo_ch[l], _lib.ip(lv.send_idx_host), i0, i1))
+            lv.nnzA = len(Ax)
+            lv.A_bsr = loc[l]["bsr"]
+            if l < nl - 1:
+                nxt = self.lv[l + 1]
+                if l + 1 == fr and gather_ch >= 0:
+                    _lib.check(Lb.amg_hier_set_gather(h, l, gather_ch, gather_rows_n))
+                Pp, Pj, Px = loc[l]["P"]
+                set_mat(l, 1, lv.n_own, nxt.n_own + nxt.n_halo, Pp, renum(Pj, l + 1), Px, False)
+                Rp, Rj, Rx = loc[l]["R"]
+                set_mat(l, 2, rrows[l][1] - rrows[l][0], n_ext, Rp, renum(Rj, l), Rx, False)
+                for which, side in ((0, "pre"), (1, "post")):
+                    sdesc = L.get(side)
+                    nm = None if sdesc is None else sdesc.get("name")
+                    if nm not in (None, "jacobi", "polynomial", "gauss_seidel", "gauss_seidel_indexed"):
+                        raise NotImplementedError(
+                            "smoother %r has no partitioned form; offered: jacobi / polynomial (chebyshev, richardson) / "
+                            "gauss_seidel and gauss_seidel_indexed as HYBRID sweeps / None" % (nm,))
+                    d = None if sdesc is None else dict(sdesc)
+                    if nm == "gauss_seidel_indexed":
+                        idx = np.asarray(d["indices"], dtype=np.int64)
+                        lo_, hi_ = own[l]
+                        d["indices"] = (idx[(idx >= lo_) & (idx < hi_)] - lo_).astype(np.intc)
+                    _lib.check(Lb.amg_hier_set_smoother(h, l, which, _desc_struct(d, keep)))
+            lv.pre, lv.post = L.get("pre"), L.get("post")
+        nc = levels[-1]["A"].shape[0]
+        self.nc = nc
+        self.nnz_coarse = int(levels[-1]["A"].nnz)
+        if coarse_dense is not None:
+            M = np.ascontiguousarray(np.asarray(coarse_dense, dtype=np.float64))
+            _lib.check(Lb.amg_hier_set_coarse_dense(h, _lib.dp(M), M.shape[0]))
+        if coarse_ch >= 0:
+            _lib.check(Lb.amg_hier_set_coarse_gather(h, coarse_ch, int(self.bounds[-1][r])))
+        _lib.check(Lb.amg_hier_finalize(h))
+        self.native = (Lb, h, comm)
+        self._b_local = None
+
+    def _native_solve(self, b_local, x_local, tol, maxiter, cycle, x_zero, fixed):
+        from . import _lib
+        Lb, h, comm = self.native
+        res = np.zeros(maxiter + 2, dtype=np.float64)
+        nres = C.c_int(0)
+        flags = (1 if x_zero else 0) | (2 if fixed else 0)
+        cyc = {"V": 0, "W": 1, "F": 2}.get(cycle)
+        if cyc is None:
+            raise NotImplementedError("AMLI cycles are not implemented on the partitioned path")
+        _lib.check(Lb.amg_hier_solve(h, b_local.ctypes.data, x_local.ctypes.data, float(tol), int(maxiter), cyc,
+                                     _lib.dp(res), C.byref(nres), flags))
+        _lib.check(Lb.amg_hier_comm_check(h))
+        return res[:nres.value]
+
+    def operator_form(self, l):
+        """storage form level l's local A is applied from: 0 CSR, 1 offset-pattern, 2 stencil"""
+        if self.native is not None:
+            return self.native[0].amg_hier_operator_form(self.native[1], int(l))
+        return self.be.L.amg_mat_form(self.lv[l].A)
+
+    def last_solve_ms(self):
+        Lb, h, comm = self.native
+        return Lb.amg_hier_last_solve_ms(h)
+
+    def device_bytes(self):
+        Lb, h, comm = self.native
+        return int(Lb.amg_hier_device_bytes(h))
+
+    def close(self):
+        """collective: every rank's arena stays mapped in its peers until all have stopped exchanging"""
+        if self.native is not None:
+            Lb, h, comm = self.native
+            if self.world > 1:
+                self.dist.barrier(group=self.host_group)
+            Lb.amg_hier_destroy(h)
+            if self.world > 1:
+                self.dist.barrier(group=self.host_group)
+            Lb.amg_comm_destroy(comm)
+            self.native = None
 
     # ------------------------------------------------------------------ communication
     def xapply(self, l, mode, v, b, v2, out, out2, c0, gscale=1.0):
@@ -533,6 +725,16 @@ class DistributedSolver(object):
     def solve(self, b_local, x0_local=None, tol=1e-5, maxiter=100, cycle="V", fixed=False):
         """multilevel.py:316-471 on the local slices; returns (x_local, residuals)"""
         cycle = str(cycle).upper()
+        if self.native is not None:
+            x_zero = x0_local is None or not np.any(x0_local)
+            if self.world > 1:                      # x0 == 0 must hold on EVERY rank for the static shortcut
+                flag = self.torch.tensor([1.0 if x_zero else 0.0], dtype=self.torch.float64)
+                self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN, group=self.host_group)
+                x_zero = bool(flag.item() > 0.5)
+            b1 = np.ascontiguousarray(b_local, dtype=np.float64)
+            x1 = np.zeros(self.lv[0].n_own) if x0_local is None else np.array(x0_local, dtype=np.float64)
+            res = self._native_solve(b1, x1, tol, maxiter, cycle, x_zero, fixed)
+            return x1, [float(v) for v in res]
         self.set_problem(b_local, x0_local)
         lv = self.lv[0]
         normb = self.global_norm(lv.b, lv.n_own)

@@ -1,6 +1,10 @@
-"""GPU: the row-partitioned cycle on real HIP kernels.  Two ranks share the one GPU of the box
-(gloo moves the CUDA halo tensors; on a multi-GPU node the same code runs over nccl = RCCL), and the
-gathered iterates must equal the single-GPU resident solve bit for bit."""
+"""GPU: the row-partitioned cycle on real HIP kernels.  Two or three ranks share the one GPU of the box and the
+gathered iterates must equal the single-GPU resident solve bit for bit, for every transport:
+  peer    the C++ cycle with IPC-mapped arenas: GPU-to-GPU pushes + flag kernels on the hierarchy's stream
+  rccl    the C++ cycle with grouped ncclSend/ncclRecv + ncclAllReduce (RCCL refuses two ranks on one device, so
+          each rank poses as its own host -- NCCL_HOSTID -- and RCCL takes its socket transport over loopback:
+          the C++/RCCL call path is the one an 8-GPU node runs, only the wire differs)
+  python  the cycle driven from pyamg_amd/distributed.py with torch.distributed collectives (gloo here)"""
 import os
 import socket
 
@@ -18,10 +22,19 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, case, out_dir):
+def _transport_env(rank, transport):
+    os.environ["AMG_DIST_TRANSPORT"] = transport
+    if transport == "rccl":
+        os.environ.update(NCCL_HOSTID="amgtest-rank%d" % rank, NCCL_SOCKET_IFNAME="lo", NCCL_IB_DISABLE="1",
+                          NCCL_P2P_DISABLE="1", NCCL_SHM_DISABLE="1", NCCL_DEBUG="ERROR")
+
+
+def _worker(rank, world, port, case, out_dir, transport):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    _transport_env(rank, transport)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    S = None
     try:
         from pyamg_amd.distributed import DistributedSolver, HipBackend, split_rows
         g = golden_io.load_hier(case)
@@ -37,17 +50,22 @@ def _worker(rank, world, port, case, out_dir):
         if rank == 0:
             np.save(os.path.join(out_dir, "res.npy"), np.array(res))
             np.save(os.path.join(out_dir, "res_fixed.npy"), np.array(res2))
+            np.save(os.path.join(out_dir, "native.npy"), np.array([1.0 if S.native is not None else 0.0]))
     finally:
+        if S is not None:
+            S.close()
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("transport", ["peer", "rccl", "python"])
 @pytest.mark.parametrize("case", ["sa_jacobi_2d", "sa_cheb2_3d"])
-def test_two_ranks_equal_single_gpu(case, tmp_path):
+def test_two_ranks_equal_single_gpu(case, transport, tmp_path):
     g = golden_io.load_hier(case)
     ml = golden_io.build_ml(g)
     res1 = []
     x1 = ml.solve(g["b"], tol=g["meta"]["tol"], maxiter=g["meta"]["maxiter"], residuals=res1)
-    mp.spawn(_worker, args=(2, _free_port(), case, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), case, str(tmp_path), transport), nprocs=2, join=True)
+    assert np.load(tmp_path / "native.npy")[0] == (0.0 if transport == "python" else 1.0)
     x = np.concatenate([np.load(tmp_path / ("x_%d.npy" % r)) for r in range(2)])
     res = np.load(tmp_path / "res.npy")
     assert len(res) == len(res1)
@@ -67,16 +85,18 @@ def _own_hierarchy(grid):
     return ml, b
 
 
-def _worker_stencil(rank, world, port, grid, out_dir):
+def _worker_stencil(rank, world, port, grid, out_dir, transport):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    _transport_env(rank, transport)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    S = None
     try:
         from pyamg_amd.distributed import DistributedSolver, HipBackend, split_rows, levels_from_ml
         ml, b = _own_hierarchy(grid)
         levels, coarse = levels_from_ml(ml)
         S = DistributedSolver(levels, coarse, HipBackend(0), rank, world, replicate_below=600)
-        assert S.be.L.amg_mat_form(S.lv[0].A) == 2, "level 0 of the slab should be in stencil form"
+        assert S.operator_form(0) == 2, "level 0 of the slab should be in stencil form"
         bnd = split_rows(len(b), world)
         lo, hi = int(bnd[rank]), int(bnd[rank + 1])
         x, res = S.solve(b[lo:hi], None, tol=0.0, maxiter=5, cycle="V", fixed=True)
@@ -84,11 +104,13 @@ def _worker_stencil(rank, world, port, grid, out_dir):
         if rank == 0:
             np.save(os.path.join(out_dir, "res.npy"), np.array(res))
     finally:
+        if S is not None:
+            S.close()
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_rank_local_stencil_form_with_halos(world, tmp_path):
+@pytest.mark.parametrize("world,transport", [(2, "peer"), (3, "peer"), (3, "rccl"), (2, "python")])
+def test_rank_local_stencil_form_with_halos(world, transport, tmp_path):
     """Level 0 of a rank's slab is large enough (>= 1024 rows) for the stencil form: its halo columns
     enter the union stencil as extra offsets, the lower-halo one FIRST in stored order although its
     local index is the largest (slot order is topological, not increasing).  3 ranks: the middle one
@@ -98,17 +120,19 @@ def test_rank_local_stencil_form_with_halos(world, tmp_path):
     ml, b = _own_hierarchy(grid)
     res1 = []
     x1 = ml.solve(b, tol=0.0, maxiter=5, residuals=res1)
-    mp.spawn(_worker_stencil, args=(world, _free_port(), grid, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker_stencil, args=(world, _free_port(), grid, str(tmp_path), transport), nprocs=world, join=True)
     x = np.concatenate([np.load(tmp_path / ("x_%d.npy" % r)) for r in range(world)])
     res = np.load(tmp_path / "res.npy")
     assert np.array_equal(x, x1), np.abs(x - x1).max()
     assert np.allclose(res, res1, rtol=1e-12, atol=1e-13 * res1[0])
 
 
-def _worker_hybrid(rank, world, port, case, out_dir, rep=0):
+def _worker_hybrid(rank, world, port, case, out_dir, rep=0, transport="peer"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    _transport_env(rank, transport)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    S = None
     try:
         from pyamg_amd.distributed import DistributedSolver, HipBackend, split_rows
         g = golden_io.load_hier(case)
@@ -119,11 +143,13 @@ def _worker_hybrid(rank, world, port, case, out_dir, rep=0):
         x, res = S.solve(g["b"][lo:hi], None, tol=0.0, maxiter=3, cycle="V", fixed=True)
         np.save(os.path.join(out_dir, "x_%d.npy" % rank), x)
     finally:
+        if S is not None:
+            S.close()
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case,rep", [("sa_gs_3d", 0), ("rs_gs_2d", 450)])
-def test_hybrid_gauss_seidel_on_gpu_matches_partition_emulation(case, rep, tmp_path):
+@pytest.mark.parametrize("case,rep,transport", [("sa_gs_3d", 0, "peer"), ("rs_gs_2d", 450, "peer"), ("rs_gs_2d", 450, "python")])
+def test_hybrid_gauss_seidel_on_gpu_matches_partition_emulation(case, rep, transport, tmp_path):
     """C4's smoother: GS inside a rank (level-scheduled HIP kernels), Jacobi across ranks; oracle =
     the partition-emulating CPU run (tests/test_distributed_cpu.py)."""
     import oracle_lib
@@ -131,7 +157,7 @@ def test_hybrid_gauss_seidel_on_gpu_matches_partition_emulation(case, rep, tmp_p
     from test_distributed_cpu import _hybrid_cycle, hybrid_bounds
     world = 2
     g = golden_io.load_hier(case)
-    mp.spawn(_worker_hybrid, args=(world, _free_port(), case, str(tmp_path), rep), nprocs=world, join=True)
+    mp.spawn(_worker_hybrid, args=(world, _free_port(), case, str(tmp_path), rep, transport), nprocs=world, join=True)
     x = np.concatenate([np.load(tmp_path / ("x_%d.npy" % r)) for r in range(world)])
     lib = oracle_lib.load()
     bounds = hybrid_bounds(g, world, rep)
