@@ -9,11 +9,13 @@ One "step" = one multilevel_solver.solve() iteration: a V-cycle + the residual
 norm (pyamg/multilevel.py:454-461).  The hierarchy is resident in HBM before the
 timed region (b and x are device vectors).  Prints ONE JSON line (rank 0).
 
-N > 1: one process per GPU (torch.distributed, backend nccl = RCCL over xGMI).  The SAME
-500^3 problem is row-partitioned over the N ranks on every level (pyamg_amd/distributed.py):
-halo exchange before each operator application, one all-reduce per step for the residual
-norm -> "scaling": "strong".  Rank 0 builds the hierarchy once and ships it to the other
-ranks through /dev/shm.  `--replicas` runs N independent copies instead (no exchange).
+N > 1: one process per GPU.  `python bench.py --gpus N` starts the N ranks itself (fresh child processes; the parent
+never touches the GPU); under `torch.distributed.run` the ranks come from the launcher (RANK / WORLD_SIZE).  The SAME
+500^3 problem is row-partitioned over the N ranks on every level: the whole partitioned cycle runs in
+libamgcore_hip.so (hier.hip + comm.hip) -- halos pushed GPU-to-GPU through IPC-mapped arenas over xGMI ("peer"), or
+grouped ncclSend/ncclRecv + ncclAllReduce ("rccl", AMG_DIST_TRANSPORT), one 8-byte all-reduce per step for the residual
+norm -> "scaling": "strong" (total work fixed).  Rank 0 builds the hierarchy once and ships it to the other ranks
+through /dev/shm.  `--replicas` runs N independent copies instead (no exchange).
 """
 import argparse
 import ctypes as C
@@ -72,12 +74,75 @@ def oracle_hierarchy(ml):
     return oracle_lib.Hierarchy(levels, M if kind == "dense" else None, dup_prolong=True)
 
 
+def cpu_baseline_of(ml, b, gpu_first):
+    """One step (V-cycle + residual norm, from x0 = 0) of the same hierarchy and right-hand side with the C oracle on the
+    host cores: the row-parallel loops over the cores this process may use, then the scalar port.  gpu_first: None, or
+    a callable returning (iterate after one GPU cycle from x0 = 0, its residual norm) for the full-size parity check."""
+    H = oracle_hierarchy(ml)
+    A0c = ml.levels[0].A
+    n = A0c.shape[0]
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+
+    def cpu_step(threads):
+        H.lib.oracle_set_threads(threads)
+        xo = np.zeros(n)
+        t0 = time.perf_counter()
+        H.cycle(xo, b, "V")
+        # + the residual norm that closes the step (multilevel.py:461)
+        Ah = np.zeros(n)
+        H.lib.oracle_csr_matvec(n, ip(A0c.indptr), ip(A0c.indices), dp(A0c.data), dp(xo), dp(Ah))
+        rn = H.lib.oracle_norm2(dp(b - Ah), n)
+        return time.perf_counter() - t0, rn, xo
+
+    cores = max(1, min(len(os.sched_getaffinity(0)), 16))      # a 1-GPU box's share of host cores
+    t_par, rn_par, xo_par = cpu_step(cores)
+    t_cpu, rn, xo = cpu_step(1)
+    H.lib.oracle_set_threads(1)
+    log("[bench] CPU oracle: 1 step in %.2fs on 1 thread, %.2fs on %d threads, residual %.6e" % (t_cpu, t_par, cores, rn))
+    cpu = {"value": round(1.0 / t_par, 5), "unit": "V-cycle iterations/s", "cores": cores, "kind": "port",
+           "sample": "1 V-cycle + residual norm of the same hierarchy and RHS from x0=0 with the C oracle "
+                     "(oracle/amg_oracle.c, -O3, row-parallel OpenMP loops: SpMV, Chebyshev and vector "
+                     "updates; includes the reference's discarded second P*coarse_x per level, "
+                     "multilevel.py:548)",
+           "seconds": round(t_par, 3),
+           "single_thread": {"value": round(1.0 / t_cpu, 5), "seconds": round(t_cpu, 3)},
+           "thread_count_independent": bool(np.array_equal(xo, xo_par) and rn == rn_par)}
+    if gpu_first is not None:
+        xg, rg = gpu_first()
+        cpu["first_step_iterate_bit_identical_to_gpu"] = bool(np.array_equal(xg, xo))
+        cpu["first_step_residual_equals_gpu"] = bool(abs(rn - rg) <= 1e-12 * abs(rn))
+        log("[bench] first iterate at full size bit-identical to the oracle's: %s" % cpu["first_step_iterate_bit_identical_to_gpu"])
+    return cpu
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (this parent never touches the
+    GPU and is never replaced), relay rank 0's JSON line, fail if any rank fails."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        out = subprocess.PIPE if r == 0 else subprocess.DEVNULL
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=out))
+    line, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(line.decode() if line else "")
+    sys.stdout.flush()
+    if any(rcs):
+        raise SystemExit("rank exit codes: %s" % rcs)
+
+
 def partitioned_main(args, rank, local_rank, world, torch, dist):
     """strong scaling: one problem, rows of every level split over the ranks"""
     import shutil
     from pyamg_amd.distributed import (DistributedSolver, HipBackend, levels_from_ml, load_levels, save_levels,
                                        split_rows)
-    host_group = dist.new_group(backend="gloo")
+    host_group = dist.group.WORLD
     n = args.grid ** 3
     # where to ship the hierarchy: a memory-backed directory with room for ~0.32 KB per fine unknown
     need = int(330.0 * n) + (1 << 28)
@@ -95,29 +160,8 @@ def partitioned_main(args, rank, local_rank, world, torch, dist):
     box = [shared]
     dist.broadcast_object_list(box, src=0, group=host_group)
     shared = box[0]
-    # RCCL self-test (uneven all_to_all + all_reduce on device tensors); on any failure every rank
-    # falls back to moving the halos through the gloo group (same code path, slower transport)
-    dev_group = None
-    ok = 1.0
-    try:
-        tin = torch.arange(world + rank, dtype=torch.float64, device="cuda")[:world].contiguous()
-        tout = torch.empty(world, dtype=torch.float64, device="cuda")
-        dist.all_to_all_single(tout, tin, [1] * world, [1] * world)
-        tt = torch.ones(1, dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt)
-        torch.cuda.synchronize()
-        if abs(tt.item() - world) > 0:
-            ok = 0.0
-    except Exception as e:   # noqa: BLE001
-        log("[bench] rank %d: device collective self-test failed: %r" % (rank, e))
-        ok = 0.0
-    flag = torch.tensor([ok], dtype=torch.float64)
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=host_group)
-    transport = "RCCL" if dist.get_backend() == "nccl" else dist.get_backend() + " (rehearsal transport)"
-    if flag.item() < 0.5:
-        dev_group = host_group
-        transport = "gloo (RCCL self-test failed)"
     t_gen = t_setup = 0.0
+    cpu = None
     if rank == 0:
         shutil.rmtree(shared, ignore_errors=True)
         ml, (t_gen, t_setup) = build_hierarchy(args.grid, args.smoother)
@@ -125,64 +169,107 @@ def partitioned_main(args, rank, local_rank, world, torch, dist):
         t0 = time.time()
         save_levels(shared, levels, coarse)
         np.random.seed(0)
-        np.save(os.path.join(shared, "b.npy"), np.random.rand(n))
+        bfull = np.random.rand(n)
+        np.save(os.path.join(shared, "b.npy"), bfull)
         log("[bench] hierarchy shipped to %s in %.1fs" % (shared, time.time() - t0))
         shape_info = [[int(L["A"].shape[0]), int(L["A"].nnz)] for L in levels]
-        del ml, levels
+        if not args.no_cpu_baseline:
+            cpu = cpu_baseline_of(ml, bfull, None)
+        del ml, levels, bfull
     dist.barrier(group=host_group)
     levels, coarse = load_levels(shared)
     t0 = time.time()
-    S = DistributedSolver(levels, coarse, HipBackend(local_rank), rank, world, group=dev_group, host_group=host_group)
     bnd = split_rows(n, world)
     lo, hi = int(bnd[rank]), int(bnd[rank + 1])
-    b = np.load(os.path.join(shared, "b.npy"), mmap_mode="r")[lo:hi]
-    S.set_problem(np.asarray(b), None)
-    log("[bench] rank %d: rows %d..%d, halos per level %s, partition+upload %.1fs" %
-        (rank, lo, hi, [lv.n_halo for lv in S.lv], time.time() - t0))
+    b = np.ascontiguousarray(np.load(os.path.join(shared, "b.npy"), mmap_mode="r")[lo:hi])
+    # transport: the C++ engine with GPU-to-GPU pushes ("peer"), else the C++ engine on RCCL, else the Python-driven
+    # cycle on torch.distributed; a transport is taken only if EVERY rank could set it up and one cycle ran clean
+    order = [os.environ["AMG_DIST_TRANSPORT"]] if os.environ.get("AMG_DIST_TRANSPORT") else ["peer", "rccl", "python"]
+    S, transport = None, None
+    for cand in order:
+        os.environ["AMG_DIST_TRANSPORT"] = cand
+        ok = 1.0
+        try:
+            S = DistributedSolver(levels, coarse, HipBackend(local_rank), rank, world, group=host_group, host_group=host_group)
+            S.solve(b, None, tol=0.0, maxiter=1, cycle="V", fixed=True)
+        except Exception as e:   # noqa: BLE001
+            log("[bench] rank %d: transport %s failed: %r" % (rank, cand, e))
+            ok = 0.0
+        flag = torch.tensor([ok], dtype=torch.float64)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=host_group)
+        if flag.item() > 0.5:
+            transport = cand
+            break
+        if S is not None and ok > 0.5:
+            S.close()
+        S = None
+    if S is None:
+        raise SystemExit("no working inter-GPU transport")
+    log("[bench] rank %d: rows %d..%d, halos per level %s, transport %s, partition+upload %.1fs" %
+        (rank, lo, hi, [lv.n_halo for lv in S.lv], transport, time.time() - t0))
     dist.barrier(group=host_group)
     if rank == 0:
         shutil.rmtree(shared, ignore_errors=True)
 
-    # self-check of the overlapped exchange on THIS machine: one cycle with and without it must give
-    # bit-identical iterates on every rank; otherwise fall back to the plain exchange
-    lv0 = S.lv[0]
-    S.overlap = False
-    S.run_fixed(1, "V", x_zero=True)
-    xa = lv0.x[:lv0.n_own].clone()
-    S.set_problem(np.asarray(b), None)
-    S.overlap = True
-    S.run_fixed(1, "V", x_zero=True)
-    same = torch.tensor([1.0 if torch.equal(xa, lv0.x[:lv0.n_own]) else 0.0], dtype=torch.float64)
-    dist.all_reduce(same, op=dist.ReduceOp.MIN, group=host_group)
-    if same.item() < 0.5:
-        log("[bench] overlapped exchange disagreed with the plain one: disabled")
-        S.overlap = False
-    del xa
-    S.set_problem(np.asarray(b), None)
-    r0 = S.residual_norm()
-    warm = S.run_fixed(args.warmup, "V", x_zero=True)
-    torch.cuda.synchronize(); dist.barrier(group=host_group); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    timed = S.run_fixed(args.steps, "V", x_zero=False)
-    torch.cuda.synchronize(); dist.barrier(group=host_group); torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
+    def sync_all():
+        torch.cuda.synchronize(); dist.barrier(group=host_group); torch.cuda.synchronize()
+
+    # warm-up from x0 = 0, then EXACTLY K timed steps continuing from the warm iterate (vectors resident in HBM)
+    if S.native is not None:
+        from pyamg_amd import _lib
+        Lb, h, comm = S.native
+        res = np.zeros(max(args.steps, args.warmup) + 2)
+        nres = C.c_int(0)
+        NO_EARLY_STOP, DEVICE_VECTORS, X0_ZERO = 2, 4, 1
+        xw = np.zeros(hi - lo)
+        _lib.check(Lb.amg_hier_solve(h, b.ctypes.data, xw.ctypes.data, 0.0, args.warmup, 0, _lib.dp(res), C.byref(nres),
+                                     NO_EARLY_STOP | X0_ZERO))
+        warm = res[:nres.value].copy()
+        db, dx = Lb.amg_hier_dev_b(h), Lb.amg_hier_dev_x(h)
+        sync_all()
+        t0 = time.perf_counter()
+        _lib.check(Lb.amg_hier_solve(h, db, dx, 0.0, args.steps, 0, _lib.dp(res), C.byref(nres), NO_EARLY_STOP | DEVICE_VECTORS))
+        sync_all()
+        wall = time.perf_counter() - t0
+        _lib.check(Lb.amg_hier_comm_check(h))
+        timed = res[:nres.value].copy()
+        r0 = float(warm[0])
+        ms_resid = C.c_double(0.0)
+        _lib.check(Lb.amg_hier_time_spmv(h, 0, 0, 1, 20, C.byref(ms_resid)))
+        ms_resid = ms_resid.value
+        form = Lb.amg_hier_operator_form(h, 0)
+        moved = Lb.amg_hier_operator_bytes(h, 0, 1)
+        overl = "interior rows overlap the exchange" if os.environ.get("AMG_DIST_OVERLAP", "1") != "0" else "plain exchange"
+    else:
+        S.set_problem(b, None)
+        r0 = S.residual_norm()
+        warm = [r0] + S.run_fixed(args.warmup, "V", x_zero=True)
+        sync_all()
+        t0 = time.perf_counter()
+        timed = S.run_fixed(args.steps, "V", x_zero=False)
+        sync_all()
+        wall = time.perf_counter() - t0
+        lv = S.lv[0]
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        S.be.apply(lv.A, 2, lv.x, lv.b, None, lv.r, None, 0.0)
+        e0.record()
+        for _ in range(20):
+            S.be.apply(lv.A, 2, lv.x, lv.b, None, lv.r, None, 0.0)
+        e1.record(); torch.cuda.synchronize()
+        ms_resid = e0.elapsed_time(e1) / 20
+        form = S.operator_form(0)
+        moved = None
+        overl = "python driver"
     tw = torch.tensor([wall], dtype=torch.float64)
     dist.all_reduce(tw, op=dist.ReduceOp.MAX, group=host_group)
     wall = float(tw.item())
-    # level-0 A-application on this rank's slab, hipEvents on the launch stream
-    lv = S.lv[0]
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 20
-    S.be.apply(lv.A, 2, lv.x, lv.b, None, lv.r, None, 0.0)
-    e0.record()
-    for _ in range(reps):
-        S.be.apply(lv.A, 2, lv.x, lv.b, None, lv.r, None, 0.0)
-    e1.record(); torch.cuda.synchronize()
-    ms_resid = e0.elapsed_time(e1) / reps
     if rank == 0:
+        lv = S.lv[0]
         n_own = lv.n_own
         spmv_bytes = 12.0 * lv.nnzA + 4.0 * (n_own + 1) + 24.0 * n_own
-        ach = spmv_bytes / (ms_resid * 1e-3) / 1e9
+        if moved is None:
+            moved = spmv_bytes
+        ach = moved / (ms_resid * 1e-3) / 1e9
         out = {
             "metric": "V-cycle iterations/sec (3D Poisson %d^3 fp64, SA-AMG, %s smoother)" % (args.grid, args.smoother),
             "value": round(args.steps / wall, 4), "unit": "V-cycle iterations/s", "n_gpus": world,
@@ -191,23 +278,27 @@ def partitioned_main(args, rank, local_rank, world, torch, dist):
             "config": {"workload": "3D Poisson %dx%dx%d (%.1fM dof) CSR fp64, smoothed aggregation (%d levels), "
                                    "%s pre/post smoother, V(1,1), b=rand seed 0" %
                                    (args.grid, args.grid, args.grid, n / 1e6, len(S.lv), args.smoother),
-                       "parallelism": "rows of every level partitioned over %d GPUs, halo exchange + residual "
-                                      "all-reduce over %s" % (world, transport),
+                       "parallelism": "rows of every level partitioned over %d ranks on %d GPU(s); transport %s (%s); "
+                                      "one 8-byte all-reduce per residual norm" %
+                                      (world, min(world, torch.cuda.device_count()), transport, overl),
+                       "transport": transport,
                        "levels": shape_info, "halo_per_level_rank0": [lv_.n_halo for lv_ in S.lv],
                        "replicated_from_level": S.first_rep,
-                       "exchange_overlapped_levels": [int(S.overlap and lv_.overlap) for lv_ in S.lv],
                        "setup_seconds": {"matrix": round(t_gen, 1), "hierarchy": round(t_setup, 1)},
-                       "residuals": [r0, warm[-1] if warm else r0, timed[-1]]},
+                       "residuals": [r0, float(warm[-1]), float(timed[-1])]},
             "roofline": {"bound": "hbm",
-                         "kernel": {0: "csr_stream_kernel", 1: "csr_pattern_kernel", 2: "stencil_kernel"}.get(
-                             S.be.L.amg_mat_form(lv.A), "csr_stream_kernel") +
+                         "kernel": {0: "csr_stream_kernel", 1: "csr_pattern_kernel", 2: "stencil_kernel"}.get(form, "csr_stream_kernel") +
                                    " (level-0 A-application on rank 0's row block)",
                          "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
-                         "bytes_per_launch": spmv_bytes, "ms_per_launch": round(ms_resid, 4)},
-            "cpu_baseline": None,
+                         "traffic_source": "not measured in this run (PMC passes need rocprofv3 around a single rank)",
+                         "bytes_per_launch": moved, "ms_per_launch": round(ms_resid, 4),
+                         "csr_equivalent_bytes_per_launch": spmv_bytes,
+                         "csr_equivalent_GBs": round(spmv_bytes / (ms_resid * 1e-3) / 1e9, 1)},
+            "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
+    S.close()
     dist.barrier(group=host_group)
     dist.destroy_process_group()
 
@@ -227,21 +318,28 @@ def main():
     ap.add_argument("--replicas", action="store_true", help="N>1: independent replicas instead of partitioning")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args)           # before anything touches the GPU
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
     import torch
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("AMG_BENCH_BACKEND", "nccl")   # "gloo": rehearsal with ranks sharing a GPU
-        local_rank = local_rank % max(torch.cuda.device_count(), 1)
+        if torch.cuda.device_count() == 0:
+            raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+        ndev = max(torch.cuda.device_count(), 1)
+        if world > ndev:
+            log("[bench] %d ranks on %d GPU(s): ranks share devices (rehearsal)" % (world, ndev))
+        local_rank = local_rank % ndev
         torch.cuda.set_device(local_rank)
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        # the process group only carries setup metadata and barriers (host tensors); the halos and the all-reduce
+        # of the solve travel GPU-to-GPU from the C++ engine (peer arenas over xGMI, or RCCL)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
 
     import pyamg_amd
     from pyamg_amd import _lib
@@ -295,7 +393,7 @@ def main():
     ev_ms = L.amg_hier_last_solve_ms(h)
     timed_res = res[:nres.value].copy()
     if dist is not None:
-        tw = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        tw = torch.tensor([wall], dtype=torch.float64)
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
         wall = float(tw.item())
 
@@ -320,15 +418,19 @@ def main():
         # `achieved` prices the launch at the CSR bytes of SURVEY.md 8(d) (12 B per stored entry), the figure
         # the reference's csr_matvec would have to stream; `moved_GBs` prices it at what this kernel's
         # storage form actually streams -- that one is bounded by the HBM peak.
+        # `achieved` / `frac` price the launch at the bytes this kernel's storage form actually streams (DESIGN.md
+        # section 4) -- the figure bounded by the HBM peak; `csr_equivalent_GBs` prices it at the CSR bytes of
+        # SURVEY.md 8(d) (12 B per stored entry), what the reference's csr_matvec would have to stream.
+        ach_moved = moved / (ms_resid * 1e-3) / 1e9
         roofline = {"bound": "hbm",
                     "kernel": kname + " (level-0 A-application, r = b - A x)",
-                    "bytes_moved_per_launch": moved, "moved_GBs": round(moved / (ms_resid * 1e-3) / 1e9, 1),
-                    "moved_frac": round(moved / (ms_resid * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "achieved": round(ach_moved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach_moved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "bytes_per_launch": moved, "ms_per_launch": round(ms_resid, 4),
+                    "csr_equivalent_bytes_per_launch": spmv_bytes, "csr_equivalent_GBs": round(ach, 1),
+                    "csr_equivalent_frac": round(ach / HBM_PEAK_GBS, 4),
                     "plain_csr_stream_ms_per_launch": round(ms_resid_csr, 4),
                     "pattern_kernel_ms_per_launch": round(ms_resid_pat, 4),
-                    "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
-                    "bytes_per_launch": spmv_bytes, "ms_per_launch": round(ms_resid, 4),
                     "cycle_bytes": cycle_bytes,
                     "cycle_achieved_GBs": round(cycle_bytes * (args.steps / (ev_ms * 1e-3)) / 1e9, 1),
                     "cycle_bytes_moved": dev.cycle_bytes_moved("V"),
@@ -366,64 +468,31 @@ def main():
                 value_index = {"error": repr(e)}
                 L.amg_hier_value_index(h, 0, 0)
         roofline["value_index_extra"] = value_index
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-        if os.path.exists(pmc):
-            pj = json.load(open(pmc))
-            if pj.get("grid") == args.grid and pj.get("form") == form:
-                # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel (profiles/README.md);
-                # FETCH_SIZE doubled per MI355X_MICROARCH.md (calibrated on a known 1e9-byte read)
-                roofline["traffic"] = pj["traffic_bytes"]
-                roofline["traffic_source"] = pj["source"]
+        for name in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
+            pmc = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(pmc):
+                pj = json.load(open(pmc))
+                if pj.get("grid") == args.grid and pj.get("form") == form:
+                    # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel (profiles/README.md): a COMMITTED
+                    # measurement of the same launch, not taken in this run (counters need rocprofv3 around the process)
+                    roofline["traffic"] = pj["traffic_bytes"]
+                    roofline["traffic_source"] = "from_file: profiles/%s (%s)" % (name, pj["source"])
+                    break
         cpu = None
         if not args.no_cpu_baseline:
-            H = oracle_hierarchy(ml)
-            A0c = ml.levels[0].A
-            ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
-            dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
-
-            def cpu_step(threads):
-                H.lib.oracle_set_threads(threads)
-                xo = np.zeros(n)
-                t0 = time.perf_counter()
-                H.cycle(xo, b, "V")
-                # + the residual norm that closes the step (multilevel.py:461)
-                Ah = np.zeros(n)
-                H.lib.oracle_csr_matvec(n, ip(A0c.indptr), ip(A0c.indices), dp(A0c.data), dp(xo), dp(Ah))
-                rn = H.lib.oracle_norm2(dp(b - Ah), n)
-                return time.perf_counter() - t0, rn, xo
-
-            # the row-parallel loops of the oracle over the host cores this process may use (same bits
-            # for any thread count), then the scalar port
-            cores = max(1, min(len(os.sched_getaffinity(0)), 16))      # a 1-GPU box's share of host cores
-            t_par, rn_par, xo_par = cpu_step(cores)
-            t_cpu, rn, xo = cpu_step(1)
-            H.lib.oracle_set_threads(1)
-            # parity at the full size: the GPU's iterate after one cycle from x0 = 0, entry by entry
-            xg = np.zeros(n)
-            r1 = np.zeros(3); n1 = C.c_int(0)
-            _lib.check(L.amg_hier_solve(h, b.ctypes.data, xg.ctypes.data, 0.0, 1, 0, _lib.dp(r1), C.byref(n1),
-                                        NO_EARLY_STOP | X0_ZERO))
-            iterate_equal = bool(np.array_equal(xg, xo)) and bool(np.array_equal(xo, xo_par))
-            del xo_par, xg
-            log("[bench] CPU oracle: 1 step in %.2fs on 1 thread, %.2fs on %d threads, residual %.6e (GPU first step: %.6e)"
-                % (t_cpu, t_par, cores, rn, warm_res[1]))
-            first_step_agrees = bool(abs(rn - warm_res[1]) <= 1e-12 * abs(rn)) and rn_par == rn
-            log("[bench] first iterate at full size bit-identical to the oracle's: %s" % iterate_equal)
-            cpu = {"value": round(1.0 / t_par, 5), "first_step_residual_equals_gpu": first_step_agrees,
-                   "first_step_iterate_bit_identical_to_gpu": iterate_equal,
-                   "unit": "V-cycle iterations/s", "cores": cores, "kind": "port",
-                   "sample": "1 V-cycle + residual norm of the same hierarchy and RHS from x0=0 with the C oracle "
-                             "(oracle/amg_oracle.c, -O3, row-parallel OpenMP loops: SpMV, Chebyshev and vector "
-                             "updates; includes the reference's discarded second P*coarse_x per level, "
-                             "multilevel.py:548)",
-                   "seconds": round(t_par, 3),
-                   "single_thread": {"value": round(1.0 / t_cpu, 5), "seconds": round(t_cpu, 3)}}
+            def gpu_first():
+                xg = np.zeros(n)
+                r1 = np.zeros(3); n1 = C.c_int(0)
+                _lib.check(L.amg_hier_solve(h, b.ctypes.data, xg.ctypes.data, 0.0, 1, 0, _lib.dp(r1), C.byref(n1),
+                                            NO_EARLY_STOP | X0_ZERO))
+                return xg, float(r1[1])
+            cpu = cpu_baseline_of(ml, b, gpu_first)
         out = {
             "metric": "V-cycle iterations/sec (3D Poisson %d^3 fp64, SA-AMG, %s smoother)" % (args.grid, args.smoother),
             "value": round(cycles_per_s, 4), "unit": "V-cycle iterations/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * wall / args.steps, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
-            "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if not args.replicas else "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
             "config": {"workload": "3D Poisson %dx%dx%d (%.1fM dof, nnz %.1fM) CSR fp64, smoothed aggregation "
                                    "(%d levels), %s pre/post smoother, V(1,1), b=rand seed 0" %
                                    (args.grid, args.grid, args.grid, n / 1e6, A0.nnz / 1e6, len(ml.levels),

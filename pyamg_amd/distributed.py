@@ -447,9 +447,19 @@ class DistributedSolver(object):
             else:
                 handles = handle
             handles = np.ascontiguousarray(handles, dtype=np.uint8)
-            _lib.check(Lb.amg_comm_connect(comm, handles.ctypes.data))
+            err = None
+            try:
+                _lib.check(Lb.amg_comm_connect(comm, handles.ctypes.data))
+            except Exception as e:          # noqa: BLE001 -- every rank must learn about it (no rank may wait forever)
+                err = e
             if W > 1:
-                dist.barrier(group=self.host_group)          # every arena is mapped everywhere before anybody pushes
+                # doubles as the barrier "every arena is mapped everywhere before anybody pushes"
+                flag = torch.tensor([0.0 if err else 1.0], dtype=torch.float64)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.host_group)
+                if flag.item() < 0.5 and err is None:
+                    err = RuntimeError("a peer could not map the IPC arenas")
+            if err is not None:
+                raise err
         h = Lb.amg_hier_create(nl, be.device)
         if not h:
             raise _lib.AmgError(Lb.amg_last_error().decode())

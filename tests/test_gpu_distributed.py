@@ -165,3 +165,23 @@ def test_hybrid_gauss_seidel_on_gpu_matches_partition_emulation(case, rep, trans
     for _ in range(3):
         _hybrid_cycle(lib, g["levels"], g["coarse_pinv"], bounds, 0, xe, np.ascontiguousarray(g["b"]))
     assert np.array_equal(x, xe), np.abs(x - xe).max()
+
+
+def test_bench_gpus_2_runs_two_ranks(tmp_path):
+    """`python bench.py --gpus 2` starts two rank processes itself (here they share the one GPU) and the line it
+    prints is the partitioned run's: n_gpus 2, strong scaling, the C++ engine's transport, roofline and cpu_baseline."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "AMG_DIST_TRANSPORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--grid", "48", "--steps", "3",
+                        "--warmup", "2"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["steps"] == 3
+    assert line["config"]["transport"] == "peer", line["config"]["parallelism"]
+    assert line["roofline"]["frac"] > 0 and "traffic" in line["roofline"]
+    assert line["cpu_baseline"] is not None and line["cpu_baseline"]["value"] > 0
+    r = line["config"]["residuals"]
+    assert r[2] < r[1] < r[0]

@@ -160,3 +160,25 @@ def test_coarse_grid_solver_names():
     assert kind == "dense" and np.allclose(M @ A.toarray(), np.eye(2))
     kind, sm = pyamg_amd.coarse_grid_solver("gauss_seidel").device_form(A)
     assert kind == "smoother" and sm.desc["iterations"] == 10
+
+
+def test_bench_launcher_starts_n_ranks_and_fails_cleanly_without_gpu(tmp_path):
+    """`python bench.py --gpus 2` must start two rank processes itself (round 1 parsed --gpus and ignored it).
+    Without a GPU every rank refuses loudly (no CPU fallback) and the parent exits non-zero without a JSON line."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--grid", "8", "--steps", "1",
+                        "--warmup", "1", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    if pyamg_amd.device_count() == 0:
+        assert p.returncode != 0
+        assert p.stdout.strip() == ""
+        assert "rank exit codes" in p.stderr and "needs a GPU" in p.stderr
+    # a launcher that disagrees with --gpus is refused before anything else happens
+    env2 = dict(env, RANK="0", WORLD_SIZE="3", LOCAL_RANK="0")
+    q = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--grid", "8"], env=env2,
+                       capture_output=True, text=True, timeout=600)
+    assert q.returncode != 0 and "--gpus 2 but the launcher started 3" in q.stderr
