@@ -341,6 +341,9 @@ void amg_hier_keep_residual(amg_hier *h, int on);
 /* tuning knobs (speed only): 0 = scalar loads, 1 = 16-byte loads in the CSR stream kernel;
  * XCD chunk: consecutive row blocks given to one XCD (0 = round-robin dispatch order) */
 void amg_set_stream_variant(int v);
+/* 1 (default): the CSR stream kernel runs as persistent workgroups that prefetch the next row block's row pointers,
+ * entries and epilogue operands while they gather for the current one; 0: one row block per workgroup.  Same bits. */
+void amg_set_stream_pipe(int on);
 void amg_set_xcd_chunk(int c);
 /* 1 (default): operators in offset-pattern form map row blocks to XCDs periodically in the slowest
  * grid axis, so one XCD's L2 serves a row's neighbours in the planes above and below; 0: chunked */

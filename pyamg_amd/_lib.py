@@ -169,6 +169,8 @@ def lib():
     L.amg_arnoldi_free.restype = None
     L.amg_set_stream_variant.argtypes = [I]
     L.amg_set_stream_variant.restype = None
+    L.amg_set_stream_pipe.argtypes = [I]
+    L.amg_set_stream_pipe.restype = None
     L.amg_hier_use_graphs.argtypes = [V, I]
     L.amg_hier_use_graphs.restype = None
     L.amg_hier_keep_residual.argtypes = [V, I]

@@ -160,6 +160,8 @@ int stream_blocks(const StreamArgs &a);   // workgroups launch_stream will use (
 int launch_sum_sqrt(const double *partial, long np, double *scratch512, double *result_dev, hipStream_t st);   // sqrt(sum), fixed order
 int launch_axpy_scaled(double *x, const double *r, double c, long n, hipStream_t st);        // x += c*r
 void set_stream_variant(int v);
+void set_stream_pipe(int on);              // 1 (default): persistent, software-pipelined CSR stream kernel
+bool stream_pipe_enabled();
 int stream_variant();
 void set_xcd_chunk(int c);
 void set_tile_target(int t);

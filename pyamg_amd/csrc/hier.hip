@@ -2135,6 +2135,7 @@ int amg_hier_time_relax(amg_hier *h, int lvl, int which, int reps, double *ms)
 }
 
 void amg_set_stream_variant(int v) { amg::set_stream_variant(v); }
+void amg_set_stream_pipe(int on) { amg::set_stream_pipe(on); }
 void amg_set_xcd_chunk(int c) { amg::set_xcd_chunk(c); }
 void amg_set_xcd_period(int on) { amg::set_xcd_period(on); }
 void amg_set_stencil_form(int on) { amg::set_stencil_form(on); }

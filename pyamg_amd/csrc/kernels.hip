@@ -351,6 +351,253 @@ __global__ __launch_bounds__(WG) void csr_stream_kernel(StreamArgs a, int xcd_ch
 }
 
 // ---------------------------------------------------------------------------
+// csr_stream_pipe: the same row-block arithmetic as csr_stream_kernel<MODE, 1>, software-pipelined across the row
+// blocks a PERSISTENT workgroup sweeps.  The plain kernel makes three dependent memory round trips per workgroup
+// (row pointers -> entries -> gathered operands) and then a fourth for the epilogue operands; with ~5 workgroups
+// resident per CU that leaves too few bytes in flight to fill HBM (measured 0.62-0.71 of the 8 TB/s spec on the
+// irregular operators).  Here a workgroup walks blocks w, w + G, w + 2G, ... and keeps three of them in flight:
+//   block k+2 : its first / last entry positions (two scalar loads)
+//   block k+1 : its row pointers, the entries of its first tile and its epilogue operands -- requested right after
+//               block k's gathers were issued (vector loads return in issue order: the gathers come back first)
+//   block k   : gathers, products to LDS, row sums, epilogue
+// so that what a block waits for was requested one block earlier.  Rows are summed exactly as before (LDS tile,
+// strict left-to-right, separate multiply and add): results are bit-identical to csr_stream_kernel.
+// ---------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(WG) void csr_stream_pipe_kernel(StreamArgs a, int xcd_chunk, int rpb, int nb)
+{
+    using MT = ModeTraits<MODE>;
+    static_assert(!MT::gs, "Gauss-Seidel levels keep the plain kernel");
+    __shared__ double sp[TILE];
+    __shared__ int sAp[WG + 1];
+    __shared__ double sdiag[MT::jac ? WG : 1];
+    constexpr int NQ = TILE / (4 * WG);
+    constexpr bool need_b = MT::sub || MODE == SM_RESIDUAL || MODE == SM_RESIDUAL_SUMSQ || MODE == SM_POLY_FIRST ||
+                            MODE == SM_POLY_STEP || MODE == SM_POLY_LAST || MODE == SM_JACOBI;
+    constexpr bool need_v2 = MODE == SM_POLY_LAST || MODE == SM_JACOBI || MODE == SM_JACOBI_BSR1;
+    const int t = threadIdx.x;
+    const int G = gridDim.x;
+    const long nnz_total = a.nnz_total;
+    const double gscale = a.gscale;
+
+    struct Span { int r0, nr, kb, ke; };
+    auto span_of = [&](int i) -> Span {                     // uniform: scalar loads
+        Span s{0, 0, 0, 0};
+        if (i < nb) {
+            const int blk = remap_block(i, nb, xcd_chunk);
+            s.r0 = a.row_lo + blk * rpb;
+            s.nr = min(rpb, a.row_hi - s.r0);
+            s.kb = a.Ap[s.r0];
+            s.ke = a.Ap[s.r0 + s.nr];
+        }
+        return s;
+    };
+    struct Pre {
+        int rp;                       // Ap[r0 + t]
+        v4i cj[NQ];
+        v2d av[NQ][2];
+        double b, v2;
+    };
+    auto prefetch = [&](const Span &s, Pre &p) {
+        p.rp = (t <= s.nr && s.nr > 0) ? a.Ap[s.r0 + t] : s.ke;      // rpb <= 256: thread nr holds the end pointer when nr < 256
+        const int tile_lo = s.kb & ~3;
+        const int tile_hi = min(tile_lo + TILE, s.ke);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int e = tile_lo + q * (4 * WG) + 4 * t;
+            p.cj[q] = v4i{0, 0, 0, 0};
+            p.av[q][0] = v2d{0.0, 0.0};
+            p.av[q][1] = v2d{0.0, 0.0};
+            if (e < tile_hi) {
+                if ((long)e + 4 <= nnz_total) {
+                    p.cj[q] = load_v4i(a.Aj + e);
+                    p.av[q][0] = load_v2d(a.Ax + e);
+                    p.av[q][1] = load_v2d(a.Ax + e + 2);
+                } else {
+                    int c[4]; double v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const bool ok = (long)e + u < nnz_total;
+                        c[u] = ok ? a.Aj[e + u] : 0;
+                        v[u] = ok ? a.Ax[e + u] : 0.0;
+                    }
+                    p.cj[q] = v4i{c[0], c[1], c[2], c[3]};
+                    p.av[q][0] = v2d{v[0], v[1]};
+                    p.av[q][1] = v2d{v[2], v[3]};
+                }
+            }
+        }
+        p.b = 0.0; p.v2 = 0.0;
+        if (t < s.nr) {
+            if (need_b) p.b = a.b[s.r0 + t];
+            if (need_v2) p.v2 = a.v2[s.r0 + t];
+            if (MODE == SM_MATVEC_ACC) p.v2 = a.out[s.r0 + t];
+        }
+    };
+
+    Span cur = span_of(blockIdx.x), nxt = span_of(blockIdx.x + G);
+    Pre pc, pn;
+    prefetch(cur, pc);
+    for (int i = blockIdx.x; i < nb; i += G) {
+        const Span aft = span_of(i + 2 * G);
+        const int r0 = cur.r0, nr = cur.nr, kbeg = cur.kb, kend = cur.ke;
+        // row pointers of this block from registers to LDS (entry 256 of a full block is the end pointer)
+        if (t <= nr) sAp[t] = pc.rp;
+        if (t == 0) sAp[nr] = kend;
+        if (MT::jac) sdiag[t] = 0.0;
+        __syncthreads();
+        const int my_s = (t < nr) ? sAp[t] : kend;
+        const int my_e = (t < nr) ? sAp[t + 1] : kend;
+        double acc = MT::sub ? pc.b : 0.0;
+        if (t >= nr) acc = 0.0;
+        const int abeg = kbeg & ~3;
+        bool first = true;
+        for (int tile_lo = abeg; tile_lo < kend; tile_lo += TILE) {
+            const int tile_hi = min(tile_lo + TILE, kend);
+            int e[NQ];
+            bool any[NQ];
+            v4i cj[NQ];
+            v2d av[NQ][2];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                e[q] = tile_lo + q * (4 * WG) + 4 * t;
+                any[q] = e[q] < tile_hi;
+            }
+            if (first) {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) { cj[q] = pc.cj[q]; av[q][0] = pc.av[q][0]; av[q][1] = pc.av[q][1]; }
+            } else {
+                // rows longer than one tile: the following tiles are loaded in place (not prefetched)
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    cj[q] = v4i{0, 0, 0, 0}; av[q][0] = v2d{0.0, 0.0}; av[q][1] = v2d{0.0, 0.0};
+                    if (any[q]) {
+                        if ((long)e[q] + 4 <= nnz_total) {
+                            cj[q] = load_v4i(a.Aj + e[q]);
+                            av[q][0] = load_v2d(a.Ax + e[q]);
+                            av[q][1] = load_v2d(a.Ax + e[q] + 2);
+                        } else {
+                            int c[4]; double v[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const bool ok = (long)e[q] + u < nnz_total;
+                                c[u] = ok ? a.Aj[e[q] + u] : 0;
+                                v[u] = ok ? a.Ax[e[q] + u] : 0.0;
+                            }
+                            cj[q] = v4i{c[0], c[1], c[2], c[3]};
+                            av[q][0] = v2d{v[0], v[1]};
+                            av[q][1] = v2d{v[2], v[3]};
+                        }
+                    }
+                }
+            }
+            // 1. this tile's operands
+            double xv[NQ][4];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int c[4] = {cj[q].x, cj[q].y, cj[q].z, cj[q].w};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) xv[q][u] = any[q] ? a.xg[c[u]] : 0.0;
+            }
+            // 2. the NEXT block's row pointers, first tile and epilogue operands (independent of everything above)
+            if (first) prefetch(nxt, pn);
+            // 3. products into the LDS tile
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                if (!any[q]) continue;
+                const int c[4] = {cj[q].x, cj[q].y, cj[q].z, cj[q].w};
+                const double v[4] = {av[q][0].x, av[q][0].y, av[q][1].x, av[q][1].y};
+                double pr[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    pr[u] = v[u] * (gscale * xv[q][u]);
+                    if (MT::jac) {
+                        const int k = e[q] + u;
+                        const int lc = c[u] - r0;
+                        if ((unsigned)lc < (unsigned)nr && k >= sAp[lc] && k < sAp[lc + 1]) {
+                            sdiag[lc] = v[u];
+                            pr[u] = 0.0;
+                        }
+                    }
+                }
+                const int qq = e[q] - tile_lo;
+                *reinterpret_cast<double2 *>(&sp[qq]) = make_double2(pr[0], pr[1]);
+                *reinterpret_cast<double2 *>(&sp[qq + 2]) = make_double2(pr[2], pr[3]);
+            }
+            __syncthreads();
+            {
+                const int s = max(my_s, tile_lo), e2 = min(my_e, tile_hi);
+                for (int k = s; k < e2; ++k) {
+                    const double p = sp[k - tile_lo];
+                    acc = MT::sub ? (acc - p) : (acc + p);
+                }
+            }
+            __syncthreads();
+            first = false;
+        }
+        if (kend <= abeg) prefetch(nxt, pn);       // an empty block issued no tile: still feed the pipeline
+
+        // epilogue (operands were requested one block ago)
+        if (MODE == SM_RESIDUAL_SUMSQ) {
+            double sq = 0.0;
+            if (t < nr) {
+                const double rr = pc.b - acc;
+                sq = rr * rr;
+                if (a.out) store_out(&a.out[r0 + t], rr);
+            }
+            const double tot = block_reduce_sum(sq, sp);
+            if (t == 0) a.out2[remap_block(i, nb, xcd_chunk)] = tot;
+            __syncthreads();
+        } else if (t < nr) {
+            const int row = r0 + t;
+            if (MODE == SM_MATVEC) {
+                store_out(&a.out[row], acc);
+            } else if (MODE == SM_MATVEC_ACC) {
+                store_out(&a.out[row], pc.v2 + acc);
+            } else if (MODE == SM_RESIDUAL) {
+                store_out(&a.out[row], pc.b - acc);
+            } else if (MODE == SM_POLY_FIRST) {
+                const double r = pc.b - acc;
+                a.out[row] = r;
+                a.out2[row] = a.c0 * r;
+            } else if (MODE == SM_POLY_STEP) {
+                const double cr = a.c0 * pc.b;
+                a.out[row] = cr + acc;
+            } else if (MODE == SM_POLY_LAST) {
+                const double cr = a.c0 * pc.b;
+                const double h = cr + acc;
+                store_out(&a.out[row], pc.v2 + h);
+            } else if (MODE == SM_JACOBI) {
+                const double d = sdiag[t];
+                if (d != 0.0) {
+                    const double q = (pc.b - acc) / d;
+                    const double t1 = (1.0 - a.c0) * pc.v2;
+                    const double t2 = a.c0 * q;
+                    a.out[row] = t1 + t2;
+                } else {
+                    a.out[row] = pc.v2;
+                }
+            } else if (MODE == SM_JACOBI_BSR1) {
+                const double d = sdiag[t];
+                if (d != 0.0) {
+                    const double t1 = (1.0 - a.c0) * pc.v2;
+                    const double t2 = (a.c0 * acc) / d;
+                    a.out[row] = t1 + t2;
+                } else {
+                    a.out[row] = pc.v2;
+                }
+            }
+        }
+        if (MT::jac) __syncthreads();               // sdiag is rewritten by the next block
+        cur = nxt; nxt = aft; pc = pn;
+    }
+}
+
+static int g_stream_pipe = 1;
+void set_stream_pipe(int on) { g_stream_pipe = on; ++g_config_epoch; }
+bool stream_pipe_enabled() { return g_stream_pipe != 0; }
+
+// ---------------------------------------------------------------------------
 // Chained Gauss-Seidel sweep over a run of NARROW dependency levels (each at most CHAIN_WG rows): one
 // workgroup, one launch.  Thread t owns row t of the current level; a barrier separates the levels.
 // What makes a level cheap here is that everything that does not depend on x -- the row's entries, its
@@ -1127,6 +1374,30 @@ static int launch_stream_mode(const StreamArgs &a, hipStream_t st)
     StreamArgs b = a;
     if (b.gscale == 0.0) b.gscale = 1.0;
     if (!g_index16 || (a.row_lo % rpb) != 0) b.Aj16 = nullptr;     // row blocks must be the coded ones
+    if constexpr (!ModeTraits<MODE>::gs) {
+        if (g_stream_pipe && g_stream_variant && !b.Aj16) {
+            // persistent grid: as many workgroups as the chip holds at once (a multiple of the 8 XCDs)
+            static int per_cu = 0;
+            if (per_cu == 0) {
+                int nbk = 0;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbk, csr_stream_pipe_kernel<MODE>, WG, 0) != hipSuccess || nbk < 1) nbk = 4;
+                per_cu = nbk;
+            }
+            static int ncu = 0;
+            if (ncu == 0) {
+                int dev = 0; hipDeviceProp_t pr;
+                if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount;
+                if (ncu < 8) ncu = 256;
+            }
+            int G = per_cu * ncu;
+            G -= G % 8;
+            if (G > nb) G = nb;
+            hipLaunchKernelGGL((csr_stream_pipe_kernel<MODE>), dim3(G), dim3(WG), 0, st, b, g_xcd_chunk, rpb, nb);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return hip_fail(e, "csr_stream_pipe launch", __FILE__, __LINE__);
+            return 0;
+        }
+    }
     if (g_stream_variant)
         hipLaunchKernelGGL((csr_stream_kernel<MODE, 1>), dim3(nb), dim3(WG), 0, st, b, g_xcd_chunk, rpb);
     else
