@@ -36,9 +36,18 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def build_hierarchy(grid, smoother):
+def build_hierarchy(grid, smoother, cache=None):
     import pyamg_amd
     from pyamg_amd.aggregation import poisson, smoothed_aggregation_solver
+    cdir = os.path.join(cache, "poisson%d_%s" % (grid, smoother)) if cache else None
+    if cdir and os.path.exists(os.path.join(cdir, "meta.json")):
+        # --cache DIR: the hierarchy of an earlier run (multilevel_solver.save), memory-mapped -- same operators in
+        # the same stored order, same smoother constants, hence the same iterates
+        t0 = time.time()
+        ml = pyamg_amd.multilevel_solver.load(cdir, mmap=True)
+        log("[bench] hierarchy loaded from %s in %.1fs" % (cdir, time.time() - t0))
+        log(repr(ml))
+        return ml, (0.0, time.time() - t0)
     t0 = time.time()
     A = poisson((grid, grid, grid))
     t1 = time.time()
@@ -55,6 +64,10 @@ def build_hierarchy(grid, smoother):
     t2 = time.time()
     log("[bench] poisson %.1fs, SA setup %.1fs" % (t1 - t0, t2 - t1))
     log(repr(ml))
+    if cdir:
+        t3 = time.time()
+        ml.save(cdir)
+        log("[bench] hierarchy saved to %s in %.1fs" % (cdir, time.time() - t3))
     return ml, (t1 - t0, t2 - t1)
 
 
@@ -164,7 +177,7 @@ def partitioned_main(args, rank, local_rank, world, torch, dist):
     cpu = None
     if rank == 0:
         shutil.rmtree(shared, ignore_errors=True)
-        ml, (t_gen, t_setup) = build_hierarchy(args.grid, args.smoother)
+        ml, (t_gen, t_setup) = build_hierarchy(args.grid, args.smoother, args.cache)
         levels, coarse = levels_from_ml(ml)
         t0 = time.time()
         save_levels(shared, levels, coarse)
@@ -316,6 +329,7 @@ def main():
     ap.add_argument("--xcd-chunk", type=int, default=None)
     ap.add_argument("--tile-target", type=int, default=None)
     ap.add_argument("--replicas", action="store_true", help="N>1: independent replicas instead of partitioning")
+    ap.add_argument("--cache", default=None, help="directory of saved hierarchies: skip the setup on reruns")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
@@ -356,7 +370,7 @@ def main():
     if world > 1 and not args.replicas:
         return partitioned_main(args, rank, local_rank, world, torch, dist)
 
-    ml, (t_gen, t_setup) = build_hierarchy(args.grid, args.smoother)
+    ml, (t_gen, t_setup) = build_hierarchy(args.grid, args.smoother, args.cache)
     ml.device = local_rank
     n = ml.levels[0].A.shape[0]
     t0 = time.time()

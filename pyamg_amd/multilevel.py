@@ -316,6 +316,18 @@ class multilevel_solver:
         sizes = [level.A.shape[0] for level in self.levels]
         return sum(sizes) / float(sizes[0])
 
+    # ------------------------------------------------------------------ on-disk format
+    def save(self, path):
+        """Write the hierarchy (operators in stored order, smoother constants, the dense coarse operator) to the
+        directory `path`; `multilevel_solver.load(path)` gives a solver with bit-identical iterates."""
+        from .hierarchy_io import save_hierarchy
+        return save_hierarchy(self, path)
+
+    @staticmethod
+    def load(path, mmap=False, device=0):
+        from .hierarchy_io import load_hierarchy
+        return load_hierarchy(path, mmap=mmap, device=device)
+
     # ------------------------------------------------------------------ device mirror
     def _invalidate_device(self):
         if self._dev is not None:
@@ -522,4 +534,4 @@ class _CoarseSolver(object):
         return "coarse_grid_solver(" + repr(self.solver) + ")"
 
     def name(self):
-        return repr(self.solver)
+        return repr(getattr(self, "solver_name", None) or self.solver)

@@ -290,3 +290,51 @@ def setup_None(lvl):
     def smoother(A, x, b):
         pass
     return _with_desc(smoother, name=None)
+
+
+# --------------------------------------------------------------------------- descriptors back to smoothers
+def spec_from_descriptor(desc):
+    """The ('name', {options}) pair that re-creates a smoother from its descriptor (`fn.desc`) with every constant
+    passed explicitly -- nothing is re-estimated (omega already carries its 1/rho, coefficients are final)."""
+    if desc is None or desc.get("name") in (None, "None"):
+        return None, {}
+    name = desc["name"]
+    it = int(desc.get("iterations", 1))
+    sweep = desc.get("sweep", "forward")
+    if name == "jacobi":
+        return name, {"iterations": it, "omega": desc["omega"], "withrho": False}
+    if name == "gauss_seidel":
+        return name, {"iterations": it, "sweep": sweep}
+    if name == "sor":
+        return name, {"iterations": it, "omega": desc["omega"], "sweep": sweep}
+    if name == "polynomial":
+        return name, {"iterations": it, "coefficients": np.asarray(desc["coefficients"], dtype=float)}
+    if name in ("block_jacobi", "block_gauss_seidel"):
+        bs = int(desc["blocksize"])
+        kw = {"iterations": it, "blocksize": bs, "Dinv": np.asarray(desc["Dinv"], dtype=float).reshape(-1, bs, bs)}
+        if name == "block_jacobi":
+            kw.update(omega=desc["omega"], withrho=False)
+        else:
+            kw["sweep"] = sweep
+        return name, kw
+    if name == "gauss_seidel_indexed":
+        return name, {"iterations": it, "sweep": sweep, "indices": np.asarray(desc["indices"], dtype=np.intc)}
+    if name in ("gauss_seidel_ne", "gauss_seidel_nr"):
+        return name, {"iterations": it, "sweep": sweep, "omega": desc.get("omega", 1.0)}
+    if name == "jacobi_ne":
+        return name, {"iterations": it, "omega": desc["omega"], "withrho": False}
+    if name == "schwarz":
+        return name, {"iterations": it, "sweep": desc.get("sweep", "symmetric"),
+                      "subdomain": np.asarray(desc["subdomain"], dtype=np.intc),
+                      "subdomain_ptr": np.asarray(desc["subdomain_ptr"], dtype=np.intc),
+                      "inv_subblock": np.asarray(desc["inv_subblock"], dtype=float),
+                      "inv_subblock_ptr": np.asarray(desc["inv_subblock_ptr"], dtype=np.intc)}
+    raise KeyError("no smoother named %r" % (name,))
+
+
+def smoother_from_descriptor(lvl, desc):
+    """the level smoother a descriptor describes (setup_* closure with .desc), or the no-op smoother"""
+    name, kw = spec_from_descriptor(desc)
+    if name is None:
+        return setup_None(lvl)
+    return globals()["setup_" + name](lvl, **kw)

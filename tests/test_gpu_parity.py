@@ -1130,3 +1130,18 @@ def test_config5_relaxation_shims_on_tet_mesh_vs_oracle(oracle):
         oracle.oracle_bsr_jacobi(oracle_lib.ip(Ap), oracle_lib.ip(Aj), oracle_lib.dp(Ax), oracle_lib.dp(xo),
                                  oracle_lib.dp(b), oracle_lib.dp(np.zeros(n)), rs, re, rt, 3, oracle_lib.dp(om))
         assert np.array_equal(x, xo), ("bsr_jacobi", rs, re, rt)
+
+
+@pytest.mark.parametrize("case", ["sa_cheb2_3d", "c5_elas_p1_cube_bgs", "sa_schwarz_2d", "rs_gs_2d"])
+def test_saved_hierarchy_reloads_to_bit_identical_iterates(case, tmp_path):
+    """multilevel_solver.save -> load (memory-mapped) -> solve gives the same iterates and history as
+    the hierarchy that was saved: operators keep their stored order, smoother constants are not re-estimated."""
+    g = golden_io.load_hier(case)
+    ml = golden_io.build_ml(g)
+    res = []
+    x = ml.solve(g["b"], x0=(g["x0"] if np.any(g["x0"]) else None), tol=0.0, maxiter=4, residuals=res)
+    ml.save(str(tmp_path / "h"))
+    back = pyamg_amd.multilevel_solver.load(str(tmp_path / "h"), mmap=True)
+    res2 = []
+    x2 = back.solve(g["b"], x0=(g["x0"] if np.any(g["x0"]) else None), tol=0.0, maxiter=4, residuals=res2)
+    assert np.array_equal(x, x2) and np.array_equal(res, res2)

@@ -182,3 +182,53 @@ def test_bench_launcher_starts_n_ranks_and_fails_cleanly_without_gpu(tmp_path):
     q = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--grid", "8"], env=env2,
                        capture_output=True, text=True, timeout=600)
     assert q.returncode != 0 and "--gpus 2 but the launcher started 3" in q.stderr
+
+
+def _tiny_hierarchies():
+    """hierarchies that exercise every stored piece: CSR + BSR(1,1) levels with Chebyshev constants, a BSR(3,3) one with
+    inverse diagonal blocks, indexed Gauss-Seidel, Schwarz subdomains"""
+    from pyamg_amd.aggregation import poisson, smoothed_aggregation_solver
+    from pyamg_amd.gallery import tet_diffusion
+    np.random.seed(0)
+    yield smoothed_aggregation_solver(poisson((12, 11)), presmoother=("chebyshev", {"degree": 2}),
+                                      postsmoother=("jacobi", {"omega": 4.0 / 3.0, "iterations": 2}), max_coarse=10)
+    bgs = ("block_gauss_seidel", {"sweep": "symmetric", "blocksize": 3})
+    yield smoothed_aggregation_solver(tet_diffusion(6, blocksize=3), presmoother=bgs,
+                                      postsmoother=("block_jacobi", {"blocksize": 3}), max_coarse=5)
+    yield smoothed_aggregation_solver(poisson((9, 9)), presmoother=("multicolor_gauss_seidel", {"sweep": "symmetric"}),
+                                      postsmoother=("schwarz", {"sweep": "forward"}), max_coarse=8,
+                                      coarse_solver=("gauss_seidel", {"iterations": 4}))
+
+
+def test_hierarchy_save_load_round_trip(tmp_path):
+    """multilevel_solver.save / load keep operators (format, block shape, STORED order), smoother
+    descriptors with their constants, and the coarse solver"""
+    for k, ml in enumerate(_tiny_hierarchies()):
+        d = str(tmp_path / ("h%d" % k))
+        ml.save(d)
+        back = pyamg_amd.multilevel_solver.load(d, mmap=(k == 0))
+        assert len(back.levels) == len(ml.levels)
+        assert repr(back) == repr(ml)
+        for a, b in zip(ml.levels, back.levels):
+            for nm in ("A", "P", "R"):
+                if hasattr(a, nm):
+                    X, Y = getattr(a, nm), getattr(b, nm)
+                    assert X.format == Y.format and X.shape == Y.shape
+                    assert getattr(X, "blocksize", None) == getattr(Y, "blocksize", None)
+                    assert np.array_equal(X.indptr, Y.indptr) and np.array_equal(X.indices, Y.indices)
+                    assert np.array_equal(X.data, Y.data)
+            for nm in ("presmoother", "postsmoother"):
+                if hasattr(a, nm):
+                    da, db = getattr(a, nm).desc, getattr(b, nm).desc
+                    assert set(k_ for k_ in da if not k_.startswith("_")) == set(db)
+                    for key, v in da.items():
+                        if key.startswith("_"):
+                            continue
+                        assert np.array_equal(np.asarray(v), np.asarray(db[key])), (nm, key)
+        ka, pa = ml.coarse_solver.device_form(ml.levels[-1].A)
+        kb, pb = back.coarse_solver.device_form(back.levels[-1].A)
+        assert ka == kb
+        if ka == "dense":
+            assert np.array_equal(pa, pb)
+        else:
+            assert pa.desc["name"] == pb.desc["name"] and pa.desc["iterations"] == pb.desc["iterations"]
