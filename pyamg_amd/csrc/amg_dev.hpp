@@ -147,8 +147,18 @@ int config_epoch();                      // bumped by every set_* knob below
 // one launch (barrier between levels, next level's rows prefetched) instead of a launch per level
 int launch_gs_chain(const DevCsr &G, const int *rowmap, const int *diagpos, const int *level_ptr_dev, int l_first,
                     int nlevels, bool reverse, bool bsr1, double *x, const double *b, hipStream_t st);
+// second generation of the chained sweep: operands produced by the last CHAIN2_D levels travel through LDS, everything
+// else (entries, diagonal, right-hand side, older operands) is prefetched CHAIN2_D levels ahead from the padded copy
+constexpr int CHAIN2_WG = 512;      // rows per level at most
+constexpr int CHAIN2_PF = 10;       // off-diagonal entries per row at most
+constexpr int CHAIN2_D = 2;         // prefetch distance in levels = levels whose results are passed through LDS
+constexpr int CHAIN2_LMAX = 4096;   // levels per launch
+constexpr int CHAIN2_EMPTY = -2147483647 - 1;
+int launch_gs_chain2(const int *row, const double *diag, const double *val, const int *code, const int *off, int l_first,
+                     int nlevels, bool reverse, bool bsr1, double *x, const double *b, hipStream_t st);
 int gs_chain_max_rows();
 bool gs_chain_enabled();
+int gs_chain_generation();
 void set_gs_chain(int on);
 bool stencil_enabled();
 int launch_index16_build(DevCsr &M, int rpb, hipStream_t st);   // fills Aj16 / wg_base / wg_flag (already allocated)

@@ -345,6 +345,11 @@ void Schedule::release()
     if (level_ptr_dev) hipFree(level_ptr_dev);
     free_bsr(Gb);
     rowmap = diagpos = rows = level_ptr_dev = nullptr;
+    for (int *p : {c2_row, c2_code_f, c2_code_b, c2_off}) if (p) hipFree(p);
+    for (double *p : {c2_diag, c2_val}) if (p) hipFree(p);
+    c2_row = c2_code_f = c2_code_b = c2_off = nullptr;
+    c2_diag = c2_val = nullptr;
+    chain2 = false;
     chains.clear();
 }
 
@@ -433,8 +438,68 @@ int build_csr_schedule(const int *Ap, const int *Aj, const double *Ax, int n, co
         if (S.level_ptr[l + 1] - S.level_ptr[l] > max_rows) { ++l; continue; }
         int e = l;
         while (e < nl && S.level_ptr[e + 1] - S.level_ptr[e] <= max_rows) ++e;
-        if (e - l >= 4) S.chains.emplace_back(l, e);
+        if (e - l >= 4)
+            for (int p = l; p < e; p += CHAIN2_LMAX) S.chains.emplace_back(p, std::min(e, p + CHAIN2_LMAX));   // one launch each
         l = e;
+    }
+    // ---- the chained sweep's padded copy (Schedule::c2_*, gs_chain2_kernel)
+    S.chain2 = false;
+    if (!S.chains.empty() && max_rows <= CHAIN2_WG) {
+        std::vector<int> lvl_of((size_t)n, -1), pos_of((size_t)n, -1), piece_of((size_t)nl, -1);
+        bool ok = true;
+        for (int l = 0; l < nl && ok; ++l)
+            for (int k = S.level_ptr[l]; k < S.level_ptr[l + 1]; ++k) {
+                const int i = rowmap[(size_t)k];
+                if (lvl_of[(size_t)i] >= 0) { ok = false; break; }          // a row listed twice: keep the first-generation chain
+                lvl_of[(size_t)i] = l; pos_of[(size_t)i] = k - S.level_ptr[l];
+            }
+        for (size_t c = 0; c < S.chains.size(); ++c)
+            for (int l = S.chains[c].first; l < S.chains[c].second; ++l) piece_of[(size_t)l] = (int)c;
+        std::vector<int> coff((size_t)nl + 1, 0);
+        for (int l = 0; l < nl; ++l) coff[(size_t)l + 1] = coff[(size_t)l] + (piece_of[(size_t)l] >= 0 ? S.level_ptr[l + 1] - S.level_ptr[l] : 0);
+        const long total = coff[(size_t)nl];
+        std::vector<int> crow((size_t)total), cf((size_t)total * CHAIN2_PF, CHAIN2_EMPTY), cb((size_t)total * CHAIN2_PF, CHAIN2_EMPTY);
+        std::vector<double> cd((size_t)total, 0.0), cv((size_t)total * CHAIN2_PF, 0.0);
+        for (int l = 0; l < nl && ok; ++l) {
+            if (piece_of[(size_t)l] < 0) continue;
+            const int base = coff[(size_t)l], cnt = S.level_ptr[l + 1] - S.level_ptr[l];
+            for (int tt = 0; tt < cnt && ok; ++tt) {
+                const int k = S.level_ptr[l] + tt, i = rowmap[(size_t)k];
+                crow[(size_t)base + tt] = i;
+                cd[(size_t)base + tt] = dpos[(size_t)k] >= 0 ? gx[(size_t)dpos[(size_t)k]] : 0.0;
+                int u = 0;
+                for (int q = gp[(size_t)k]; q < gp[(size_t)k + 1]; ++q) {
+                    const int c = gj[(size_t)q];
+                    if (c == i) continue;                                   // the diagonal is not part of the sum
+                    if (u >= CHAIN2_PF) { ok = false; break; }
+                    const size_t at = (size_t)CHAIN2_PF * base + (size_t)u * cnt + tt;
+                    cv[at] = gx[(size_t)q];
+                    int f = c, bk = c;                                       // default: settled in memory, read by column
+                    if (c >= 0 && c < n && lvl_of[(size_t)c] >= 0 && piece_of[(size_t)lvl_of[(size_t)c]] == piece_of[(size_t)l]) {
+                        const int dl = l - lvl_of[(size_t)c];                // > 0: produced earlier in a forward sweep
+                        if (dl >= 1 && dl <= CHAIN2_D) f = -1 - (dl * 1024 + pos_of[(size_t)c]);
+                        if (-dl >= 1 && -dl <= CHAIN2_D) bk = -1 - ((-dl) * 1024 + pos_of[(size_t)c]);
+                    }
+                    cf[at] = f; cb[at] = bk;
+                    ++u;
+                }
+            }
+        }
+        if (ok && total > 0) {
+            CHK(dev_alloc(&S.c2_row, total, (long *)nullptr));
+            CHK(dev_alloc(&S.c2_diag, total, (long *)nullptr));
+            CHK(dev_alloc(&S.c2_val, total * CHAIN2_PF, (long *)nullptr));
+            CHK(dev_alloc(&S.c2_code_f, total * CHAIN2_PF, (long *)nullptr));
+            CHK(dev_alloc(&S.c2_code_b, total * CHAIN2_PF, (long *)nullptr));
+            CHK(dev_alloc(&S.c2_off, nl + 1, (long *)nullptr));
+            AMG_HIP(hipMemcpy(S.c2_row, crow.data(), sizeof(int) * crow.size(), hipMemcpyHostToDevice));
+            AMG_HIP(hipMemcpy(S.c2_diag, cd.data(), sizeof(double) * cd.size(), hipMemcpyHostToDevice));
+            AMG_HIP(hipMemcpy(S.c2_val, cv.data(), sizeof(double) * cv.size(), hipMemcpyHostToDevice));
+            AMG_HIP(hipMemcpy(S.c2_code_f, cf.data(), sizeof(int) * cf.size(), hipMemcpyHostToDevice));
+            AMG_HIP(hipMemcpy(S.c2_code_b, cb.data(), sizeof(int) * cb.size(), hipMemcpyHostToDevice));
+            AMG_HIP(hipMemcpy(S.c2_off, coff.data(), sizeof(int) * coff.size(), hipMemcpyHostToDevice));
+            S.chain2 = true;
+        }
     }
     return 0;
 }
@@ -560,7 +625,11 @@ int gs_sweep_csr(const Schedule &S, bool bsr1, double *x, const double *b, bool 
         const auto &ch = S.chains[(size_t)(reverse ? nc - 1 - c : c)];
         if (!reverse) { CHK(launches(pos, ch.first)); pos = ch.second; }
         else { CHK(launches(ch.second, pos)); pos = ch.first; }
-        CHK(launch_gs_chain(S.G, S.rowmap, S.diagpos, S.level_ptr_dev, ch.first, ch.second - ch.first, reverse, bsr1, x, b, st));
+        if (S.chain2 && gs_chain_enabled() && gs_chain_generation() == 2)
+            CHK(launch_gs_chain2(S.c2_row, S.c2_diag, S.c2_val, reverse ? S.c2_code_b : S.c2_code_f, S.c2_off, ch.first,
+                                 ch.second - ch.first, reverse, bsr1, x, b, st));
+        else
+            CHK(launch_gs_chain(S.G, S.rowmap, S.diagpos, S.level_ptr_dev, ch.first, ch.second - ch.first, reverse, bsr1, x, b, st));
     }
     if (!reverse) CHK(launches(pos, nl));
     else CHK(launches(0, pos));

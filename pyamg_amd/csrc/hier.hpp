@@ -26,6 +26,14 @@ struct Schedule {
     // maximal runs [first, last) of consecutive levels that are all narrow enough for ONE workgroup:
     // such a run is swept by a single launch (gs_chain_kernel) instead of one launch per level
     std::vector<std::pair<int, int>> chains;
+    // The chained sweep's own copy of those runs (gs_chain2_kernel, kernels.hip): per level the rows' off-diagonal
+    // entries padded to CHAIN2_PF slots and stored slot-major (coalesced, no row pointer), the diagonal and the row
+    // id per row, and for every entry an operand CODE per sweep direction: >= 0 the global column (the operand is
+    // final in memory long before it is needed and is prefetched), < 0 a slot of the workgroup's LDS ring (the
+    // operand was produced by one of the last CHAIN2_D levels of this very launch).
+    bool chain2 = false;
+    int *c2_row = nullptr, *c2_code_f = nullptr, *c2_code_b = nullptr, *c2_off = nullptr;
+    double *c2_diag = nullptr, *c2_val = nullptr;
     // BSR flavour: block rows listed in level order
     int *rows = nullptr;          // device
     DevBsr Gb;                    // BSR flavour with values: block rows copied in level order (streamed)

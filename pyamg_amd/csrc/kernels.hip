@@ -169,6 +169,17 @@ __global__ __launch_bounds__(WG) void csr_stream_kernel(StreamArgs a, int xcd_ch
         if (!MT::sub) gs_b = a.b[row];
     }
 
+    // the epilogue's streamed operands do not depend on the row sums: request them now, so that their latency
+    // overlaps the matrix stream instead of following it (one dependent round trip less per workgroup)
+    double ep_b = 0.0, ep_v2 = 0.0;
+    if (!MT::gs && t < nr) {
+        if (MODE == SM_RESIDUAL || MODE == SM_RESIDUAL_SUMSQ || MODE == SM_POLY_FIRST || MODE == SM_POLY_STEP ||
+            MODE == SM_POLY_LAST || MODE == SM_JACOBI)
+            ep_b = a.b[r0 + t];
+        if (MODE == SM_POLY_LAST || MODE == SM_JACOBI || MODE == SM_JACOBI_BSR1) ep_v2 = a.v2[r0 + t];
+        if (MODE == SM_MATVEC_ACC) ep_v2 = a.out[r0 + t];
+    }
+
     // tile origin aligned to 4 entries so that 16-byte loads are aligned
     const int abeg = VEC ? (kbeg & ~3) : kbeg;
 
@@ -294,7 +305,7 @@ __global__ __launch_bounds__(WG) void csr_stream_kernel(StreamArgs a, int xcd_ch
         // per-workgroup partial of ||b - A x||^2 (fixed order: lanes by shuffle tree, waves in order)
         double sq = 0.0;
         if (t < nr) {
-            double rr = a.b[r0 + t] - acc;
+            double rr = ep_b - acc;
             sq = rr * rr;
             if (a.out) store_out(&a.out[r0 + t], rr);     // kept for the next pre-smoother (hier.hip)
         }
@@ -308,25 +319,25 @@ __global__ __launch_bounds__(WG) void csr_stream_kernel(StreamArgs a, int xcd_ch
     if (MODE == SM_MATVEC) {
         store_out(&a.out[i], acc);
     } else if (MODE == SM_MATVEC_ACC) {
-        store_out(&a.out[i], a.out[i] + acc);
+        store_out(&a.out[i], ep_v2 + acc);
     } else if (MODE == SM_RESIDUAL) {
-        store_out(&a.out[i], a.b[i] - acc);
+        store_out(&a.out[i], ep_b - acc);
     } else if (MODE == SM_POLY_FIRST) {
-        double r = a.b[i] - acc;
+        double r = ep_b - acc;
         a.out[i] = r;
         a.out2[i] = a.c0 * r;
     } else if (MODE == SM_POLY_STEP) {
-        double cr = a.c0 * a.b[i];
+        double cr = a.c0 * ep_b;
         a.out[i] = cr + acc;
     } else if (MODE == SM_POLY_LAST) {
-        double cr = a.c0 * a.b[i];
+        double cr = a.c0 * ep_b;
         double h = cr + acc;
-        store_out(&a.out[i], a.v2[i] + h);
+        store_out(&a.out[i], ep_v2 + h);
     } else if (MODE == SM_JACOBI) {
         double d = sdiag[t];
-        double told = a.v2[i];
+        double told = ep_v2;
         if (d != 0.0) {
-            double q = (a.b[i] - acc) / d;
+            double q = (ep_b - acc) / d;
             double t1 = (1.0 - a.c0) * told;
             double t2 = a.c0 * q;
             a.out[i] = t1 + t2;
@@ -335,7 +346,7 @@ __global__ __launch_bounds__(WG) void csr_stream_kernel(StreamArgs a, int xcd_ch
         }
     } else if (MODE == SM_JACOBI_BSR1) {
         double d = sdiag[t];
-        double told = a.v2[i];
+        double told = ep_v2;
         if (d != 0.0) {
             double t1 = (1.0 - a.c0) * told;
             double t2 = (a.c0 * acc) / d;
@@ -593,7 +604,7 @@ __global__ __launch_bounds__(WG) void csr_stream_pipe_kernel(StreamArgs a, int x
     }
 }
 
-static int g_stream_pipe = 1;
+static int g_stream_pipe = 0;   // measured slower than one row block per workgroup: opt-in
 void set_stream_pipe(int on) { g_stream_pipe = on; ++g_config_epoch; }
 bool stream_pipe_enabled() { return g_stream_pipe != 0; }
 
@@ -707,9 +718,138 @@ __global__ __launch_bounds__(CHAIN_WG) void gs_chain_kernel(const int *Ap, const
     }
 }
 
-static int g_gs_chain = 1;
+// ---------------------------------------------------------------------------
+// gs_chain2: a run of narrow dependency levels swept by ONE workgroup with the new values handed from level to
+// level through LDS.  In gs_chain_kernel a level costs ~3 us: its operands are stored to L2 by the previous level
+// and gathered back after the barrier.  Here thread t of level q
+//   * reads the operands produced by levels q-1 .. q-D from an LDS ring (D + 1 buffers of 512 doubles, written by
+//     their rows right after the global store),
+//   * finds everything else already in registers: entry values, diagonal, right-hand side and the operands that were
+//     final in memory >= D + 1 levels ago were requested D levels ahead, the entry codes they depend on D + 1 levels
+//     ahead (dependent loads never sit in one stage: a wave issues in order and would stall on them),
+// so the per-level critical path is barrier -> LDS reads -> the row sum -> divide -> store, a few hundred cycles.
+// Row sums run over the stored off-diagonal entries in stored order with separate multiply and add: bit-identical
+// to relaxation.h:34-62 / :90-173 (bs = 1) and to the level-per-launch path.
+// ---------------------------------------------------------------------------
+template <bool BSR1>
+__global__ __launch_bounds__(CHAIN2_WG) void gs_chain2_kernel(const int *crow, const double *cdiag, const double *cval,
+                                                             const int *ccode, const int *coff, double *x, const double *b,
+                                                             int l_first, int nl, int reverse)
+{
+    constexpr int PF = CHAIN2_PF, D = CHAIN2_D, NB = CHAIN2_D + 1;
+    __shared__ int soff[CHAIN2_LMAX + 1];
+    __shared__ double ring[NB][CHAIN2_WG];
+    const int t = threadIdx.x;
+    for (int k = t; k <= nl; k += CHAIN2_WG) soff[k] = coff[l_first + k];
+    __syncthreads();
+    volatile double *xs = x;
+    const int org = soff[0];                       // arrays are indexed from the start of the schedule's chain copy
+
+    struct Codes { int row; int n; int base; int code[PF]; };
+    struct Stage { int row; int lvl; double d, bb; int code[PF]; double val[PF]; double xv[PF]; };
+    auto level_of = [&](int q) { return reverse ? nl - 1 - q : q; };
+    (void)org;
+    auto stage_a = [&](int q) -> Codes {           // row id and operand codes (D + 1 levels ahead)
+        Codes c;
+        c.row = -1; c.n = 0; c.base = 0;
+#pragma unroll
+        for (int u = 0; u < PF; ++u) c.code[u] = CHAIN2_EMPTY;
+        if (q < nl) {
+            const int l = level_of(q);
+            c.base = soff[l];
+            c.n = soff[l + 1] - c.base;
+            if (t < c.n) {
+                c.row = crow[c.base + t];
+#pragma unroll
+                for (int u = 0; u < PF; ++u) c.code[u] = ccode[(size_t)PF * c.base + (size_t)u * c.n + t];
+            }
+        }
+        return c;
+    };
+    auto stage_b = [&](int q, const Codes &c) -> Stage {   // values, diagonal, right-hand side, settled operands (D ahead)
+        Stage s;
+        s.row = c.row; s.lvl = (q < nl) ? l_first + level_of(q) : 0; s.d = 0.0; s.bb = 0.0;
+#pragma unroll
+        for (int u = 0; u < PF; ++u) { s.code[u] = c.code[u]; s.val[u] = 0.0; s.xv[u] = 0.0; }
+        if (c.row >= 0) {
+            s.d = cdiag[c.base + t];
+            s.bb = b[c.row];
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                if (c.code[u] != CHAIN2_EMPTY) s.val[u] = cval[(size_t)PF * c.base + (size_t)u * c.n + t];
+                if (c.code[u] >= 0) s.xv[u] = xs[c.code[u]];
+            }
+        }
+        return s;
+    };
+
+    // fill the pipeline: codes of levels 0 .. D, stages of levels 0 .. D - 1
+    Codes ca[D + 1];
+#pragma unroll
+    for (int k = 0; k <= D; ++k) ca[k] = stage_a(k);
+    Stage sb[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) sb[k] = stage_b(k, ca[k]);
+
+    for (int q = 0; q < nl; ++q) {
+        // requests for the levels ahead first (nothing below waits for them)
+        Stage ahead = stage_b(q + D, ca[D]);
+        Codes cnew = stage_a(q + D + 1);
+        Stage &cur = sb[0];
+        if (cur.row >= 0) {
+            double acc = BSR1 ? cur.bb : 0.0;
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int code = cur.code[u];
+                if (code == CHAIN2_EMPTY) continue;
+                double xo = cur.xv[u];
+                if (code < 0) {                    // produced by one of the last D levels: LDS ring
+                    const int info = -1 - code;
+                    const int dl = info >> 10, pos = info & 1023;
+                    const int src = reverse ? cur.lvl + dl : cur.lvl - dl;
+                    xo = ring[src % NB][pos];
+                }
+                const double pr = cur.val[u] * xo;
+                acc = BSR1 ? (acc - pr) : (acc + pr);
+            }
+            if (cur.d != 0.0) {
+                const double xn = BSR1 ? (acc / cur.d) : ((cur.bb - acc) / cur.d);
+                xs[cur.row] = xn;
+                ring[cur.lvl % NB][t] = xn;
+            } else {
+                ring[cur.lvl % NB][t] = xs[cur.row];     // untouched row (zero diagonal): its old value is what others read
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k + 1 < D; ++k) sb[k] = sb[k + 1];
+        sb[D - 1] = ahead;
+#pragma unroll
+        for (int k = 0; k < D; ++k) ca[k] = ca[k + 1];
+        ca[D] = cnew;
+    }
+}
+
+int launch_gs_chain2(const int *row, const double *diag, const double *val, const int *code, const int *off, int l_first,
+                     int nlevels, bool reverse, bool bsr1, double *x, const double *b, hipStream_t st)
+{
+    if (nlevels <= 0) return 0;
+    if (nlevels > CHAIN2_LMAX) { set_error("gs_chain2: run longer than one launch holds"); return -4; }
+    if (bsr1)
+        hipLaunchKernelGGL((gs_chain2_kernel<true>), dim3(1), dim3(CHAIN2_WG), 0, st, row, diag, val, code, off, x, b, l_first,
+                           nlevels, reverse ? 1 : 0);
+    else
+        hipLaunchKernelGGL((gs_chain2_kernel<false>), dim3(1), dim3(CHAIN2_WG), 0, st, row, diag, val, code, off, x, b, l_first,
+                           nlevels, reverse ? 1 : 0);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "gs chain2 launch", __FILE__, __LINE__);
+    return 0;
+}
+
+static int g_gs_chain = 2;       // 0: a launch per level, 1: first-generation chain (operands through L2), 2: LDS hand-off chain
 void set_gs_chain(int on) { g_gs_chain = on; ++g_config_epoch; }
 bool gs_chain_enabled() { return g_gs_chain != 0; }
+int gs_chain_generation() { return g_gs_chain >= 2 ? 2 : 1; }
 int gs_chain_max_rows() { return CHAIN_WG; }
 
 int launch_gs_chain(const DevCsr &G, const int *rowmap, const int *diagpos, const int *level_ptr_dev, int l_first,
