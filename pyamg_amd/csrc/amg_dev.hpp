@@ -150,12 +150,12 @@ int launch_gs_chain(const DevCsr &G, const int *rowmap, const int *diagpos, cons
 // second generation of the chained sweep: operands produced by the last CHAIN2_D levels travel through LDS, everything
 // else (entries, diagonal, right-hand side, older operands) is prefetched CHAIN2_D levels ahead from the padded copy
 constexpr int CHAIN2_WG = 512;      // rows per level at most
-constexpr int CHAIN2_PF = 10;       // off-diagonal entries per row at most
+constexpr int CHAIN2_PF = 12;       // off-diagonal entries per row at most (copies are padded to 4, 8 or 12 slots)
 constexpr int CHAIN2_D = 2;         // prefetch distance in levels = levels whose results are passed through LDS
 constexpr int CHAIN2_LMAX = 4096;   // levels per launch
 constexpr int CHAIN2_EMPTY = -2147483647 - 1;
-int launch_gs_chain2(const int *row, const double *diag, const double *val, const int *code, const int *off, int l_first,
-                     int nlevels, bool reverse, bool bsr1, double *x, const double *b, hipStream_t st);
+int launch_gs_chain2(const int *row, const double *diag, const double *val, const int *code, const int *off, double *dummy, int pf,
+                     int l_first, int nlevels, bool reverse, bool bsr1, double *x, const double *b, hipStream_t st);
 int gs_chain_max_rows();
 bool gs_chain_enabled();
 int gs_chain_generation();

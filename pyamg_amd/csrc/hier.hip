@@ -346,9 +346,9 @@ void Schedule::release()
     free_bsr(Gb);
     rowmap = diagpos = rows = level_ptr_dev = nullptr;
     for (int *p : {c2_row, c2_code_f, c2_code_b, c2_off}) if (p) hipFree(p);
-    for (double *p : {c2_diag, c2_val}) if (p) hipFree(p);
+    for (double *p : {c2_diag, c2_val, c2_dummy}) if (p) hipFree(p);
     c2_row = c2_code_f = c2_code_b = c2_off = nullptr;
-    c2_diag = c2_val = nullptr;
+    c2_diag = c2_val = c2_dummy = nullptr;
     chain2 = false;
     chains.clear();
 }
@@ -458,8 +458,21 @@ int build_csr_schedule(const int *Ap, const int *Aj, const double *Ax, int n, co
         std::vector<int> coff((size_t)nl + 1, 0);
         for (int l = 0; l < nl; ++l) coff[(size_t)l + 1] = coff[(size_t)l] + (piece_of[(size_t)l] >= 0 ? S.level_ptr[l + 1] - S.level_ptr[l] : 0);
         const long total = coff[(size_t)nl];
-        std::vector<int> crow((size_t)total), cf((size_t)total * CHAIN2_PF, CHAIN2_EMPTY), cb((size_t)total * CHAIN2_PF, CHAIN2_EMPTY);
-        std::vector<double> cd((size_t)total, 0.0), cv((size_t)total * CHAIN2_PF, 0.0);
+        // slots per row: the longest off-diagonal row of the chained levels, rounded up to 4, 8 or 12
+        int longest = 0;
+        for (int l = 0; l < nl && ok; ++l) {
+            if (piece_of[(size_t)l] < 0) continue;
+            for (int k = S.level_ptr[l]; k < S.level_ptr[l + 1]; ++k) {
+                int cnt = 0;
+                for (int q = gp[(size_t)k]; q < gp[(size_t)k + 1]; ++q) cnt += (gj[(size_t)q] != rowmap[(size_t)k]) ? 1 : 0;
+                longest = std::max(longest, cnt);
+            }
+        }
+        if (longest > CHAIN2_PF) ok = false;
+        const int PFs = longest <= 4 ? 4 : (longest <= 8 ? 8 : 12);
+        S.c2_pf = PFs;
+        std::vector<int> crow((size_t)total), cf((size_t)total * PFs, CHAIN2_EMPTY), cb((size_t)total * PFs, CHAIN2_EMPTY);
+        std::vector<double> cd((size_t)total, 0.0), cv((size_t)total * PFs, 0.0);
         for (int l = 0; l < nl && ok; ++l) {
             if (piece_of[(size_t)l] < 0) continue;
             const int base = coff[(size_t)l], cnt = S.level_ptr[l + 1] - S.level_ptr[l];
@@ -471,8 +484,8 @@ int build_csr_schedule(const int *Ap, const int *Aj, const double *Ax, int n, co
                 for (int q = gp[(size_t)k]; q < gp[(size_t)k + 1]; ++q) {
                     const int c = gj[(size_t)q];
                     if (c == i) continue;                                   // the diagonal is not part of the sum
-                    if (u >= CHAIN2_PF) { ok = false; break; }
-                    const size_t at = (size_t)CHAIN2_PF * base + (size_t)u * cnt + tt;
+                    if (u >= PFs) { ok = false; break; }
+                    const size_t at = (size_t)PFs * base + (size_t)u * cnt + tt;
                     cv[at] = gx[(size_t)q];
                     int f = c, bk = c;                                       // default: settled in memory, read by column
                     if (c >= 0 && c < n && lvl_of[(size_t)c] >= 0 && piece_of[(size_t)lvl_of[(size_t)c]] == piece_of[(size_t)l]) {
@@ -488,10 +501,11 @@ int build_csr_schedule(const int *Ap, const int *Aj, const double *Ax, int n, co
         if (ok && total > 0) {
             CHK(dev_alloc(&S.c2_row, total, (long *)nullptr));
             CHK(dev_alloc(&S.c2_diag, total, (long *)nullptr));
-            CHK(dev_alloc(&S.c2_val, total * CHAIN2_PF, (long *)nullptr));
-            CHK(dev_alloc(&S.c2_code_f, total * CHAIN2_PF, (long *)nullptr));
-            CHK(dev_alloc(&S.c2_code_b, total * CHAIN2_PF, (long *)nullptr));
+            CHK(dev_alloc(&S.c2_val, total * PFs, (long *)nullptr));
+            CHK(dev_alloc(&S.c2_code_f, total * PFs, (long *)nullptr));
+            CHK(dev_alloc(&S.c2_code_b, total * PFs, (long *)nullptr));
             CHK(dev_alloc(&S.c2_off, nl + 1, (long *)nullptr));
+            CHK(dev_alloc(&S.c2_dummy, CHAIN2_WG, (long *)nullptr));
             AMG_HIP(hipMemcpy(S.c2_row, crow.data(), sizeof(int) * crow.size(), hipMemcpyHostToDevice));
             AMG_HIP(hipMemcpy(S.c2_diag, cd.data(), sizeof(double) * cd.size(), hipMemcpyHostToDevice));
             AMG_HIP(hipMemcpy(S.c2_val, cv.data(), sizeof(double) * cv.size(), hipMemcpyHostToDevice));
@@ -626,7 +640,7 @@ int gs_sweep_csr(const Schedule &S, bool bsr1, double *x, const double *b, bool 
         if (!reverse) { CHK(launches(pos, ch.first)); pos = ch.second; }
         else { CHK(launches(ch.second, pos)); pos = ch.first; }
         if (S.chain2 && gs_chain_enabled() && gs_chain_generation() == 2)
-            CHK(launch_gs_chain2(S.c2_row, S.c2_diag, S.c2_val, reverse ? S.c2_code_b : S.c2_code_f, S.c2_off, ch.first,
+            CHK(launch_gs_chain2(S.c2_row, S.c2_diag, S.c2_val, reverse ? S.c2_code_b : S.c2_code_f, S.c2_off, S.c2_dummy, S.c2_pf, ch.first,
                                  ch.second - ch.first, reverse, bsr1, x, b, st));
         else
             CHK(launch_gs_chain(S.G, S.rowmap, S.diagpos, S.level_ptr_dev, ch.first, ch.second - ch.first, reverse, bsr1, x, b, st));

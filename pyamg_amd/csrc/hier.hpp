@@ -32,8 +32,9 @@ struct Schedule {
     // final in memory long before it is needed and is prefetched), < 0 a slot of the workgroup's LDS ring (the
     // operand was produced by one of the last CHAIN2_D levels of this very launch).
     bool chain2 = false;
+    int c2_pf = 0;                 // slots per row of the copy: 4, 8 or 12
     int *c2_row = nullptr, *c2_code_f = nullptr, *c2_code_b = nullptr, *c2_off = nullptr;
-    double *c2_diag = nullptr, *c2_val = nullptr;
+    double *c2_diag = nullptr, *c2_val = nullptr, *c2_dummy = nullptr;   // dummy: where idle lanes store (512 doubles)
     // BSR flavour: block rows listed in level order
     int *rows = nullptr;          // device
     DevBsr Gb;                    // BSR flavour with values: block rows copied in level order (streamed)

@@ -114,6 +114,16 @@ __device__ __forceinline__ void store_out(double *p, double v)
 #endif
 }
 
+// x entries another wave of the SAME workgroup may have rewritten since this CU last cached them: an agent-scope
+// relaxed load (global_load ... sc1) is served from L2, where the producer's store has landed before the barrier
+// that separates the two (s_waitcnt vmcnt(0) precedes s_barrier).  NOT `volatile`: the compiler follows every
+// volatile access with s_waitcnt vmcnt(0), which turns a batch of independent gathers into a chain of round trips
+// (measured: ~3 us per dependency level in the chained sweeps, whatever else they did).
+__device__ __forceinline__ double load_fresh(const double *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <int MODE> struct ModeTraits {
     static constexpr bool jac = (MODE == SM_JACOBI || MODE == SM_JACOBI_BSR1);
     static constexpr bool gs = (MODE == SM_GS || MODE == SM_GS_BSR1);
@@ -634,7 +644,6 @@ __global__ __launch_bounds__(CHAIN_WG) void gs_chain_kernel(const int *Ap, const
                                                            const int *lp, int l_first, int nl, int reverse)
 {
     const int t = threadIdx.x;
-    volatile double *xs = x;         // re-read every level (values change between barriers)
     __shared__ int slp[CHAIN_LMAX + 1];
     for (int k = t; k <= nl; k += CHAIN_WG) slp[k] = lp[l_first + k];
     __syncthreads();
@@ -673,7 +682,7 @@ __global__ __launch_bounds__(CHAIN_WG) void gs_chain_kernel(const int *Ap, const
         // 1. operands of the current level first
         double xv[CHAIN_PF];
 #pragma unroll
-        for (int u = 0; u < CHAIN_PF; ++u) xv[u] = (cur.s + u < cur.e) ? xs[cc[u]] : 0.0;
+        for (int u = 0; u < CHAIN_PF; ++u) xv[u] = (cur.s + u < cur.e) ? load_fresh(&x[cc[u]]) : 0.0;
         // 2. entries of the next level, 3. row pointers of the one after (neither depends on x)
         int pc[CHAIN_PF];
         double pv[CHAIN_PF];
@@ -702,10 +711,10 @@ __global__ __launch_bounds__(CHAIN_WG) void gs_chain_kernel(const int *Ap, const
             }
             for (int k = cur.s + CHAIN_PF; k < cur.e; ++k) {        // rows longer than the register window
                 if (k == cur.dp) continue;
-                const double pr = Ax[k] * xs[Aj[k]];
+                const double pr = Ax[k] * load_fresh(&x[Aj[k]]);
                 acc = BSR1 ? (acc - pr) : (acc + pr);
             }
-            if (c_d != 0.0) xs[cur.row] = BSR1 ? (acc / c_d) : ((c_b - acc) / c_d);
+            if (c_d != 0.0) x[cur.row] = BSR1 ? (acc / c_d) : ((c_b - acc) / c_d);
         }
         // One workgroup = one CU: its waves share the L1, so workgroup-scope ordering (what __syncthreads
         // provides: stores complete, then the barrier) is all the next level needs -- no cache maintenance
@@ -731,116 +740,135 @@ __global__ __launch_bounds__(CHAIN_WG) void gs_chain_kernel(const int *Ap, const
 // Row sums run over the stored off-diagonal entries in stored order with separate multiply and add: bit-identical
 // to relaxation.h:34-62 / :90-173 (bs = 1) and to the level-per-launch path.
 // ---------------------------------------------------------------------------
-template <bool BSR1>
+template <bool BSR1, int PF>
 __global__ __launch_bounds__(CHAIN2_WG) void gs_chain2_kernel(const int *crow, const double *cdiag, const double *cval,
                                                              const int *ccode, const int *coff, double *x, const double *b,
-                                                             int l_first, int nl, int reverse)
+                                                             double *dummy, int l_first, int nl, int reverse)
 {
-    constexpr int PF = CHAIN2_PF, D = CHAIN2_D, NB = CHAIN2_D + 1;
+    constexpr int D = CHAIN2_D, NB = CHAIN2_D + 1;
+    // Vector-memory results return in issue order, so whatever an iteration needs must have been requested at least
+    // TWO iterations earlier -- then the requests of the iteration in between may still be in flight while it runs:
+    //   codes (operand addresses) of level q + D + A are requested in iteration q        (A = 2)
+    //   values / diagonal / right-hand side / settled operands of level q + D, which need those codes, in iteration q
+    //   level q is computed in iteration q from what was requested in iteration q - D   (D = 2)
+    // Every request is UNCONDITIONAL (idle lanes and the steps past the last level read harmless addresses): a load
+    // inside a branch makes the number of outstanding requests path-dependent and the compiler then waits for all.
+    constexpr int A = 2;
     __shared__ int soff[CHAIN2_LMAX + 1];
-    __shared__ double ring[NB][CHAIN2_WG];
+    __shared__ double ring[NB * CHAIN2_WG];
     const int t = threadIdx.x;
     for (int k = t; k <= nl; k += CHAIN2_WG) soff[k] = coff[l_first + k];
     __syncthreads();
-    volatile double *xs = x;
-    const int org = soff[0];                       // arrays are indexed from the start of the schedule's chain copy
 
-    struct Codes { int row; int n; int base; int code[PF]; };
-    struct Stage { int row; int lvl; double d, bb; int code[PF]; double val[PF]; double xv[PF]; };
+    struct Codes { int arow; int at; int n; bool live; int code[PF]; };       // at = base + lane (clamped)
+    struct Stage { int row; int arow; int lvl; double d, bb, xold; int code[PF]; double val[PF]; double xv[PF]; };
     auto level_of = [&](int q) { return reverse ? nl - 1 - q : q; };
-    (void)org;
-    auto stage_a = [&](int q) -> Codes {           // row id and operand codes (D + 1 levels ahead)
+    auto stage_a = [&](int q) -> Codes {           // row id and operand codes
         Codes c;
-        c.row = -1; c.n = 0; c.base = 0;
+        const int l = level_of(min(q, nl - 1));
+        const int base = soff[l];
+        c.n = soff[l + 1] - base;                  // >= 1: dependency levels are never empty
+        const int tt = min(t, c.n - 1);
+        c.live = (q < nl) && (t < c.n);
+        c.at = base + tt;
+        c.arow = crow[c.at];
 #pragma unroll
-        for (int u = 0; u < PF; ++u) c.code[u] = CHAIN2_EMPTY;
-        if (q < nl) {
-            const int l = level_of(q);
-            c.base = soff[l];
-            c.n = soff[l + 1] - c.base;
-            if (t < c.n) {
-                c.row = crow[c.base + t];
-#pragma unroll
-                for (int u = 0; u < PF; ++u) c.code[u] = ccode[(size_t)PF * c.base + (size_t)u * c.n + t];
-            }
-        }
+        for (int u = 0; u < PF; ++u) c.code[u] = ccode[(size_t)PF * base + (size_t)u * c.n + tt];
         return c;
     };
-    auto stage_b = [&](int q, const Codes &c) -> Stage {   // values, diagonal, right-hand side, settled operands (D ahead)
+    auto stage_b = [&](int q, const Codes &c) -> Stage {   // values, diagonal, right-hand side, settled operands
         Stage s;
-        s.row = c.row; s.lvl = (q < nl) ? l_first + level_of(q) : 0; s.d = 0.0; s.bb = 0.0;
+        s.row = c.live ? c.arow : -1;
+        s.arow = c.arow;
+        s.lvl = l_first + level_of(min(q, nl - 1));
+        s.d = cdiag[c.at];
+        s.bb = b[c.arow];
+        s.xold = load_fresh(&x[c.arow]);           // what a row with a zero diagonal keeps (relaxation.h:58-60)
+        const size_t e0 = (size_t)PF * (c.at - min(t, c.n - 1)) + (size_t)min(t, c.n - 1);
 #pragma unroll
-        for (int u = 0; u < PF; ++u) { s.code[u] = c.code[u]; s.val[u] = 0.0; s.xv[u] = 0.0; }
-        if (c.row >= 0) {
-            s.d = cdiag[c.base + t];
-            s.bb = b[c.row];
-#pragma unroll
-            for (int u = 0; u < PF; ++u) {
-                if (c.code[u] != CHAIN2_EMPTY) s.val[u] = cval[(size_t)PF * c.base + (size_t)u * c.n + t];
-                if (c.code[u] >= 0) s.xv[u] = xs[c.code[u]];
-            }
+        for (int u = 0; u < PF; ++u) {
+            s.code[u] = c.code[u];
+            s.val[u] = cval[e0 + (size_t)u * c.n];                                   // padded slots hold 0 and are never summed
+            s.xv[u] = load_fresh(&x[c.code[u] >= 0 ? c.code[u] : c.arow]);           // LDS / empty slots: a harmless address
         }
         return s;
     };
 
-    // fill the pipeline: codes of levels 0 .. D, stages of levels 0 .. D - 1
-    Codes ca[D + 1];
-#pragma unroll
-    for (int k = 0; k <= D; ++k) ca[k] = stage_a(k);
-    Stage sb[D];
-#pragma unroll
-    for (int k = 0; k < D; ++k) sb[k] = stage_b(k, ca[k]);
+    // Rotating buffers WITHOUT register moves (a move of a register a load is still filling would wait for that
+    // load): level L's stage lives in sb[L % 3], its codes in cq[L % 3], and the loop body is written out for the
+    // three residues so that every index is a compile-time constant.
+    static_assert(D == 2 && A == 2, "the rotation below is written for D = A = 2");
+    Stage sb[3];
+    Codes cq[3];
+    cq[0] = stage_a(0);
+    cq[1] = stage_a(1);
+    sb[0] = stage_b(0, cq[0]);
+    sb[1] = stage_b(1, cq[1]);
+    cq[2] = stage_a(2);
+    cq[0] = stage_a(3);
 
-    for (int q = 0; q < nl; ++q) {
-        // requests for the levels ahead first (nothing below waits for them)
-        Stage ahead = stage_b(q + D, ca[D]);
-        Codes cnew = stage_a(q + D + 1);
-        Stage &cur = sb[0];
-        if (cur.row >= 0) {
-            double acc = BSR1 ? cur.bb : 0.0;
+    auto compute = [&](Stage &cur) {
+        // operands produced by the last D levels come from the LDS ring (every lane reads, lanes without such an
+        // operand read slot 0 and drop it); no branch and no memory request in here besides the one store
+        double xo[PF];
 #pragma unroll
-            for (int u = 0; u < PF; ++u) {
-                const int code = cur.code[u];
-                if (code == CHAIN2_EMPTY) continue;
-                double xo = cur.xv[u];
-                if (code < 0) {                    // produced by one of the last D levels: LDS ring
-                    const int info = -1 - code;
-                    const int dl = info >> 10, pos = info & 1023;
-                    const int src = reverse ? cur.lvl + dl : cur.lvl - dl;
-                    xo = ring[src % NB][pos];
-                }
-                const double pr = cur.val[u] * xo;
-                acc = BSR1 ? (acc - pr) : (acc + pr);
-            }
-            if (cur.d != 0.0) {
-                const double xn = BSR1 ? (acc / cur.d) : ((cur.bb - acc) / cur.d);
-                xs[cur.row] = xn;
-                ring[cur.lvl % NB][t] = xn;
-            } else {
-                ring[cur.lvl % NB][t] = xs[cur.row];     // untouched row (zero diagonal): its old value is what others read
-            }
+        for (int u = 0; u < PF; ++u) {
+            const int code = cur.code[u];
+            const bool near = code < 0 && code != CHAIN2_EMPTY;
+            const int info = near ? (-1 - code) : 0;
+            const int dl = info >> 10, pos = info & 1023;
+            const int src = reverse ? cur.lvl + dl : cur.lvl - dl;
+            const double lv = ring[(src % NB) * CHAIN2_WG + pos];
+            // a bitwise blend instead of `near ? lv : xv`: the compiler would sink the LDS read into a branch of its
+            // own (one read, one wait, per slot) if the value were only conditionally used
+            const long long m = near ? -1LL : 0LL;
+            xo[u] = __longlong_as_double((__double_as_longlong(lv) & m) | (__double_as_longlong(cur.xv[u]) & ~m));
         }
+        double acc = BSR1 ? cur.bb : 0.0;
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const double pr = cur.val[u] * xo[u];
+            const double nxt = BSR1 ? (acc - pr) : (acc + pr);
+            acc = (cur.code[u] == CHAIN2_EMPTY) ? acc : nxt;
+        }
+        const double dd = (cur.d != 0.0) ? cur.d : 1.0;
+        const double q1 = BSR1 ? (acc / dd) : ((cur.bb - acc) / dd);
+        const double xn = (cur.d != 0.0) ? q1 : cur.xold;
+        double *dst = (cur.row >= 0) ? &x[cur.row] : &dummy[t];     // idle lanes store to a scratch line of their own
+        *dst = xn;
+        ring[(cur.lvl % NB) * CHAIN2_WG + t] = xn;
+    };
+    // one level: requests for the levels ahead first (nothing in `compute` waits for them), then the row, then the barrier
+    auto step = [&](int q, Stage &cur, Stage &fill, const Codes &use, Codes &refill) {
+        fill = stage_b(q + D, use);
+        refill = stage_a(q + D + A);
+        compute(cur);
         __syncthreads();
+    };
+    // (the compiler drains every outstanding request at the loop's back edge: four rotations per trip make that
+    // one drain per 12 levels; steps past the last level run on idle lanes only)
+    for (int q = 0; q < nl; q += 12) {
 #pragma unroll
-        for (int k = 0; k + 1 < D; ++k) sb[k] = sb[k + 1];
-        sb[D - 1] = ahead;
-#pragma unroll
-        for (int k = 0; k < D; ++k) ca[k] = ca[k + 1];
-        ca[D] = cnew;
+        for (int r = 0; r < 12; r += 3) {
+            step(q + r, sb[0], sb[2], cq[2], cq[1]);
+            step(q + r + 1, sb[1], sb[0], cq[0], cq[2]);
+            step(q + r + 2, sb[2], sb[1], cq[1], cq[0]);
+        }
     }
 }
 
-int launch_gs_chain2(const int *row, const double *diag, const double *val, const int *code, const int *off, int l_first,
-                     int nlevels, bool reverse, bool bsr1, double *x, const double *b, hipStream_t st)
+int launch_gs_chain2(const int *row, const double *diag, const double *val, const int *code, const int *off, double *dummy, int pf,
+                     int l_first, int nlevels, bool reverse, bool bsr1, double *x, const double *b, hipStream_t st)
 {
     if (nlevels <= 0) return 0;
     if (nlevels > CHAIN2_LMAX) { set_error("gs_chain2: run longer than one launch holds"); return -4; }
-    if (bsr1)
-        hipLaunchKernelGGL((gs_chain2_kernel<true>), dim3(1), dim3(CHAIN2_WG), 0, st, row, diag, val, code, off, x, b, l_first,
-                           nlevels, reverse ? 1 : 0);
-    else
-        hipLaunchKernelGGL((gs_chain2_kernel<false>), dim3(1), dim3(CHAIN2_WG), 0, st, row, diag, val, code, off, x, b, l_first,
-                           nlevels, reverse ? 1 : 0);
+#define C2_LAUNCH(B, P) hipLaunchKernelGGL((gs_chain2_kernel<B, P>), dim3(1), dim3(CHAIN2_WG), 0, st, row, diag, val, code, off, x, b, \
+                                           dummy, l_first, nlevels, reverse ? 1 : 0)
+    if (pf == 4) { if (bsr1) C2_LAUNCH(true, 4); else C2_LAUNCH(false, 4); }
+    else if (pf == 8) { if (bsr1) C2_LAUNCH(true, 8); else C2_LAUNCH(false, 8); }
+    else if (pf == 12) { if (bsr1) C2_LAUNCH(true, 12); else C2_LAUNCH(false, 12); }
+    else { set_error("gs_chain2: unsupported slot count"); return -1; }
+#undef C2_LAUNCH
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "gs chain2 launch", __FILE__, __LINE__);
     return 0;
@@ -1992,6 +2020,21 @@ __global__ __launch_bounds__(WG) void bsr_stream_kernel(BsrStreamArgs a, int rpb
             }
         }
         __syncthreads();
+        if (BMODE != BM_SPMV) {
+            // the relaxation kernels sum in two levels (relaxation.h: gemm gives v = sum_c p[r][c] left to right per
+            // block, then rsum += v block by block): the per-block sums are independent -- ALL threads form them,
+            // each writing v over the first product of its block row -- and only the short chain over the blocks
+            // stays with the row's own thread
+            const int nrow_t = (te - tb) * bs;
+            for (int idx = t; idx < nrow_t; idx += WG) {
+                const int lb = idx / bs, rr = idx - lb * bs;
+                double *p = &sp[(long)lb * B2 + rr * bs];
+                double v = 0.0;
+                for (int c = 0; c < bs; ++c) v = v + p[c];
+                p[0] = v;
+            }
+            __syncthreads();
+        }
         if (active) {
             const int s = max(my_s, tb), e = min(my_e, te);
             for (int jj = s; jj < e; ++jj) {
@@ -2003,9 +2046,7 @@ __global__ __launch_bounds__(WG) void bsr_stream_kernel(BsrStreamArgs a, int rpb
                     continue;
                 }
                 if (sbj[jj - tb] == brow) { dptr = (long)jj * B2; continue; }
-                const double *p = &sp[(long)(jj - tb) * B2 + r * bs];
-                double v = 0.0;
-                for (int c = 0; c < bs; ++c) v = v + p[c];
+                const double v = sp[(long)(jj - tb) * B2 + r * bs];
                 rsum = point ? (rsum - v) : (rsum + v);
             }
         }
