@@ -158,6 +158,15 @@ typedef struct {
     int nsdomains;
 } amg_smoother_desc;
 
+#define AMG_SM_CALLBACK 100
+/* A relaxation supplied by the caller (the device-resident Krylov smoothers, pyamg/relaxation/smoothing.py:481-509):
+ * called inside the cycle with DEVICE pointers to the level's iterate and right-hand side; it enqueues its work on
+ * amg_hier_stream(h) (amg_hier_apply, amg_dev_*) and returns 0, or non-zero to abort the solve. */
+typedef int (*amg_relax_callback)(void *user, int level, double *x_dev, const double *b_dev);
+/* A coarse solver supplied by the caller (multilevel.py:642-692: Krylov names, callables): HOST vectors of the
+ * coarsest level's size; x is zero on entry. */
+typedef int (*amg_coarse_callback)(void *user, int n, const double *b_host, double *x_host);
+
 /* flags for amg_hier_solve */
 #define AMG_SOLVE_X0_ZERO        1  /* caller guarantees x is all zeros on entry */
 #define AMG_SOLVE_NO_EARLY_STOP  2  /* run exactly maxiter cycles; residual norms stay on
@@ -193,6 +202,14 @@ int amg_hier_set_aux_matrix(amg_hier *h, int lvl, int which, int slot, int nmajo
 int amg_hier_set_coarse_dense(amg_hier *h, const double *M, int n);
 /* coarse_grid_solver(<relaxation name>) (multilevel.py:662-680): x = 0, then the smoother */
 int amg_hier_set_coarse_smoother(amg_hier *h, const amg_smoother_desc *d);
+int amg_hier_set_callback_smoother(amg_hier *h, int lvl, int which, amg_relax_callback cb, void *user);
+int amg_hier_set_coarse_callback(amg_hier *h, amg_coarse_callback cb, void *user);
+/* y = M x for a stored operator on DEVICE vectors, enqueued on the hierarchy's stream (which = AMG_MAT_A/P/R);
+ * amg_hier_apply_aux: the auxiliary operator of a smoother slot (amg_hier_set_aux_matrix: A by columns = A^T by rows) */
+int amg_hier_apply(amg_hier *h, int lvl, int which, const double *x_dev, double *y_dev);
+int amg_hier_apply_aux(amg_hier *h, int lvl, int which, int slot, const double *x_dev, double *y_dev);
+/* device scratch of the hierarchy for the reductions of amg_dev_dot_host / amg_dev_norm_host (>= 1040 doubles) */
+double *amg_hier_scratch(amg_hier *h);
 /* allocate work vectors, build Gauss-Seidel level schedules */
 int amg_hier_finalize(amg_hier *h);
 
@@ -281,6 +298,18 @@ int amg_dev_norm2(const double *x, long n, double *scratch, double *result_dev, 
 int amg_dev_dot(const double *x, const double *y, long n, double *scratch, double *result_dev, void *stream);
 int amg_dev_dense_apply(const double *Mt, const double *b, double *x, int n, void *stream);
 int amg_dev_gather(double *out, const double *in, const int *idx, long n, void *stream);
+/* device-resident vectors for the Krylov methods around the cycle: allocation, copies (kind 0 H2D, 1 D2H, 2 D2D),
+ * BLAS-1 updates, and reductions that return ONE scalar to the host */
+double *amg_dev_alloc(long n);
+void amg_dev_free(double *p);
+int amg_dev_copy(double *dst, const double *src, long n, int kind, void *stream);
+int amg_dev_fill(double *x, double v, long n, void *stream);
+int amg_dev_axmy(double *w, const double *v, double a, long n, void *stream);          /* w -= a v */
+int amg_dev_scale_add(double *p, double beta, const double *z, long n, void *stream);  /* p = beta p + z */
+int amg_dev_sub(double *out, const double *a, const double *b, long n, void *stream);  /* out = a - b */
+int amg_dev_divide(double *w, double a, long n, void *stream);                          /* w /= a */
+int amg_dev_dot_host(const double *x, const double *y, long n, double *scratch, double *result, void *stream);
+int amg_dev_norm_host(const double *x, long n, double *scratch, double *result, void *stream);
 
 /* ------------------------------------------------------------------------ */
 /* 4. Row-partitioned hierarchies: one process per GPU of a node, every level */

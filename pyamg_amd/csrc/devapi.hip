@@ -154,6 +154,51 @@ int amg_dev_dot(const double *x, const double *y, long n, double *scratch, doubl
 { return launch_dot(x, y, n, scratch, result_dev, (hipStream_t)stream); }
 int amg_dev_dense_apply(const double *Mt, const double *b, double *x, int n, void *stream)
 { return launch_dense_apply(Mt, b, x, n, (hipStream_t)stream); }
+// ---- device-resident vectors for the Krylov methods that wrap the cycle (pyamg_amd/krylov.py): the vectors live in
+// HBM, only scalars (inner products, norms, the few leading entries the Householder GMRES variants look at) cross PCIe
+double *amg_dev_alloc(long n)
+{
+    double *p = nullptr;
+    if (n < 0 || hipMalloc((void **)&p, sizeof(double) * (size_t)(n + PAD)) != hipSuccess) { set_error("device allocation failed"); return nullptr; }
+    hipMemset(p, 0, sizeof(double) * (size_t)(n + PAD));
+    hipDeviceSynchronize();
+    return p;
+}
+void amg_dev_free(double *p) { if (p) hipFree(p); }
+/* kind: 0 host->device, 1 device->host, 2 device->device; ordered on `stream`, host copies synchronous on return */
+int amg_dev_copy(double *dst, const double *src, long n, int kind, void *stream)
+{
+    if (n <= 0) return 0;
+    const hipMemcpyKind k = kind == 0 ? hipMemcpyHostToDevice : (kind == 1 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice);
+    AMG_HIP(hipMemcpyAsync(dst, src, sizeof(double) * (size_t)n, k, (hipStream_t)stream));
+    if (kind != 2) AMG_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+}
+int amg_dev_fill(double *x, double v, long n, void *stream) { return launch_fill(x, v, n, (hipStream_t)stream); }
+int amg_dev_axmy(double *w, const double *v, double a, long n, void *stream)          /* w -= a v */
+{ return launch_axmy(w, v, a, n, (hipStream_t)stream); }
+int amg_dev_scale_add(double *p, double beta, const double *z, long n, void *stream)  /* p = beta p + z */
+{ return launch_scale_add(p, beta, z, n, (hipStream_t)stream); }
+int amg_dev_sub(double *out, const double *a, const double *b, long n, void *stream)  /* out = a - b */
+{ return launch_sub(out, a, b, n, (hipStream_t)stream); }
+int amg_dev_divide(double *w, double a, long n, void *stream)                          /* w /= a */
+{ return launch_divide(w, a, n, (hipStream_t)stream); }
+/* host scalar = <x, y> / ||x||_2 (deterministic two-stage reductions; one 8-byte read-back, stream synchronised) */
+int amg_dev_dot_host(const double *x, const double *y, long n, double *scratch, double *result, void *stream)
+{
+    CHK(launch_dot(x, y, n, scratch, scratch + 1030, (hipStream_t)stream));
+    AMG_HIP(hipMemcpyAsync(result, scratch + 1030, sizeof(double), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    AMG_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+}
+int amg_dev_norm_host(const double *x, long n, double *scratch, double *result, void *stream)
+{
+    CHK(launch_norm2(x, n, scratch, scratch + 1030, (hipStream_t)stream));
+    AMG_HIP(hipMemcpyAsync(result, scratch + 1030, sizeof(double), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    AMG_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+}
+
 int amg_dev_gather(double *out, const double *in, const int *idx, long n, void *stream)
 {
     if (n <= 0) return 0;

@@ -490,8 +490,11 @@ int build_csr_schedule(const int *Ap, const int *Aj, const double *Ax, int n, co
                     int f = c, bk = c;                                       // default: settled in memory, read by column
                     if (c >= 0 && c < n && lvl_of[(size_t)c] >= 0 && piece_of[(size_t)lvl_of[(size_t)c]] == piece_of[(size_t)l]) {
                         const int dl = l - lvl_of[(size_t)c];                // > 0: produced earlier in a forward sweep
-                        if (dl >= 1 && dl <= CHAIN2_D) f = -1 - (dl * 1024 + pos_of[(size_t)c]);
-                        if (-dl >= 1 && -dl <= CHAIN2_D) bk = -1 - ((-dl) * 1024 + pos_of[(size_t)c]);
+                        // produced within the last CHAIN2_D levels of the sweep: the operand is read from the ring
+                        // buffer its level wrote, (level % (D + 1)) * 512 + position in the level
+                        const int slot = (lvl_of[(size_t)c] % (CHAIN2_D + 1)) * CHAIN2_WG + pos_of[(size_t)c];
+                        if (dl >= 1 && dl <= CHAIN2_D) f = -1 - slot;
+                        if (-dl >= 1 && -dl <= CHAIN2_D) bk = -1 - slot;
                     }
                     cf[at] = f; cb[at] = bk;
                     ++u;
@@ -748,6 +751,12 @@ static int relax(amg_hier *h, Level &L, Smoother &s, double *&x, double *&xalt, 
     switch (s.kind) {
     case AMG_SM_NONE:
         return 0;
+    case AMG_SM_CALLBACK: {
+        if (!s.cb) { set_error("callback smoother without a callback"); return AMG_ESTATE; }
+        const int lvl = (int)(&L - &h->lv[0]);
+        if (s.cb(s.cb_user, lvl, x, b) != 0) { if (last_error().empty()) set_error("callback smoother failed"); return AMG_ESTATE; }
+        return 0;
+    }
     case AMG_SM_JACOBI:
         // relaxation.py:357-427
         for (int it = 0; it < s.iterations; ++it) {
@@ -946,6 +955,17 @@ static int coarse_solve(amg_hier *h, const double *b, double *&x, double *&xalt)
         return 0;
     }
     if (h->coarse_kind == 1) return launch_dense_apply(h->coarse_Mt, b, x, n, h->stream);
+    if (h->coarse_kind == 3) {
+        // host coarse solver (multilevel.py:642-692 Krylov names / callables): the coarsest right-hand side (a few
+        // hundred entries) goes to the host, the correction comes back
+        h->coarse_hb.resize((size_t)n); h->coarse_hx.assign((size_t)n, 0.0);
+        AMG_HIP(hipMemcpyAsync(h->coarse_hb.data(), b, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, h->stream));
+        AMG_HIP(hipStreamSynchronize(h->stream));
+        if (h->coarse_cb(h->coarse_cb_user, n, h->coarse_hb.data(), h->coarse_hx.data()) != 0) { set_error("coarse solver callback failed"); return AMG_ESTATE; }
+        AMG_HIP(hipMemcpyAsync(x, h->coarse_hx.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, h->stream));
+        AMG_HIP(hipStreamSynchronize(h->stream));
+        return 0;
+    }
     if (h->comm && L.part.channel >= 0) { set_error("relaxation as coarse solver has no row-partitioned form"); return AMG_ENOTIMPL; }
     AMG_HIP(hipMemsetAsync(x, 0, sizeof(double) * (size_t)n, h->stream));   // multilevel.py:675
     return relax(h, L, h->coarse_sm, x, xalt, b, true);
@@ -1103,7 +1123,7 @@ static int graph_iteration(amg_hier *h, int cyc, bool x_zero, double *dst)
 {
     hipStream_t st = h->stream;
     double *slot = h->norm_scratch + 1028;
-    if (!h->use_graphs || cyc == AMG_CYCLE_AMLI) return iteration_with_norm(h, cyc, x_zero, dst);
+    if (!h->use_graphs || cyc == AMG_CYCLE_AMLI || h->has_callbacks) return iteration_with_norm(h, cyc, x_zero, dst);
     if (h->graph_epoch != config_epoch()) {      // a launch knob changed: the captured launches are stale
         drop_graphs(h);
         h->graph_epoch = config_epoch();
@@ -1547,6 +1567,58 @@ static int need_schedule(amg_hier *h, Level &L, Smoother &s)
         }
     }
     return 0;
+}
+
+int amg_hier_set_callback_smoother(amg_hier *h, int lvl, int which, amg_relax_callback cb, void *user)
+{
+    ENTER(h);
+    if (lvl < 0 || lvl >= h->nlevels || which < 0 || which > 1 || !cb) { set_error("bad callback smoother"); return AMG_EINVAL; }
+    Smoother &s = h->lv[lvl].sm[which];
+    free_smoother(s);
+    s = Smoother();
+    s.kind = AMG_SM_CALLBACK; s.cb = cb; s.cb_user = user;
+    h->has_callbacks = true;
+    h->finalized = false;
+    return 0;
+}
+
+int amg_hier_set_coarse_callback(amg_hier *h, amg_coarse_callback cb, void *user)
+{
+    ENTER(h);
+    if (!cb) { set_error("null coarse callback"); return AMG_EINVAL; }
+    h->coarse_cb = cb; h->coarse_cb_user = user; h->coarse_kind = 3;
+    h->has_callbacks = true;
+    h->finalized = false;
+    return 0;
+}
+
+int amg_hier_apply(amg_hier *h, int lvl, int which, const double *x_dev, double *y_dev)
+{
+    ENTER(h);
+    if (lvl < 0 || lvl >= h->nlevels || which < 0 || which > 2) { set_error("bad level/which"); return AMG_EINVAL; }
+    Level &L = h->lv[lvl];
+    const DevCsr &M = (which == AMG_MAT_A) ? L.A : (which == AMG_MAT_P ? L.P : L.Rm);
+    if (!M.Ap && !(M.blk && M.blk->Ap)) { set_error("operator not set"); return AMG_ESTATE; }
+    return spmv(M, SM_MATVEC, x_dev, nullptr, nullptr, y_dev, nullptr, 0.0, h->stream);
+}
+
+int amg_hier_apply_aux(amg_hier *h, int lvl, int which, int slot, const double *x_dev, double *y_dev)
+{
+    ENTER(h);
+    if (lvl < 0 || lvl >= h->nlevels || which < 0 || which > 2 || slot < 0 || slot > 1) { set_error("bad level/which/slot"); return AMG_EINVAL; }
+    Smoother &s = (which == 2) ? h->coarse_sm : h->lv[lvl].sm[which];
+    if (!s.aux[slot].Ap) { set_error("auxiliary operator not set"); return AMG_ESTATE; }
+    return spmv(s.aux[slot], SM_MATVEC, x_dev, nullptr, nullptr, y_dev, nullptr, 0.0, h->stream);
+}
+
+double *amg_hier_scratch(amg_hier *h)
+{
+    if (!h) return nullptr;
+    if (!h->norm_scratch) {
+        hipSetDevice(h->device);
+        if (dev_alloc(&h->norm_scratch, 1024 + 8, &h->dev_bytes) != 0) return nullptr;
+    }
+    return h->norm_scratch;
 }
 
 /* ---- row-partitioned hierarchies (one process per GPU): see hier.hpp Partition, comm.hpp ---- */

@@ -52,6 +52,10 @@ int sweep_block_schedule(const Schedule &S, BlockMode mode, const double *Dinv, 
                          double omega, bool reverse, hipStream_t st);
 
 struct Smoother {
+    // AMG_SM_CALLBACK: the relaxation is driven from outside (the device-resident Krylov smoothers of
+    // pyamg_amd/krylov.py): cb(user, level, x, b) is called with DEVICE pointers and enqueues on the hierarchy's stream
+    amg_relax_callback cb = nullptr;
+    void *cb_user = nullptr;
     int kind = AMG_SM_NONE;
     int iterations = 1;
     int sweep = AMG_SWEEP_FORWARD;
@@ -148,7 +152,10 @@ struct amg_hier {
     hipStream_t stream = nullptr;
     bool finalized = false;
     // coarse solve
-    int coarse_kind = 0;              // 0 none (zero correction), 1 dense, 2 smoother
+    int coarse_kind = 0;              // 0 none (zero correction), 1 dense, 2 smoother, 3 host callback
+    amg_coarse_callback coarse_cb = nullptr;   // x = solve(A_coarse, b) on HOST vectors (Krylov names, callables: <= a few hundred rows)
+    void *coarse_cb_user = nullptr;
+    std::vector<double> coarse_hb, coarse_hx;
     double *coarse_Mt = nullptr;
     int coarse_n = 0;
     amg::Smoother coarse_sm;
@@ -169,6 +176,7 @@ struct amg_hier {
     // hipGraph replay of the iteration (launch-bound hierarchies: small levels, level-scheduled GS)
     std::vector<amg::GraphEntry> graphs;
     int use_graphs = 1;
+    bool has_callbacks = false;                  // callback smoothers / coarse solver: iterations run eagerly
     int graph_epoch = 0;                         // amg::config_epoch() the cached graphs were captured under
     int keep_residual = 1;                       // hand the outer residual to the next pre-smoother
     bool r_kept = false;                         // lv[0].r == lv[0].b - A*lv[0].x right now (solve loop only)

@@ -772,8 +772,9 @@ __global__ __launch_bounds__(CHAIN2_WG) void gs_chain2_kernel(const int *crow, c
         c.live = (q < nl) && (t < c.n);
         c.at = base + tt;
         c.arow = crow[c.at];
+        const int *pc = ccode + ((size_t)PF * base + tt);          // slot u of this row: pc[u * n]
 #pragma unroll
-        for (int u = 0; u < PF; ++u) c.code[u] = ccode[(size_t)PF * base + (size_t)u * c.n + tt];
+        for (int u = 0; u < PF; ++u) { c.code[u] = *pc; pc += c.n; }
         return c;
     };
     auto stage_b = [&](int q, const Codes &c) -> Stage {   // values, diagonal, right-hand side, settled operands
@@ -784,11 +785,12 @@ __global__ __launch_bounds__(CHAIN2_WG) void gs_chain2_kernel(const int *crow, c
         s.d = cdiag[c.at];
         s.bb = b[c.arow];
         s.xold = load_fresh(&x[c.arow]);           // what a row with a zero diagonal keeps (relaxation.h:58-60)
-        const size_t e0 = (size_t)PF * (c.at - min(t, c.n - 1)) + (size_t)min(t, c.n - 1);
+        const int tt = min(t, c.n - 1);
+        const double *pv = cval + ((size_t)PF * (c.at - tt) + tt);
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
             s.code[u] = c.code[u];
-            s.val[u] = cval[e0 + (size_t)u * c.n];                                   // padded slots hold 0 and are never summed
+            s.val[u] = *pv; pv += c.n;                                               // padded slots hold 0 and are never summed
             s.xv[u] = load_fresh(&x[c.code[u] >= 0 ? c.code[u] : c.arow]);           // LDS / empty slots: a harmless address
         }
         return s;
@@ -815,10 +817,7 @@ __global__ __launch_bounds__(CHAIN2_WG) void gs_chain2_kernel(const int *crow, c
         for (int u = 0; u < PF; ++u) {
             const int code = cur.code[u];
             const bool near = code < 0 && code != CHAIN2_EMPTY;
-            const int info = near ? (-1 - code) : 0;
-            const int dl = info >> 10, pos = info & 1023;
-            const int src = reverse ? cur.lvl + dl : cur.lvl - dl;
-            const double lv = ring[(src % NB) * CHAIN2_WG + pos];
+            const double lv = ring[near ? (-1 - code) : 0];          // the code IS the ring slot (set at schedule build)
             // a bitwise blend instead of `near ? lv : xv`: the compiler would sink the LDS read into a branch of its
             // own (one read, one wait, per slot) if the value were only conditionally used
             const long long m = near ? -1LL : 0LL;
@@ -2148,7 +2147,13 @@ static int bsr_rows_per_wg(const BsrStreamArgs &a, long nblocks_hint)
     int rpb = WG / a.bs;
     if (nblocks_hint > 0 && rows > 0) {
         double per_row = (double)nblocks_hint * B2 / (double)rows;
-        int want = (int)(g_tile_target / (per_row > 1.0 ? per_row : 1.0));
+        // Passes over ALL block rows (Jacobi-type sweeps, operator applications) want workgroups that fill most of
+        // their 256 lanes in the row phase: 4 LDS tiles of products each (measured on the C5 operator, bs = 3:
+        // block Jacobi 3.6 -> 4.2 TB/s, r = b - A x 4.5 -> 5.0 TB/s).  A level of a scheduled Gauss-Seidel sweep is a
+        // small launch that needs many workgroups instead: half a tile each (tools/bsr_tile_sweep.py).
+        const bool whole = a.rowmap == nullptr;
+        const double target = whole ? 4.0 * g_tile_target : 0.5 * g_tile_target;
+        int want = (int)(target / (per_row > 1.0 ? per_row : 1.0));
         if (want < 1) want = 1;
         if (want < rpb) rpb = want;
     }
