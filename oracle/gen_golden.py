@@ -242,6 +242,13 @@ def smoother_desc(out, key, spec, fn, lvl):
     for k in ("iterations", "sweep", "blocksize"):
         if k in cv:
             d[k] = cv[k]
+    if str(name) in ("gmres", "cg", "cgne", "cgnr"):
+        # smoothing.py:481-509: Krylov iterations as relaxation; tol / maxiter / restrt are the closure's constants
+        d["method"] = str(name)
+        d["name"] = "krylov"
+        d["tol"] = float(cv["tol"])
+        d["maxiter"] = cv["maxiter"]
+        d["restrt"] = cv.get("restrt")
     if "omega" in cv:
         d["omega"] = float(np.ravel(cv["omega"])[0])
     if "coefficients" in cv:

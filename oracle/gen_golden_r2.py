@@ -31,6 +31,14 @@ import gen_golden as gg  # noqa: E402
 
 def main():
     pyamg = ref_env.stage()
+    only_new = "--only-new" in sys.argv
+    real_gen = gg.gen_hier
+
+    def gen_if_missing(pyamg_, name, *a, **k):
+        if only_new and os.path.exists(os.path.join(gg.OUT, "hier_%s.npz" % name)):
+            return
+        real_gen(pyamg_, name, *a, **k)
+    gg.gen_hier = gen_if_missing
     P = ref_env.poisson
     sa = lambda mc: (lambda A, **kw: pyamg.smoothed_aggregation_solver(A, max_coarse=mc, **kw))
     jac = ("jacobi", {"omega": 4.0 / 3.0})
@@ -49,6 +57,15 @@ def main():
                 ("gauss_seidel", {"sweep": "forward"}), dict(tol=1e-9, maxiter=25, accel="gmres"))
     gg.gen_hier(pyamg, "accel_bicgstab_F_2d", P((36, 36)), sa(20), jac, jac,
                 dict(tol=1e-9, maxiter=25, accel="bicgstab", cycle="F"))
+
+    # ---- Krylov iterations as smoothers (smoothing.py:481-509; relaxation/tests/test_smoothing.py:25-30) and as
+    #      coarse solvers (multilevel.py:642-660).  The C oracle has no Krylov methods: these are pinned by the
+    #      reference's histories alone (file prefix krylov_).
+    gg.gen_hier(pyamg, "krylov_gmres3_2d", P((30, 30)), sa(10), ("gmres", {"maxiter": 3}), ("gmres", {"maxiter": 3}),
+                dict(tol=1e-9, maxiter=25))
+    gg.gen_hier(pyamg, "krylov_cgnr_cgne_2d", P((30, 30)), sa(10), ("cgnr", {"maxiter": 2}), ("cgne", {"maxiter": 2}),
+                dict(tol=1e-9, maxiter=25))
+    gg.gen_hier(pyamg, "krylov_cg_2d", P((30, 30)), sa(10), None, ("cg", {"maxiter": 2}), dict(tol=1e-9, maxiter=25))
 
     # ---- C5 on the reference's own unstructured tetrahedral mesh
     d = scipy.io.loadmat("/root/reference/pyamg/gallery/example_data/unit_cube.mat")

@@ -26,6 +26,10 @@ class AmgDeviceError(AmgError):
     pass
 
 
+RELAX_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p)
+COARSE_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, c_dbl_p, c_dbl_p)
+
+
 class SmootherDesc(C.Structure):
     _fields_ = [("kind", C.c_int), ("iterations", C.c_int), ("sweep", C.c_int),
                 ("omega", C.c_double), ("ncoef", C.c_int), ("coef", c_dbl_p),
@@ -103,6 +107,18 @@ def lib():
         "amg_dev_dot": [V, V, C.c_long, V, V, V],
         "amg_dev_dense_apply": [V, V, V, I, V],
         "amg_dev_gather": [V, V, V, C.c_long, V],
+        "amg_hier_set_callback_smoother": [V, I, I, RELAX_CALLBACK, V],
+        "amg_hier_set_coarse_callback": [V, COARSE_CALLBACK, V],
+        "amg_hier_apply": [V, I, I, V, V],
+        "amg_hier_apply_aux": [V, I, I, I, V, V],
+        "amg_dev_copy": [V, V, C.c_long, I, V],
+        "amg_dev_fill": [V, D, C.c_long, V],
+        "amg_dev_axmy": [V, V, D, C.c_long, V],
+        "amg_dev_scale_add": [V, D, V, C.c_long, V],
+        "amg_dev_sub": [V, V, V, C.c_long, V],
+        "amg_dev_divide": [V, D, C.c_long, V],
+        "amg_dev_dot_host": [V, V, C.c_long, V, C.POINTER(C.c_double), V],
+        "amg_dev_norm_host": [V, C.c_long, V, C.POINTER(C.c_double), V],
         "amg_comm_add_channel": [V, c_int_p],
         "amg_comm_commit": [V, V],
         "amg_comm_connect": [V, V],
@@ -151,6 +167,12 @@ def lib():
     L.amg_hier_dev_x.restype = V
     L.amg_hier_dev_b.argtypes = [V]
     L.amg_hier_dev_b.restype = V
+    L.amg_dev_alloc.argtypes = [C.c_long]
+    L.amg_dev_alloc.restype = V
+    L.amg_dev_free.argtypes = [V]
+    L.amg_dev_free.restype = None
+    L.amg_hier_scratch.argtypes = [V]
+    L.amg_hier_scratch.restype = V
     L.amg_comm_create.argtypes = [I, I, I, I]
     L.amg_comm_create.restype = V
     L.amg_comm_destroy.argtypes = [V]

@@ -873,7 +873,7 @@ int launch_gs_chain2(const int *row, const double *diag, const double *val, cons
     return 0;
 }
 
-static int g_gs_chain = 2;       // 0: a launch per level, 1: first-generation chain (operands through L2), 2: LDS hand-off chain
+static int g_gs_chain = 1;       // 0: a launch per level, 1 (default): chain with operands gathered back from L2, 2: LDS hand-off chain (measured slower: instruction-bound)
 void set_gs_chain(int on) { g_gs_chain = on; ++g_config_epoch; }
 bool gs_chain_enabled() { return g_gs_chain != 0; }
 int gs_chain_generation() { return g_gs_chain >= 2 ? 2 : 1; }

@@ -21,6 +21,7 @@ __all__ = ["multilevel_solver", "coarse_grid_solver"]
 _SM_KIND = {None: 0, "None": 0, "jacobi": 1, "gauss_seidel": 2, "sor": 3, "polynomial": 4,
             "block_jacobi": 5, "block_gauss_seidel": 6, "gauss_seidel_indexed": 7, "schwarz": 8,
             "gauss_seidel_ne": 9, "gauss_seidel_nr": 10, "jacobi_ne": 11}
+# (name "krylov": a callback smoother, registered by _DeviceHierarchy._set_krylov_smoother)
 _SWEEP = {"forward": 0, "backward": 1, "symmetric": 2}
 _CYCLE = {"V": 0, "W": 1, "F": 2, "AMLI": 3}
 _X0_ZERO, _NO_EARLY_STOP, _DEVICE_VECTORS = 1, 2, 4
@@ -72,6 +73,8 @@ class _DeviceHierarchy(object):
         levels = ml.levels
         self.n = levels[0].A.shape[0]
         self._shapes = {}
+        self._callbacks = []             # ctypes callbacks must outlive the hierarchy
+        self._callback_error = None
         self.h = L.amg_hier_create(len(levels), int(device))
         if not self.h:
             msg = L.amg_last_error().decode()
@@ -108,6 +111,8 @@ class _DeviceHierarchy(object):
             raise NotImplementedError(
                 "level %d: smoother %r carries no device descriptor; use pyamg_amd.smoothing."
                 "change_smoothers with one of the device smoothers" % (lvl, fn))
+        if desc is not None and desc.get("name") == "krylov":
+            return self._set_krylov_smoother(lvl, which, desc, A)
         keep = []
         d = _desc_struct(desc, keep)
         if which == 2:
@@ -132,6 +137,49 @@ class _DeviceHierarchy(object):
             As = A.tocsr().copy()
             As.sort_indices()
             self._set_aux(lvl, which, 1, As)
+
+    def _set_krylov_smoother(self, lvl, which, desc, A):
+        """smoothing.py:481-509: a few iterations of an unpreconditioned Krylov method as the level's smoother, run by
+        pyamg_amd.krylov on the level's resident vectors from a callback inside the cycle"""
+        from . import krylov
+        if which == 2:
+            raise NotImplementedError("Krylov methods as coarse solver go through coarse_grid_solver('cg' ...)")
+        method = desc["method"]
+        tol, maxiter, restrt = float(desc["tol"]), desc["maxiter"], desc.get("restrt")
+        aux = (which, 0) if method in ("cgne", "cgnr") else None
+        owner = self
+
+        def relax(user, level, x_dev, b_dev):
+            try:
+                with krylov.DeviceSpace(owner, level, cycle=None, aux=aux) as V:
+                    krylov.run(method, V, b_dev, x_dev, tol, maxiter, restrt=restrt)
+                return 0
+            except Exception as e:          # noqa: BLE001 -- must not propagate through the C frames
+                owner._callback_error = e
+                return 1
+        cb = _lib.RELAX_CALLBACK(relax)
+        self._callbacks.append(cb)
+        _lib.check(self.L.amg_hier_set_callback_smoother(self.h, lvl, which, cb, None))
+        if aux is not None:
+            self._set_aux(lvl, which, 0, sparse.csc_matrix(A))        # A by columns = A^T by rows
+
+    def _set_coarse_callback(self, fn, Ac):
+        """multilevel.py:642-692: Krylov names and callables as coarse solver -- host code on the coarsest level's few
+        hundred unknowns, called from inside the cycle"""
+        owner = self
+
+        def solve(user, n, b_ptr, x_ptr):
+            try:
+                b = np.ctypeslib.as_array(b_ptr, shape=(n,)).copy()
+                x = np.asarray(fn(Ac, b), dtype=np.float64).ravel()
+                np.ctypeslib.as_array(x_ptr, shape=(n,))[:] = x
+                return 0
+            except Exception as e:          # noqa: BLE001
+                owner._callback_error = e
+                return 1
+        cb = _lib.COARSE_CALLBACK(solve)
+        self._callbacks.append(cb)
+        _lib.check(self.L.amg_hier_set_coarse_callback(self.h, cb, None))
 
     def _set_aux(self, lvl, which, slot, M):
         M.sort_indices()
@@ -160,16 +208,24 @@ class _DeviceHierarchy(object):
             _lib.check(self.L.amg_hier_set_coarse_dense(self.h, _lib.dp(M), M.shape[0]))
         elif kind == "smoother":
             self._set_smoother(len(levels) - 1, 2, payload, Ac)
+        elif kind == "callback":
+            self._set_coarse_callback(payload, Ac)
         elif kind != "none":
             raise NotImplementedError("coarse solver %s has no device implementation" % cs.name())
         _lib.check(self.L.amg_hier_finalize(self.h))
+
+    def _check(self, rc):
+        err, self._callback_error = self._callback_error, None
+        if err is not None:
+            raise err
+        _lib.check(rc)
 
     def solve(self, b, x, tol, maxiter, cycle, x0_zero=False, fixed=False):
         res = np.zeros(maxiter + 2, dtype=np.float64)
         nres = _lib.C.c_int(0)
         flags = (_X0_ZERO if x0_zero else 0) | (_NO_EARLY_STOP if fixed else 0)
-        _lib.check(self.L.amg_hier_solve(self.h, b.ctypes.data, x.ctypes.data, float(tol), int(maxiter),
-                                         _CYCLE[cycle], _lib.dp(res), _lib.C.byref(nres), flags))
+        self._check(self.L.amg_hier_solve(self.h, b.ctypes.data, x.ctypes.data, float(tol), int(maxiter),
+                                          _CYCLE[cycle], _lib.dp(res), _lib.C.byref(nres), flags))
         return res[:nres.value]
 
     def pcg(self, b, x, tol, maxiter, cycle, x0_zero=False):
@@ -181,8 +237,16 @@ class _DeviceHierarchy(object):
         return res[:nres.value], info.value
 
     def cycle(self, b, x, cycle, x0_zero=False):
-        _lib.check(self.L.amg_hier_cycle(self.h, b.ctypes.data, x.ctypes.data, _CYCLE[cycle],
-                                         _X0_ZERO if x0_zero else 0))
+        self._check(self.L.amg_hier_cycle(self.h, b.ctypes.data, x.ctypes.data, _CYCLE[cycle],
+                                          _X0_ZERO if x0_zero else 0))
+
+    def cycle_device(self, b_dev, x_dev, cycle):
+        """x_dev = one cycle from a zero guess for the right-hand side b_dev (DEVICE pointers): the preconditioner
+        M of multilevel.py:306-314 for the device-resident Krylov methods"""
+        self._check(self.L.amg_hier_cycle(self.h, b_dev, x_dev, _CYCLE[cycle], _X0_ZERO | _DEVICE_VECTORS))
+
+    def level_size(self, lvl):
+        return self._shapes[(lvl, 0)][0]
 
     def relax(self, lvl, which, b, x):
         _lib.check(self.L.amg_hier_relax(self.h, lvl, which, _lib.dp(b), _lib.dp(x)))
@@ -433,6 +497,26 @@ class multilevel_solver:
             if residuals is not None:
                 residuals[:] = [float(r) for r in res]
             return x1.reshape(np.asarray(b).shape)
+        from . import krylov
+        name = accel if isinstance(accel, str) else getattr(accel, "__name__", None)
+        if name in krylov.METHODS and (isinstance(accel, str) or accel is krylov.METHODS[name]):
+            # pyamg.krylov's own methods (multilevel.py:390-394), device-resident: vectors stay in HBM, the cycle is M
+            n = self.levels[0].A.shape[0]
+            b1 = np.ascontiguousarray(np.ravel(b), dtype=np.float64)
+            x1 = np.zeros(n) if x0 is None else np.ascontiguousarray(np.ravel(np.array(x0)), dtype=np.float64)
+            dev = self.device_hierarchy()
+            aux = None
+            if name in ("cgne", "cgnr"):
+                dev._set_aux(0, 0, 0, sparse.csc_matrix(self.levels[0].A))
+                aux = (0, 0)
+            with krylov.DeviceSpace(dev, 0, cycle=cycle, aux=aux) as V:
+                bd, xd = V.upload(b1), V.upload(x1)
+                info = krylov.run(name, V, bd, xd, tol, maxiter, residuals=residuals, callback=callback)
+                x1 = V.download(xd)
+            if info < 0 and name == "cg":
+                warn("Indefinite matrix or preconditioner detected in CG, aborting")
+            return x1.reshape(np.asarray(b).shape)
+        # anything else is scipy's (multilevel.py:395-396, 404-422): host vectors, the device cycle as M
         import scipy.sparse.linalg as spla
         if isinstance(accel, str):
             if not hasattr(spla, accel):
@@ -465,8 +549,9 @@ def coarse_grid_solver(solver):
     one dense operator at setup and applied on the device; relaxation names run
     the corresponding device smoother from a zero guess (default 10
     iterations); None gives a zero correction.  ('dense', {'M': array}) supplies
-    the operator directly.  Krylov names / arbitrary callables are host code
-    outside the device path and raise NotImplementedError when a solve needs them.
+    the operator directly.  Krylov names ('cg', 'gmres', 'bicgstab', ... and
+    scipy's 'cgs', 'qmr', 'minres', 'bicg') and arbitrary callables act on the
+    coarsest level's few hundred unknowns from a callback inside the cycle.
     """
     if isinstance(solver, _CoarseSolver):
         return solver
@@ -515,7 +600,23 @@ class _CoarseSolver(object):
             lvl = multilevel_solver.level()
             lvl.A = A
             return "smoother", getattr(smoothing, "setup_" + str(s))(lvl, **kw)
-        raise NotImplementedError("coarse solver %r runs on the host and is outside the device path" % (s,))
+        # Krylov names and callables (multilevel.py:642-660, 687-689): host code on the coarsest level, called from
+        # inside the device cycle with the restricted right-hand side
+        kw = dict(self.kwargs)
+        if callable(s):
+            return "callback", (lambda A_, b_: s(A_, b_, **kw))
+        from . import krylov
+        if "tol" not in kw:
+            kw["tol"] = float(np.finfo(np.float64).eps * 1e6)                  # multilevel.py:649-657
+        if s in krylov.METHODS:
+            return "callback", (lambda A_, b_: krylov.solve_host(A_, b_, method=s, **kw))
+        import scipy.sparse.linalg as spla
+
+        def scipy_solve(A_, b_):
+            k2 = dict(kw)
+            k2["rtol"] = k2.pop("tol")
+            return getattr(spla, s)(A_, b_, **k2)[0]
+        return "callback", scipy_solve
 
     def __call__(self, A, b):
         """generic_solver.__call__ (multilevel.py:694-712): solve on the device."""
@@ -524,6 +625,9 @@ class _CoarseSolver(object):
             return np.zeros(b.shape)
         lvl = multilevel_solver.level()
         lvl.A = sparse.csr_matrix(A) if not (sparse.isspmatrix_csr(A) or sparse.isspmatrix_bsr(A)) else A
+        kind, payload = self.device_form(lvl.A)
+        if kind == "callback":
+            return np.asarray(payload(lvl.A, np.ravel(b))).reshape(b.shape)
         ml = multilevel_solver([lvl], coarse_solver=self)
         x = np.zeros(A.shape[0])
         ml.device_hierarchy().cycle(np.ascontiguousarray(np.ravel(b), dtype=np.float64), x, "V", x0_zero=True)

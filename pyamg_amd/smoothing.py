@@ -286,6 +286,34 @@ def setup_strength_based_schwarz(lvl, iterations=1, sweep="symmetric"):
                          subdomain_ptr=Cm.indptr.copy(), sweep=sweep)
 
 
+def _setup_krylov(method, lvl, tol, maxiter, restrt=None, M=None, callback=None, residuals=None):
+    """smoothing.py:481-509: x <- method(A, b, x0=x, tol, maxiter) with no preconditioner as the level's relaxation;
+    on the device the iterations run on the level's resident vectors (pyamg_amd.krylov, from a callback in the cycle)"""
+    if M is not None or callback is not None or residuals is not None:
+        raise NotImplementedError("Krylov smoothers run unpreconditioned and silent on the device")
+    from . import krylov
+
+    def smoother(A, x, b):
+        x[:] = krylov.solve_host(A, b, x0=x, method=method, tol=tol, maxiter=maxiter, restrt=restrt).reshape(x.shape)
+    return _with_desc(smoother, name="krylov", method=method, tol=float(tol), maxiter=maxiter, restrt=restrt)
+
+
+def setup_gmres(lvl, tol=1e-12, maxiter=1, restrt=None, M=None, callback=None, residuals=None):
+    return _setup_krylov("gmres", lvl, tol, maxiter, restrt, M, callback, residuals)
+
+
+def setup_cg(lvl, tol=1e-12, maxiter=1, M=None, callback=None, residuals=None):
+    return _setup_krylov("cg", lvl, tol, maxiter, None, M, callback, residuals)
+
+
+def setup_cgne(lvl, tol=1e-12, maxiter=1, M=None, callback=None, residuals=None):
+    return _setup_krylov("cgne", lvl, tol, maxiter, None, M, callback, residuals)
+
+
+def setup_cgnr(lvl, tol=1e-12, maxiter=1, M=None, callback=None, residuals=None):
+    return _setup_krylov("cgnr", lvl, tol, maxiter, None, M, callback, residuals)
+
+
 def setup_None(lvl):
     def smoother(A, x, b):
         pass
@@ -323,6 +351,11 @@ def spec_from_descriptor(desc):
         return name, {"iterations": it, "sweep": sweep, "omega": desc.get("omega", 1.0)}
     if name == "jacobi_ne":
         return name, {"iterations": it, "omega": desc["omega"], "withrho": False}
+    if name == "krylov":
+        kw = {"tol": desc["tol"], "maxiter": desc["maxiter"]}
+        if desc["method"] == "gmres":
+            kw["restrt"] = desc.get("restrt")
+        return desc["method"], kw
     if name == "schwarz":
         return name, {"iterations": it, "sweep": desc.get("sweep", "symmetric"),
                       "subdomain": np.asarray(desc["subdomain"], dtype=np.intc),

@@ -15,7 +15,13 @@ def _all_cases():
 
 def hier_cases():
     """hierarchies solved by the stand-alone cycle iteration"""
-    return [c for c in _all_cases() if not c.startswith("accel_")]
+    return [c for c in _all_cases() if not c.startswith(("accel_", "krylov_"))]
+
+
+def krylov_smoother_cases():
+    """hierarchies whose smoothers are Krylov iterations (smoothing.py:481-509): no oracle form, pinned by the
+    reference's own histories"""
+    return [c for c in _all_cases() if c.startswith("krylov_")]
 
 
 def accel_cases(method=None):
@@ -152,6 +158,11 @@ def smoother_spec(d):
         return (name, {"iterations": it, "sweep": d.get("sweep", "forward"), "omega": d.get("omega", 1.0)})
     if name == "jacobi_ne":
         return ("jacobi_ne", {"iterations": it, "omega": d["omega"], "withrho": False})
+    if name == "krylov":
+        kw = {"tol": d["tol"], "maxiter": d["maxiter"]}
+        if d["method"] == "gmres":
+            kw["restrt"] = d.get("restrt")
+        return (d["method"], kw)
     if name == "schwarz":
         return ("schwarz", {"iterations": it, "sweep": d.get("sweep", "symmetric"), "subdomain": d["subdomain"],
                             "subdomain_ptr": d["subdomain_ptr"], "inv_subblock": d["inv_subblock"],
