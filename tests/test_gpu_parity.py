@@ -526,8 +526,8 @@ def test_coarse_grid_solver_exact_on_small_systems():
         relaxation.gauss_seidel(A, xo, b)
     assert np.array_equal(x, xo)
     assert np.array_equal(pyamg_amd.coarse_grid_solver(None)(A, b), np.zeros(16))
-    with pytest.raises(NotImplementedError):
-        pyamg_amd.coarse_grid_solver("cg")(A, b)
+    xk = pyamg_amd.coarse_grid_solver("cg")(A, b)            # Krylov names: round 1 refused them (multilevel.py:642-660)
+    assert np.allclose(A * xk, b, atol=1e-6)
 
 
 def test_aspreconditioner_and_accel_like_reference_tests():
@@ -1206,8 +1206,9 @@ def test_device_krylov_accel_vs_reference_generated_history(case):
     assert len(res) == len(ref), (len(res), len(ref))
     assert np.allclose(res, ref, rtol=2e-7, atol=1e-12 * ref[0]), np.max(np.abs(np.array(res) - ref) / ref)
     assert np.linalg.norm(x - g["x"]) <= 1e-7 * np.linalg.norm(g["x"])
-    A = g["levels"][0]["A"]
-    assert np.linalg.norm(g["b"] - A * x) <= 10 * m["tol"] * np.linalg.norm(g["b"] - A * g["x0"])
+    if m["accel"] != "gmres":        # (gmres is left-preconditioned: it stops on the PRECONDITIONED residual norm)
+        A = g["levels"][0]["A"]
+        assert np.linalg.norm(g["b"] - A * x) <= 10 * m["tol"] * np.linalg.norm(g["b"] - A * g["x0"])
 
 
 def test_device_cg_with_callback_and_function_handle():
