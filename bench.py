@@ -142,9 +142,13 @@ def launch_ranks(args):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         out = subprocess.PIPE if r == 0 else subprocess.DEVNULL
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=out))
-    line, _ = procs[0].communicate()
+    out, _ = procs[0].communicate()
     rcs = [p.wait() for p in procs]
-    sys.stdout.write(line.decode() if line else "")
+    for ln in (out.decode() if out else "").splitlines():
+        if ln.startswith("{"):               # rank 0's result line (anything else a library printed goes to stderr)
+            sys.stdout.write(ln + "\n")
+        elif ln.strip():
+            sys.stderr.write(ln + "\n")
     sys.stdout.flush()
     if any(rcs):
         raise SystemExit("rank exit codes: %s" % rcs)
@@ -353,7 +357,18 @@ def main():
         torch.cuda.set_device(local_rank)
         # the process group only carries setup metadata and barriers (host tensors); the halos and the all-reduce
         # of the solve travel GPU-to-GPU from the C++ engine (peer arenas over xGMI, or RCCL)
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        # (gloo announces its connections on STDOUT from C++: keep the one-JSON-line contract by pointing fd 1 at
+        # stderr while the group forms)
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     import pyamg_amd
     from pyamg_amd import _lib
