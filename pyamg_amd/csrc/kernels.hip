@@ -1943,16 +1943,22 @@ constexpr int MAXBS = 16;
 // The small dense epilogue (Dinv*t, or the point sweep over the diagonal block) goes through LDS.
 // ---------------------------------------------------------------------------
 template <int BMODE, int BS>      // BS > 0: compile-time block size (index arithmetic folds); 0: a.bs
-__global__ __launch_bounds__(WG) void bsr_stream_kernel(BsrStreamArgs a, int rpb)
+__global__ __launch_bounds__(WG) void bsr_stream_kernel(BsrStreamArgs a, int rpb, int xcd_chunk)
 {
     __shared__ double sp[TILE];
-    __shared__ int sbj[TILE];          // block column of every block in the tile
+    // block column of every block in the tile: TILE / bs^2 blocks at most (a tile holds whole blocks); sized exactly when
+    // the block size is a template constant -- 20 KB of LDS per workgroup instead of 27, i.e. 8 resident workgroups
+    // per CU instead of 5
+    __shared__ int sbj[BS > 1 ? TILE / (BS * BS) + 2 : TILE];
     __shared__ int sAp[WG + 1];
     __shared__ double st[WG];
 
     const int t = threadIdx.x;
     const int bs = BS > 0 ? BS : a.bs, B2 = bs * bs;
-    const int r0 = a.brow_lo + blockIdx.x * rpb;
+    // whole passes: consecutive row blocks to one XCD (its L2 then serves the neighbouring rows' operands); the
+    // epilogue of SM_RESIDUAL_SUMSQ indexes its partial by blockIdx, which only has to be a permutation
+    const int blk = xcd_chunk > 0 ? remap_block(blockIdx.x, gridDim.x, xcd_chunk) : (int)blockIdx.x;
+    const int r0 = a.brow_lo + blk * rpb;
     const int nr = min(rpb, a.brow_hi - r0);
     for (int i = t; i <= nr; i += WG) sAp[i] = a.Ap[r0 + i];
     __syncthreads();
@@ -2175,7 +2181,8 @@ int launch_bsr_stream(BlockMode m, const BsrStreamArgs &a, long nblocks_hint, hi
     if (a.bs > MAXBS || a.bs < 1) { set_error("block kernels support blocksize 1..16"); return -5; }
     const int rpb = bsr_rows_per_wg(a, nblocks_hint);
     dim3 g((rows + rpb - 1) / rpb), b(WG);
-#define BSR_LAUNCH(MODE, BSV) hipLaunchKernelGGL((bsr_stream_kernel<MODE, BSV>), g, b, 0, st, a, rpb)
+    const int chunk = (a.rowmap == nullptr && g.x >= 4096) ? g_xcd_chunk : 0;
+#define BSR_LAUNCH(MODE, BSV) hipLaunchKernelGGL((bsr_stream_kernel<MODE, BSV>), g, b, 0, st, a, rpb, chunk)
 #define BSR_BY_BS(MODE)                                 \
     switch (a.bs) {                                     \
     case 2: BSR_LAUNCH(MODE, 2); break;                 \
