@@ -250,20 +250,63 @@ void amgsetup_csr_sort_indices(int n_row, const int64_t *Ap, int *Aj, double *Ax
 }
 
 // B = A^T for CSR (scipy csr_tocsc order: entries of each output row in ascending source row)
+}   // extern "C" (templates below)
+
+// Row ranges of (nearly) equal entry counts for `parts` threads; part p owns rows [cut[p], cut[p+1])
+static std::vector<int> split_by_entries(int n_row, const int64_t *Ap, int parts)
+{
+    std::vector<int> cut((size_t)parts + 1, n_row);
+    cut[0] = 0;
+    const int64_t nnz = Ap[n_row];
+    for (int p = 1; p < parts; p++) {
+        const int64_t want = nnz * p / parts;
+        cut[(size_t)p] = (int)(std::lower_bound(Ap, Ap + n_row + 1, want) - Ap);
+        if (cut[(size_t)p] > n_row) cut[(size_t)p] = n_row;
+        if (cut[(size_t)p] < cut[(size_t)p - 1]) cut[(size_t)p] = cut[(size_t)p - 1];
+    }
+    return cut;
+}
+
+// Counting-sort transpose in parallel: thread p counts the columns of its row range, the per-column offsets are the
+// prefix over (column, thread) -- so entries of one output row still come in ascending source row (threads own
+// ascending row ranges), exactly csr_tocsc's order -- then every thread scatters its own rows.  width = values per entry.
+template <class Scatter>
+static void transpose_pattern(int n_row, int n_col, const int64_t *Ap, const int *Aj, int64_t *Bp, int *Bi, Scatter put)
+{
+    int parts = omp_get_max_threads();
+    if ((int64_t)parts * n_col > (int64_t)1 << 31) parts = std::max(1, (int)(((int64_t)1 << 31) / std::max(n_col, 1)));   // <= 16 GB of counters
+    if (Ap[n_row] < 1000000) parts = 1;
+    const std::vector<int> cut = split_by_entries(n_row, Ap, parts);
+    std::vector<int64_t> cnt((size_t)parts * (size_t)n_col, 0);
+#pragma omp parallel for schedule(static, 1) num_threads(parts)
+    for (int p = 0; p < parts; p++) {
+        int64_t *c = cnt.data() + (size_t)p * n_col;
+        for (int64_t k = Ap[cut[(size_t)p]]; k < Ap[cut[(size_t)p + 1]]; k++) c[Aj[k]]++;
+    }
+    Bp[0] = 0;
+    for (int c = 0; c < n_col; c++) {                    // prefix over (column, thread); cnt becomes the start offset
+        int64_t run = Bp[c];
+        for (int p = 0; p < parts; p++) { int64_t v = cnt[(size_t)p * n_col + c]; cnt[(size_t)p * n_col + c] = run; run += v; }
+        Bp[c + 1] = run;
+    }
+#pragma omp parallel for schedule(static, 1) num_threads(parts)
+    for (int p = 0; p < parts; p++) {
+        int64_t *cur = cnt.data() + (size_t)p * n_col;
+        for (int i = cut[(size_t)p]; i < cut[(size_t)p + 1]; i++)
+            for (int64_t k = Ap[i]; k < Ap[i + 1]; k++) {
+                const int64_t d = cur[Aj[k]]++;
+                Bi[d] = i;
+                put(d, k);
+            }
+    }
+}
+
+extern "C" {
+
 void amgsetup_csr_transpose(int n_row, int n_col, const int64_t *Ap, const int *Aj, const double *Ax,
                             int64_t *Bp, int *Bi, double *Bx)
 {
-    std::fill(Bp, Bp + n_col + 1, (int64_t)0);
-    int64_t nnz = Ap[n_row];
-    for (int64_t k = 0; k < nnz; k++) Bp[Aj[k] + 1]++;
-    for (int c = 0; c < n_col; c++) Bp[c + 1] += Bp[c];
-    std::vector<int64_t> cur(Bp, Bp + n_col);
-    for (int i = 0; i < n_row; i++)
-        for (int64_t k = Ap[i]; k < Ap[i + 1]; k++) {
-            int64_t d = cur[Aj[k]]++;
-            Bi[d] = i;
-            Bx[d] = Ax[k];
-        }
+    transpose_pattern(n_row, n_col, Ap, Aj, Bp, Bi, [&](int64_t d, int64_t k) { Bx[d] = Ax[k]; });
 }
 
 // pyamg/amg_core/smoothed_aggregation.h:323-500 for one candidate and scalar
@@ -491,20 +534,13 @@ void amgsetup_bsr_matmat_fill(int n_brow, int R, int N, int C, const int64_t *Ap
 void amgsetup_bsr_transpose(int n_brow, int n_bcol, int R, int C, const int64_t *Ap, const int *Aj, const double *Ax,
                             int64_t *Bp, int *Bi, double *Bx)
 {
-    std::fill(Bp, Bp + n_bcol + 1, (int64_t)0);
-    const int64_t nb = Ap[n_brow], RC = (int64_t)R * C;
-    for (int64_t k = 0; k < nb; k++) Bp[Aj[k] + 1]++;
-    for (int c = 0; c < n_bcol; c++) Bp[c + 1] += Bp[c];
-    std::vector<int64_t> cur(Bp, Bp + n_bcol);
-    for (int i = 0; i < n_brow; i++)
-        for (int64_t k = Ap[i]; k < Ap[i + 1]; k++) {
-            const int64_t d = cur[Aj[k]]++;
-            Bi[d] = i;
-            const double *a = Ax + k * RC;
-            double *b = Bx + d * RC;
-            for (int r = 0; r < R; r++)
-                for (int c = 0; c < C; c++) b[(int64_t)c * R + r] = a[(int64_t)r * C + c];
-        }
+    const int64_t RC = (int64_t)R * C;
+    transpose_pattern(n_brow, n_bcol, Ap, Aj, Bp, Bi, [&](int64_t d, int64_t k) {
+        const double *a = Ax + k * RC;
+        double *b = Bx + d * RC;
+        for (int r = 0; r < R; r++)
+            for (int c = 0; c < C; c++) b[(int64_t)c * R + r] = a[(int64_t)r * C + c];
+    });
 }
 
 // Jacobi-smoothed prolongator P = T - (w D^-1 S) T for BSR S (bs x bs blocks) and a tentative T with ONE
