@@ -146,7 +146,7 @@ int config_epoch();                      // bumped by every set_* knob below
 // Gauss-Seidel: runs of dependency levels of at most gs_chain_max_rows() rows swept by ONE workgroup in
 // one launch (barrier between levels, next level's rows prefetched) instead of a launch per level
 int launch_gs_chain(const DevCsr &G, const int *rowmap, const int *diagpos, const int *level_ptr_dev, int l_first,
-                    int nlevels, bool reverse, bool bsr1, double *x, const double *b, hipStream_t st);
+                    int nlevels, int width, bool reverse, bool bsr1, double *x, const double *b, hipStream_t st);
 // second generation of the chained sweep: operands produced by the last CHAIN2_D levels travel through LDS, everything
 // else (entries, diagonal, right-hand side, older operands) is prefetched CHAIN2_D levels ahead from the padded copy
 constexpr int CHAIN2_WG = 512;      // rows per level at most
@@ -154,8 +154,10 @@ constexpr int CHAIN2_PF = 12;       // off-diagonal entries per row at most (cop
 constexpr int CHAIN2_D = 2;         // prefetch distance in levels = levels whose results are passed through LDS
 constexpr int CHAIN2_LMAX = 4096;   // levels per launch
 constexpr int CHAIN2_EMPTY = -2147483647 - 1;
-int launch_gs_chain2(const int *row, const double *diag, const double *val, const int *code, const int *off, double *dummy, int pf,
-                     int l_first, int nlevels, bool reverse, bool bsr1, double *x, const double *b, hipStream_t st);
+int launch_perm_gather(const int *rowmap, const double *x, const double *b, double *xp, double *bp, int n, hipStream_t st);
+int launch_perm_scatter(const int *rowmap, const double *xp, double *x, int n, hipStream_t st);
+int launch_gs_chain2(const int *lp, const double *diag, const double *val, const int *code, const int *off, double *dummy, int pf,
+                     int l_first, int nlevels, int width, bool reverse, bool bsr1, double *x, const double *b, hipStream_t st);
 int gs_chain_max_rows();
 bool gs_chain_enabled();
 int gs_chain_generation();

@@ -3,6 +3,7 @@
 // constant and work vector in HBM.  The host only sequences kernel launches on
 // one HIP stream; one 8-byte copy per iteration brings the residual norm back
 // when a tolerance has to be checked.
+#include <array>
 #include "hier.hpp"
 
 #include <algorithm>
@@ -345,12 +346,13 @@ void Schedule::release()
     if (level_ptr_dev) hipFree(level_ptr_dev);
     free_bsr(Gb);
     rowmap = diagpos = rows = level_ptr_dev = nullptr;
-    for (int *p : {c2_row, c2_code_f, c2_code_b, c2_off}) if (p) hipFree(p);
-    for (double *p : {c2_diag, c2_val, c2_dummy}) if (p) hipFree(p);
-    c2_row = c2_code_f = c2_code_b = c2_off = nullptr;
-    c2_diag = c2_val = c2_dummy = nullptr;
-    chain2 = false;
+    for (int *p : {c2_code_f, c2_code_b, c2_off, perm_Aj}) if (p) hipFree(p);
+    for (double *p : {c2_diag, c2_val, c2_dummy, xp, bp}) if (p) hipFree(p);
+    c2_code_f = c2_code_b = c2_off = perm_Aj = nullptr;
+    c2_diag = c2_val = c2_dummy = xp = bp = nullptr;
+    chain2 = perm = false;
     chains.clear();
+    chain_width.clear();
 }
 
 int build_levels(int n, const int *Ap, const int *Aj, const int *tasks, int ntasks,
@@ -428,6 +430,7 @@ int build_csr_schedule(const int *Ap, const int *Aj, const double *Ax, int n, co
     CHK(dev_alloc(&S.level_ptr_dev, (long)S.level_ptr.size(), (long *)nullptr));
     AMG_HIP(hipMemcpy(S.level_ptr_dev, S.level_ptr.data(), sizeof(int) * S.level_ptr.size(), hipMemcpyHostToDevice));
     S.chains.clear();
+    S.chain_width.clear();
     // Measured (tools/gs_chain_ab.py): one workgroup beats a launch per level only when the levels are
     // really small -- a few hundred short rows (2-D 5/9-point operators: -12 % per cycle); on levels of
     // ~1000 rows or rows of 30 entries (SA coarse levels) it is 1.5-2.5x slower.  Hence the narrow window.
@@ -438,20 +441,61 @@ int build_csr_schedule(const int *Ap, const int *Aj, const double *Ax, int n, co
         if (S.level_ptr[l + 1] - S.level_ptr[l] > max_rows) { ++l; continue; }
         int e = l;
         while (e < nl && S.level_ptr[e + 1] - S.level_ptr[e] <= max_rows) ++e;
-        if (e - l >= 4)
-            for (int p = l; p < e; p += CHAIN2_LMAX) S.chains.emplace_back(p, std::min(e, p + CHAIN2_LMAX));   // one launch each
+        if (e - l >= 4) {
+            // Pieces of one width class each (64 / 128 / 256 / 512 threads): the workgroup of a piece is sized to its
+            // widest level, because idle waves still issue the whole pipeline.  A piece shorter than 16 levels is not
+            // worth a launch of its own and joins its wider neighbour.
+            auto cls = [&](int q) { const int w = S.level_ptr[q + 1] - S.level_ptr[q]; return w <= 64 ? 64 : (w <= 128 ? 128 : (w <= 256 ? 256 : 512)); };
+            std::vector<std::array<int, 3>> pc;                              // first, last + 1, class
+            for (int q = l; q < e; ++q) {
+                const int c = cls(q);
+                if (!pc.empty() && pc.back()[2] == c) pc.back()[1] = q + 1;
+                else pc.push_back({q, q + 1, c});
+            }
+            for (bool merged = true; merged && pc.size() > 1;) {
+                merged = false;
+                for (size_t k = 0; k < pc.size(); ++k) {
+                    if (pc[k][1] - pc[k][0] >= 16) continue;
+                    // join the neighbour whose class is closer from above (or the only one)
+                    size_t j;
+                    if (k == 0) j = 1;
+                    else if (k + 1 == pc.size()) j = k - 1;
+                    else j = (pc[k - 1][2] >= pc[k][2] && (pc[k + 1][2] < pc[k][2] || pc[k - 1][2] <= pc[k + 1][2])) ? k - 1 : k + 1;
+                    const size_t a0 = std::min(j, k), a1 = std::max(j, k);
+                    pc[a0] = {pc[a0][0], pc[a1][1], std::max(pc[a0][2], pc[a1][2])};
+                    pc.erase(pc.begin() + (long)a1);
+                    merged = true;
+                    break;
+                }
+                // neighbours that ended up in the same class are one piece
+                for (size_t k = 0; k + 1 < pc.size();)
+                    if (pc[k][2] == pc[k + 1][2]) { pc[k][1] = pc[k + 1][1]; pc.erase(pc.begin() + (long)k + 1); merged = true; }
+                    else ++k;
+            }
+            for (const auto &q : pc)
+                for (int p = q[0]; p < q[1]; p += CHAIN2_LMAX) {             // one launch each
+                    S.chains.emplace_back(p, std::min(q[1], p + CHAIN2_LMAX));
+                    S.chain_width.push_back(q[2]);
+                }
+        }
         l = e;
     }
     // ---- the chained sweep's padded copy (Schedule::c2_*, gs_chain2_kernel)
     S.chain2 = false;
-    if (!S.chains.empty() && max_rows <= CHAIN2_WG) {
-        std::vector<int> lvl_of((size_t)n, -1), pos_of((size_t)n, -1), piece_of((size_t)nl, -1);
+    S.perm = false;
+    // The second-generation chain runs in LEVEL-ORDER numbering (unknown k = the k-th row of the schedule), which
+    // needs the schedule to be a permutation of the unknowns of a square operator: every row listed exactly once and
+    // no column outside (a partitioned level's halo columns are).
+    bool permutation = !S.chains.empty() && max_rows <= CHAIN2_WG && ntasks == n;
+    for (size_t q = 0; permutation && q < gj.size(); ++q) permutation = gj[q] >= 0 && gj[q] < n;
+    if (permutation) {
+        std::vector<int> lvl_of((size_t)n, -1), pos_of((size_t)n, -1), piece_of((size_t)nl, -1), inv((size_t)n, -1);
         bool ok = true;
         for (int l = 0; l < nl && ok; ++l)
             for (int k = S.level_ptr[l]; k < S.level_ptr[l + 1]; ++k) {
                 const int i = rowmap[(size_t)k];
                 if (lvl_of[(size_t)i] >= 0) { ok = false; break; }          // a row listed twice: keep the first-generation chain
-                lvl_of[(size_t)i] = l; pos_of[(size_t)i] = k - S.level_ptr[l];
+                lvl_of[(size_t)i] = l; pos_of[(size_t)i] = k - S.level_ptr[l]; inv[(size_t)i] = k;
             }
         for (size_t c = 0; c < S.chains.size(); ++c)
             for (int l = S.chains[c].first; l < S.chains[c].second; ++l) piece_of[(size_t)l] = (int)c;
@@ -471,14 +515,13 @@ int build_csr_schedule(const int *Ap, const int *Aj, const double *Ax, int n, co
         if (longest > CHAIN2_PF) ok = false;
         const int PFs = longest <= 4 ? 4 : (longest <= 8 ? 8 : 12);
         S.c2_pf = PFs;
-        std::vector<int> crow((size_t)total), cf((size_t)total * PFs, CHAIN2_EMPTY), cb((size_t)total * PFs, CHAIN2_EMPTY);
+        std::vector<int> cf((size_t)total * PFs, CHAIN2_EMPTY), cb((size_t)total * PFs, CHAIN2_EMPTY);
         std::vector<double> cd((size_t)total, 0.0), cv((size_t)total * PFs, 0.0);
         for (int l = 0; l < nl && ok; ++l) {
             if (piece_of[(size_t)l] < 0) continue;
             const int base = coff[(size_t)l], cnt = S.level_ptr[l + 1] - S.level_ptr[l];
             for (int tt = 0; tt < cnt && ok; ++tt) {
                 const int k = S.level_ptr[l] + tt, i = rowmap[(size_t)k];
-                crow[(size_t)base + tt] = i;
                 cd[(size_t)base + tt] = dpos[(size_t)k] >= 0 ? gx[(size_t)dpos[(size_t)k]] : 0.0;
                 int u = 0;
                 for (int q = gp[(size_t)k]; q < gp[(size_t)k + 1]; ++q) {
@@ -487,8 +530,8 @@ int build_csr_schedule(const int *Ap, const int *Aj, const double *Ax, int n, co
                     if (u >= PFs) { ok = false; break; }
                     const size_t at = (size_t)PFs * base + (size_t)u * cnt + tt;
                     cv[at] = gx[(size_t)q];
-                    int f = c, bk = c;                                       // default: settled in memory, read by column
-                    if (c >= 0 && c < n && lvl_of[(size_t)c] >= 0 && piece_of[(size_t)lvl_of[(size_t)c]] == piece_of[(size_t)l]) {
+                    int f = inv[(size_t)c], bk = inv[(size_t)c];             // default: settled in memory, read at its level-order position
+                    if (piece_of[(size_t)lvl_of[(size_t)c]] == piece_of[(size_t)l]) {
                         const int dl = l - lvl_of[(size_t)c];                // > 0: produced earlier in a forward sweep
                         // produced within the last CHAIN2_D levels of the sweep: the operand is read from the ring
                         // buffer its level wrote, (level % (D + 1)) * 512 + position in the level
@@ -502,20 +545,27 @@ int build_csr_schedule(const int *Ap, const int *Aj, const double *Ax, int n, co
             }
         }
         if (ok && total > 0) {
-            CHK(dev_alloc(&S.c2_row, total, (long *)nullptr));
             CHK(dev_alloc(&S.c2_diag, total, (long *)nullptr));
             CHK(dev_alloc(&S.c2_val, total * PFs, (long *)nullptr));
             CHK(dev_alloc(&S.c2_code_f, total * PFs, (long *)nullptr));
             CHK(dev_alloc(&S.c2_code_b, total * PFs, (long *)nullptr));
             CHK(dev_alloc(&S.c2_off, nl + 1, (long *)nullptr));
             CHK(dev_alloc(&S.c2_dummy, CHAIN2_WG, (long *)nullptr));
-            AMG_HIP(hipMemcpy(S.c2_row, crow.data(), sizeof(int) * crow.size(), hipMemcpyHostToDevice));
             AMG_HIP(hipMemcpy(S.c2_diag, cd.data(), sizeof(double) * cd.size(), hipMemcpyHostToDevice));
             AMG_HIP(hipMemcpy(S.c2_val, cv.data(), sizeof(double) * cv.size(), hipMemcpyHostToDevice));
             AMG_HIP(hipMemcpy(S.c2_code_f, cf.data(), sizeof(int) * cf.size(), hipMemcpyHostToDevice));
             AMG_HIP(hipMemcpy(S.c2_code_b, cb.data(), sizeof(int) * cb.size(), hipMemcpyHostToDevice));
             AMG_HIP(hipMemcpy(S.c2_off, coff.data(), sizeof(int) * coff.size(), hipMemcpyHostToDevice));
+            // the level-ordered copy's columns in level-order numbering (for the per-level launches and the first-
+            // generation chain of the same sweep) and the gathered x / b the sweep works on
+            std::vector<int> pj(gj.size());
+            for (size_t q = 0; q < gj.size(); ++q) pj[q] = inv[(size_t)gj[q]];
+            CHK(dev_alloc(&S.perm_Aj, (long)pj.size(), (long *)nullptr));
+            CHK(dev_alloc(&S.xp, n, (long *)nullptr));
+            CHK(dev_alloc(&S.bp, n, (long *)nullptr));
+            AMG_HIP(hipMemcpy(S.perm_Aj, pj.data(), sizeof(int) * pj.size(), hipMemcpyHostToDevice));
             S.chain2 = true;
+            S.perm = true;
         }
     }
     return 0;
@@ -618,39 +668,63 @@ int spmv(const DevCsr &M, StreamMode mode, const double *xg, const double *b, co
     return apply_operator(M, mode, a, st);
 }
 
-// one directional sweep of a scheduled (CSR flavour) Gauss-Seidel
-int gs_sweep_csr(const Schedule &S, bool bsr1, double *x, const double *b, bool reverse,
+// directional sweeps of a scheduled (CSR flavour) Gauss-Seidel, in the order given (seq[k] != 0: reversed).  With the
+// second-generation chain the sweeps run in LEVEL-ORDER numbering on gathered copies of x and b (one gather before,
+// one scatter after the whole sequence): every access of a level is then contiguous over the lanes.
+int gs_sweep_csr(const Schedule &S, bool bsr1, double *x, const double *b, const unsigned char *seq, int nseq,
                  hipStream_t st)
 {
-    StreamArgs a = base_args(S.G);
-    a.xg = x; a.b = b; a.out = x; a.rowmap = S.rowmap; a.diagpos = S.diagpos;
-    const int nl = S.nlevels();
-    auto launches = [&](int l0, int l1) -> int {          // levels [l0, l1), one launch each, in sweep order
-        for (int q = 0; q < l1 - l0; ++q) {
-            const int l = reverse ? l1 - 1 - q : l0 + q;
-            a.row_lo = S.level_ptr[l];
-            a.row_hi = S.level_ptr[l + 1];
-            CHK(launch_stream(bsr1 ? SM_GS_BSR1 : SM_GS, a, st));
-        }
-        return 0;
-    };
-    if (!gs_chain_enabled() || S.chains.empty()) return launches(0, nl);
-    // segments in sweep order: wide levels by launches, runs of narrow levels by one chained launch each
-    const int nc = (int)S.chains.size();
-    int pos = reverse ? nl : 0;
-    for (int c = 0; c < nc; ++c) {
-        const auto &ch = S.chains[(size_t)(reverse ? nc - 1 - c : c)];
-        if (!reverse) { CHK(launches(pos, ch.first)); pos = ch.second; }
-        else { CHK(launches(ch.second, pos)); pos = ch.first; }
-        if (S.chain2 && gs_chain_enabled() && gs_chain_generation() == 2)
-            CHK(launch_gs_chain2(S.c2_row, S.c2_diag, S.c2_val, reverse ? S.c2_code_b : S.c2_code_f, S.c2_off, S.c2_dummy, S.c2_pf, ch.first,
-                                 ch.second - ch.first, reverse, bsr1, x, b, st));
-        else
-            CHK(launch_gs_chain(S.G, S.rowmap, S.diagpos, S.level_ptr_dev, ch.first, ch.second - ch.first, reverse, bsr1, x, b, st));
+    if (nseq <= 0) return 0;
+    const bool perm = S.perm && gs_chain_enabled() && gs_chain_generation() == 2;
+    DevCsr G = S.G;
+    G.owned = false;
+    const int *rowmap = S.rowmap;
+    double *xs = x;
+    const double *bs = b;
+    if (perm) {
+        CHK(launch_perm_gather(S.rowmap, x, b, S.xp, S.bp, S.ntasks, st));
+        G.Aj = S.perm_Aj; rowmap = nullptr; xs = S.xp; bs = S.bp;
     }
-    if (!reverse) CHK(launches(pos, nl));
-    else CHK(launches(0, pos));
+    StreamArgs a = base_args(G);
+    a.xg = xs; a.b = bs; a.out = xs; a.rowmap = rowmap; a.diagpos = S.diagpos;
+    const int nl = S.nlevels();
+    for (int k = 0; k < nseq; ++k) {
+        const bool reverse = seq[k] != 0;
+        auto launches = [&](int l0, int l1) -> int {          // levels [l0, l1), one launch each, in sweep order
+            for (int q = 0; q < l1 - l0; ++q) {
+                const int l = reverse ? l1 - 1 - q : l0 + q;
+                a.row_lo = S.level_ptr[l];
+                a.row_hi = S.level_ptr[l + 1];
+                CHK(launch_stream(bsr1 ? SM_GS_BSR1 : SM_GS, a, st));
+            }
+            return 0;
+        };
+        if (!gs_chain_enabled() || S.chains.empty()) { CHK(launches(0, nl)); continue; }
+        // segments in sweep order: wide levels by launches, runs of narrow levels by one chained launch each
+        const int nc = (int)S.chains.size();
+        int pos = reverse ? nl : 0;
+        for (int c = 0; c < nc; ++c) {
+            const auto &ch = S.chains[(size_t)(reverse ? nc - 1 - c : c)];
+            const int width = S.chain_width[(size_t)(reverse ? nc - 1 - c : c)];
+            if (!reverse) { CHK(launches(pos, ch.first)); pos = ch.second; }
+            else { CHK(launches(ch.second, pos)); pos = ch.first; }
+            if (perm)
+                CHK(launch_gs_chain2(S.level_ptr_dev, S.c2_diag, S.c2_val, reverse ? S.c2_code_b : S.c2_code_f, S.c2_off, S.c2_dummy, S.c2_pf,
+                                     ch.first, ch.second - ch.first, width, reverse, bsr1, xs, bs, st));
+            else
+                CHK(launch_gs_chain(G, rowmap, S.diagpos, S.level_ptr_dev, ch.first, ch.second - ch.first, width, reverse, bsr1, xs, bs, st));
+        }
+        if (!reverse) CHK(launches(pos, nl));
+        else CHK(launches(0, pos));
+    }
+    if (perm) CHK(launch_perm_scatter(S.rowmap, S.xp, x, S.ntasks, st));
     return 0;
+}
+
+int gs_sweep_csr(const Schedule &S, bool bsr1, double *x, const double *b, bool reverse, hipStream_t st)
+{
+    const unsigned char r = reverse ? 1 : 0;
+    return gs_sweep_csr(S, bsr1, x, b, &r, 1, st);
 }
 
 // one directional pass over the block rows of a schedule built WITH values (Schedule::Gb: the rows copied in level
@@ -784,6 +858,16 @@ static int relax(amg_hier *h, Level &L, Smoother &s, double *&x, double *&xalt, 
             return gs_sweep_csr(*s.sched, bsr && s.kind != AMG_SM_GAUSS_SEIDEL_INDEXED, x, b, reverse, st);
         };
         auto gs = [&](int iterations, int sweep) -> int {
+            if (!point_block && !h->comm) {
+                // all directional sweeps of this application in one call (level-order numbering entered once)
+                std::vector<unsigned char> seq;
+                for (int it = 0; it < iterations; ++it) {
+                    if (sweep == AMG_SWEEP_FORWARD) seq.push_back(0);
+                    else if (sweep == AMG_SWEEP_BACKWARD) seq.push_back(1);
+                    else { seq.push_back(0); seq.push_back(1); }
+                }
+                return gs_sweep_csr(*s.sched, bsr && s.kind != AMG_SM_GAUSS_SEIDEL_INDEXED, x, b, seq.data(), (int)seq.size(), st);
+            }
             for (int it = 0; it < iterations; ++it) {
                 if (sweep == AMG_SWEEP_FORWARD) CHK(sweep_once(false));
                 else if (sweep == AMG_SWEEP_BACKWARD) CHK(sweep_once(true));

@@ -26,15 +26,21 @@ struct Schedule {
     // maximal runs [first, last) of consecutive levels that are all narrow enough for ONE workgroup:
     // such a run is swept by a single launch (gs_chain_kernel) instead of one launch per level
     std::vector<std::pair<int, int>> chains;
+    std::vector<int> chain_width;      // threads of each chain's workgroup (64 .. 512, by its widest level)
     // The chained sweep's own copy of those runs (gs_chain2_kernel, kernels.hip): per level the rows' off-diagonal
     // entries padded to CHAIN2_PF slots and stored slot-major (coalesced, no row pointer), the diagonal and the row
-    // id per row, and for every entry an operand CODE per sweep direction: >= 0 the global column (the operand is
+    // per row, and for every entry an operand CODE per sweep direction: >= 0 the operand's level-order position (it is
     // final in memory long before it is needed and is prefetched), < 0 a slot of the workgroup's LDS ring (the
     // operand was produced by one of the last CHAIN2_D levels of this very launch).
     bool chain2 = false;
     int c2_pf = 0;                 // slots per row of the copy: 4, 8 or 12
-    int *c2_row = nullptr, *c2_code_f = nullptr, *c2_code_b = nullptr, *c2_off = nullptr;
+    int *c2_code_f = nullptr, *c2_code_b = nullptr, *c2_off = nullptr;
     double *c2_diag = nullptr, *c2_val = nullptr, *c2_dummy = nullptr;   // dummy: where idle lanes store (512 doubles)
+    // LEVEL-ORDER numbering (unknown k = k-th row of the schedule; only when the schedule lists every unknown once):
+    // the sweeps of the second-generation chain run on xp = x[rowmap], bp = b[rowmap] with G's columns renumbered
+    bool perm = false;
+    int *perm_Aj = nullptr;
+    double *xp = nullptr, *bp = nullptr;
     // BSR flavour: block rows listed in level order
     int *rows = nullptr;          // device
     DevBsr Gb;                    // BSR flavour with values: block rows copied in level order (streamed)

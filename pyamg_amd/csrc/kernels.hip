@@ -626,7 +626,7 @@ bool stream_pipe_enabled() { return g_stream_pipe != 0; }
 // so the per-level critical path is barrier -> gather x (L2) -> multiply-adds -> store, not the three
 // dependent memory round trips of a fresh launch.  Same per-row arithmetic as SM_GS / SM_GS_BSR1.
 // ---------------------------------------------------------------------------
-constexpr int CHAIN_WG = 1024;
+constexpr int CHAIN_WG = 512;         // widest level a chain takes; the launch picks 64 .. 512 threads by the run's widest level
 constexpr int CHAIN_PF = 12;         // entries of a row carried in registers through the pipeline
 constexpr int CHAIN_LMAX = 4096;     // levels per launch (their offsets sit in LDS)
 
@@ -638,14 +638,14 @@ constexpr int CHAIN_LMAX = 4096;     // levels per launch (their offsets sit in 
 //               from row pointers that were requested two iterations ago
 //   level q+3 : its row pointers (and row / diagonal positions) are requested; the level offsets they
 //               need come from LDS (loaded once), not from a dependent global load
-template <bool BSR1>
-__global__ __launch_bounds__(CHAIN_WG) void gs_chain_kernel(const int *Ap, const int *Aj, const double *Ax, const int *rowmap,
+template <bool BSR1, int WGS>
+__global__ __launch_bounds__(WGS) void gs_chain_kernel(const int *Ap, const int *Aj, const double *Ax, const int *rowmap,
                                                            const int *diagpos, double *x, const double *b,
                                                            const int *lp, int l_first, int nl, int reverse)
 {
     const int t = threadIdx.x;
     __shared__ int slp[CHAIN_LMAX + 1];
-    for (int k = t; k <= nl; k += CHAIN_WG) slp[k] = lp[l_first + k];
+    for (int k = t; k <= nl; k += WGS) slp[k] = lp[l_first + k];
     __syncthreads();
     auto level_of = [&](int q) { return reverse ? nl - 1 - q : q; };      // index into slp
 
@@ -740,8 +740,8 @@ __global__ __launch_bounds__(CHAIN_WG) void gs_chain_kernel(const int *Ap, const
 // Row sums run over the stored off-diagonal entries in stored order with separate multiply and add: bit-identical
 // to relaxation.h:34-62 / :90-173 (bs = 1) and to the level-per-launch path.
 // ---------------------------------------------------------------------------
-template <bool BSR1, int PF>
-__global__ __launch_bounds__(CHAIN2_WG) void gs_chain2_kernel(const int *crow, const double *cdiag, const double *cval,
+template <bool BSR1, int PF, int WGS>
+__global__ __launch_bounds__(WGS) void gs_chain2_kernel(const int *lp, const double *cdiag, const double *cval,
                                                              const int *ccode, const int *coff, double *x, const double *b,
                                                              double *dummy, int l_first, int nl, int reverse)
 {
@@ -754,10 +754,15 @@ __global__ __launch_bounds__(CHAIN2_WG) void gs_chain2_kernel(const int *crow, c
     // Every request is UNCONDITIONAL (idle lanes and the steps past the last level read harmless addresses): a load
     // inside a branch makes the number of outstanding requests path-dependent and the compiler then waits for all.
     constexpr int A = 2;
+    // x and b are numbered in LEVEL ORDER (the sweep runs on the gathered copies Schedule::xp / bp): the rows of a
+    // level are lp[l] .. lp[l+1]-1, so the right-hand side, the old value and the store are contiguous over the lanes,
+    // and an operand from a neighbouring level sits at a neighbouring position.  (Addressed by original row these
+    // were one cache line per lane and per access: the vector L1's tag rate, not latency, set the cost of a level.)
     __shared__ int soff[CHAIN2_LMAX + 1];
+    __shared__ int slp[CHAIN2_LMAX + 1];
     __shared__ double ring[NB * CHAIN2_WG];
     const int t = threadIdx.x;
-    for (int k = t; k <= nl; k += CHAIN2_WG) soff[k] = coff[l_first + k];
+    for (int k = t; k <= nl; k += WGS) { soff[k] = coff[l_first + k]; slp[k] = lp[l_first + k]; }
     __syncthreads();
 
     struct Codes { int arow; int at; int n; bool live; int code[PF]; };       // at = base + lane (clamped)
@@ -771,7 +776,7 @@ __global__ __launch_bounds__(CHAIN2_WG) void gs_chain2_kernel(const int *crow, c
         const int tt = min(t, c.n - 1);
         c.live = (q < nl) && (t < c.n);
         c.at = base + tt;
-        c.arow = crow[c.at];
+        c.arow = slp[l] + tt;
         const int *pc = ccode + ((size_t)PF * base + tt);          // slot u of this row: pc[u * n]
 #pragma unroll
         for (int u = 0; u < PF; ++u) { c.code[u] = *pc; pc += c.n; }
@@ -856,45 +861,85 @@ __global__ __launch_bounds__(CHAIN2_WG) void gs_chain2_kernel(const int *crow, c
     }
 }
 
-int launch_gs_chain2(const int *row, const double *diag, const double *val, const int *code, const int *off, double *dummy, int pf,
-                     int l_first, int nlevels, bool reverse, bool bsr1, double *x, const double *b, hipStream_t st)
+// threads per workgroup for a run whose widest level has `width` rows: the smallest of 64 .. 512 that covers it (idle
+// waves still issue every instruction of the pipeline, so a 40-row level is swept by ONE wave, not by eight)
+static int chain_threads(int width) { return width <= 64 ? 64 : (width <= 128 ? 128 : (width <= 256 ? 256 : 512)); }
+
+int launch_gs_chain2(const int *lp, const double *diag, const double *val, const int *code, const int *off, double *dummy, int pf,
+                     int l_first, int nlevels, int width, bool reverse, bool bsr1, double *x, const double *b, hipStream_t st)
 {
     if (nlevels <= 0) return 0;
     if (nlevels > CHAIN2_LMAX) { set_error("gs_chain2: run longer than one launch holds"); return -4; }
-#define C2_LAUNCH(B, P) hipLaunchKernelGGL((gs_chain2_kernel<B, P>), dim3(1), dim3(CHAIN2_WG), 0, st, row, diag, val, code, off, x, b, \
-                                           dummy, l_first, nlevels, reverse ? 1 : 0)
-    if (pf == 4) { if (bsr1) C2_LAUNCH(true, 4); else C2_LAUNCH(false, 4); }
-    else if (pf == 8) { if (bsr1) C2_LAUNCH(true, 8); else C2_LAUNCH(false, 8); }
-    else if (pf == 12) { if (bsr1) C2_LAUNCH(true, 12); else C2_LAUNCH(false, 12); }
+    if (width > CHAIN2_WG) { set_error("gs_chain2: level wider than the workgroup"); return -4; }
+    const int wg = chain_threads(width);
+#define C2_LAUNCH(B, P, W) hipLaunchKernelGGL((gs_chain2_kernel<B, P, W>), dim3(1), dim3(W), 0, st, lp, diag, val, code, off, x, b, \
+                                              dummy, l_first, nlevels, reverse ? 1 : 0)
+#define C2_WIDTH(B, P) do { if (wg == 64) C2_LAUNCH(B, P, 64); else if (wg == 128) C2_LAUNCH(B, P, 128); \
+                            else if (wg == 256) C2_LAUNCH(B, P, 256); else C2_LAUNCH(B, P, 512); } while (0)
+    if (pf == 4) { if (bsr1) C2_WIDTH(true, 4); else C2_WIDTH(false, 4); }
+    else if (pf == 8) { if (bsr1) C2_WIDTH(true, 8); else C2_WIDTH(false, 8); }
+    else if (pf == 12) { if (bsr1) C2_WIDTH(true, 12); else C2_WIDTH(false, 12); }
     else { set_error("gs_chain2: unsupported slot count"); return -1; }
+#undef C2_WIDTH
 #undef C2_LAUNCH
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "gs chain2 launch", __FILE__, __LINE__);
     return 0;
 }
 
-static int g_gs_chain = 1;       // 0: a launch per level, 1 (default): chain with operands gathered back from L2, 2: LDS hand-off chain (measured slower: instruction-bound)
+// level-order numbering of a scheduled sweep: xp[k] = x[rowmap[k]], bp[k] = b[rowmap[k]] before, x[rowmap[k]] = xp[k] after
+__global__ __launch_bounds__(256) void perm_gather_kernel(const int *rowmap, const double *x, const double *b, double *xp, double *bp, int n)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k < n) { const int i = rowmap[k]; xp[k] = x[i]; bp[k] = b[i]; }
+}
+__global__ __launch_bounds__(256) void perm_scatter_kernel(const int *rowmap, const double *xp, double *x, int n)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k < n) x[rowmap[k]] = xp[k];
+}
+int launch_perm_gather(const int *rowmap, const double *x, const double *b, double *xp, double *bp, int n, hipStream_t st)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(perm_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, st, rowmap, x, b, xp, bp, n);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "perm gather launch", __FILE__, __LINE__);
+    return 0;
+}
+int launch_perm_scatter(const int *rowmap, const double *xp, double *x, int n, hipStream_t st)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(perm_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, st, rowmap, xp, x, n);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "perm scatter launch", __FILE__, __LINE__);
+    return 0;
+}
+
+static int g_gs_chain = 2;       // 0: a launch per level, 1: chain with operands gathered back from L2, 2 (default): LDS hand-off chain (tools/gs_chain_ab.py)
 void set_gs_chain(int on) { g_gs_chain = on; ++g_config_epoch; }
 bool gs_chain_enabled() { return g_gs_chain != 0; }
 int gs_chain_generation() { return g_gs_chain >= 2 ? 2 : 1; }
 int gs_chain_max_rows() { return CHAIN_WG; }
 
 int launch_gs_chain(const DevCsr &G, const int *rowmap, const int *diagpos, const int *level_ptr_dev, int l_first,
-                    int nlevels, bool reverse, bool bsr1, double *x, const double *b, hipStream_t st)
+                    int nlevels, int width, bool reverse, bool bsr1, double *x, const double *b, hipStream_t st)
 {
     if (nlevels <= 0) return 0;
+    if (width > CHAIN_WG) { set_error("gs_chain: level wider than the workgroup"); return -4; }
+    const int wg = chain_threads(width);
     // at most CHAIN_LMAX levels per launch, pieces in sweep order
     const int npiece = (nlevels + CHAIN_LMAX - 1) / CHAIN_LMAX;
     for (int c = 0; c < npiece; ++c) {
         const int piece = reverse ? npiece - 1 - c : c;
         const int lf = l_first + piece * CHAIN_LMAX;
         const int cnt = std::min(CHAIN_LMAX, nlevels - piece * CHAIN_LMAX);
-        if (bsr1)
-            hipLaunchKernelGGL((gs_chain_kernel<true>), dim3(1), dim3(CHAIN_WG), 0, st, G.Ap, G.Aj, G.Ax, rowmap, diagpos, x, b,
-                               level_ptr_dev, lf, cnt, reverse ? 1 : 0);
-        else
-            hipLaunchKernelGGL((gs_chain_kernel<false>), dim3(1), dim3(CHAIN_WG), 0, st, G.Ap, G.Aj, G.Ax, rowmap, diagpos, x, b,
-                               level_ptr_dev, lf, cnt, reverse ? 1 : 0);
+#define C1_LAUNCH(B, W) hipLaunchKernelGGL((gs_chain_kernel<B, W>), dim3(1), dim3(W), 0, st, G.Ap, G.Aj, G.Ax, rowmap, diagpos, x, b, \
+                                           level_ptr_dev, lf, cnt, reverse ? 1 : 0)
+#define C1_WIDTH(B) do { if (wg == 64) C1_LAUNCH(B, 64); else if (wg == 128) C1_LAUNCH(B, 128); \
+                         else if (wg == 256) C1_LAUNCH(B, 256); else C1_LAUNCH(B, 512); } while (0)
+        if (bsr1) C1_WIDTH(true); else C1_WIDTH(false);
+#undef C1_WIDTH
+#undef C1_LAUNCH
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "gs chain launch", __FILE__, __LINE__);
