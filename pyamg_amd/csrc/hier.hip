@@ -515,7 +515,9 @@ int build_csr_schedule(const int *Ap, const int *Aj, const double *Ax, int n, co
         if (longest > CHAIN2_PF) ok = false;
         const int PFs = longest <= 4 ? 4 : (longest <= 8 ? 8 : 12);
         S.c2_pf = PFs;
-        std::vector<int> cf((size_t)total * PFs, CHAIN2_EMPTY), cb((size_t)total * PFs, CHAIN2_EMPTY);
+        if ((double)total * PFs * 8.0 >= 4.0e9 || (double)n * 8.0 >= 4.0e9) ok = false;     // the kernel addresses with 32-bit byte offsets
+        // padded slots: value 0, operand = the permanent 0.0 kept behind the last unknown of xp
+        std::vector<int> cf((size_t)total * PFs, n), cb((size_t)total * PFs, n);
         std::vector<double> cd((size_t)total, 0.0), cv((size_t)total * PFs, 0.0);
         for (int l = 0; l < nl && ok; ++l) {
             if (piece_of[(size_t)l] < 0) continue;
@@ -523,6 +525,7 @@ int build_csr_schedule(const int *Ap, const int *Aj, const double *Ax, int n, co
             for (int tt = 0; tt < cnt && ok; ++tt) {
                 const int k = S.level_ptr[l] + tt, i = rowmap[(size_t)k];
                 cd[(size_t)base + tt] = dpos[(size_t)k] >= 0 ? gx[(size_t)dpos[(size_t)k]] : 0.0;
+                if (cd[(size_t)base + tt] == 0.0) { ok = false; break; }    // a row that keeps its value (relaxation.h:58-60): first-generation chain
                 int u = 0;
                 for (int q = gp[(size_t)k]; q < gp[(size_t)k + 1]; ++q) {
                     const int c = gj[(size_t)q];
@@ -536,8 +539,8 @@ int build_csr_schedule(const int *Ap, const int *Aj, const double *Ax, int n, co
                         // produced within the last CHAIN2_D levels of the sweep: the operand is read from the ring
                         // buffer its level wrote, (level % (D + 1)) * 512 + position in the level
                         const int slot = (lvl_of[(size_t)c] % (CHAIN2_D + 1)) * CHAIN2_WG + pos_of[(size_t)c];
-                        if (dl >= 1 && dl <= CHAIN2_D) f = -1 - slot;
-                        if (-dl >= 1 && -dl <= CHAIN2_D) bk = -1 - slot;
+                        if (dl >= 1 && dl <= CHAIN2_D) f = ~(slot * 8);      // ~(byte offset into the ring)
+                        if (-dl >= 1 && -dl <= CHAIN2_D) bk = ~(slot * 8);
                     }
                     cf[at] = f; cb[at] = bk;
                     ++u;
@@ -561,7 +564,8 @@ int build_csr_schedule(const int *Ap, const int *Aj, const double *Ax, int n, co
             std::vector<int> pj(gj.size());
             for (size_t q = 0; q < gj.size(); ++q) pj[q] = inv[(size_t)gj[q]];
             CHK(dev_alloc(&S.perm_Aj, (long)pj.size(), (long *)nullptr));
-            CHK(dev_alloc(&S.xp, n, (long *)nullptr));
+            CHK(dev_alloc(&S.xp, (long)n + 1, (long *)nullptr));
+            AMG_HIP(hipMemset(S.xp, 0, sizeof(double) * ((size_t)n + 1)));       // xp[n] stays 0.0: the operand of padded slots
             CHK(dev_alloc(&S.bp, n, (long *)nullptr));
             AMG_HIP(hipMemcpy(S.perm_Aj, pj.data(), sizeof(int) * pj.size(), hipMemcpyHostToDevice));
             S.chain2 = true;

@@ -742,8 +742,8 @@ __global__ __launch_bounds__(WGS) void gs_chain_kernel(const int *Ap, const int 
 // ---------------------------------------------------------------------------
 template <bool BSR1, int PF, int WGS>
 __global__ __launch_bounds__(WGS) void gs_chain2_kernel(const int *lp, const double *cdiag, const double *cval,
-                                                             const int *ccode, const int *coff, double *x, const double *b,
-                                                             double *dummy, int l_first, int nl, int reverse)
+                                                       const int *ccode, const int *coff, double *x, const double *b,
+                                                       double *dummy, int l_first, int nl, int reverse)
 {
     constexpr int D = CHAIN2_D, NB = CHAIN2_D + 1;
     // Vector-memory results return in issue order, so whatever an iteration needs must have been requested at least
@@ -755,48 +755,59 @@ __global__ __launch_bounds__(WGS) void gs_chain2_kernel(const int *lp, const dou
     // inside a branch makes the number of outstanding requests path-dependent and the compiler then waits for all.
     constexpr int A = 2;
     // x and b are numbered in LEVEL ORDER (the sweep runs on the gathered copies Schedule::xp / bp): the rows of a
-    // level are lp[l] .. lp[l+1]-1, so the right-hand side, the old value and the store are contiguous over the lanes,
-    // and an operand from a neighbouring level sits at a neighbouring position.  (Addressed by original row these
-    // were one cache line per lane and per access: the vector L1's tag rate, not latency, set the cost of a level.)
+    // level are lp[l] .. lp[l+1]-1, so the right-hand side and the store are contiguous over the lanes, and an operand
+    // from a neighbouring level sits at a neighbouring position.  (Addressed by original row these were one cache line
+    // per lane and per access: the vector L1's tag rate, not latency, set the cost of a level.)
+    // A level is bound by its INSTRUCTION STREAM (every wave issues the whole pipeline), so the per-slot work is kept
+    // minimal: all addresses are 32-bit byte offsets from uniform bases, a slot's code is either the operand's
+    // position (>= 0; padded slots point at the permanent 0.0 behind the last unknown and carry the value 0, which
+    // leaves the running sum untouched bit for bit) or ~(byte offset into the LDS ring) (< 0).
     __shared__ int soff[CHAIN2_LMAX + 1];
     __shared__ int slp[CHAIN2_LMAX + 1];
-    __shared__ double ring[NB * CHAIN2_WG];
+    __shared__ double ring[NB * CHAIN2_WG + 1];               // + 1: what a slot without a ring operand reads
+    constexpr unsigned RING_BYTES = NB * CHAIN2_WG * 8u;
+    constexpr bool KEEP_LA = !(PF == 12 && WGS == 512);       // (that variant has no registers to spare for the ring addresses)
     const int t = threadIdx.x;
     for (int k = t; k <= nl; k += WGS) { soff[k] = coff[l_first + k]; slp[k] = lp[l_first + k]; }
+    if (t == 0) ring[NB * CHAIN2_WG] = 0.0;
     __syncthreads();
 
-    struct Codes { int arow; int at; int n; bool live; int code[PF]; };       // at = base + lane (clamped)
-    struct Stage { int row; int arow; int lvl; double d, bb, xold; int code[PF]; double val[PF]; double xv[PF]; };
+    auto at_bytes = [](const void *base, unsigned off) { return (const void *)((const char *)base + (size_t)off); };
+    struct Codes { unsigned at; int arow; int n; bool live; int code[PF]; };          // at = position in the copy (clamped lane)
+    struct Stage { int row; unsigned arow8; int lvl; double d, bb; int code[PF]; unsigned la[PF]; double val[PF]; double xv[PF]; };
     auto level_of = [&](int q) { return reverse ? nl - 1 - q : q; };
-    auto stage_a = [&](int q) -> Codes {           // row id and operand codes
+    auto stage_a = [&](int q) -> Codes {           // row position and operand codes
         Codes c;
         const int l = level_of(min(q, nl - 1));
         const int base = soff[l];
         c.n = soff[l + 1] - base;                  // >= 1: dependency levels are never empty
         const int tt = min(t, c.n - 1);
         c.live = (q < nl) && (t < c.n);
-        c.at = base + tt;
+        c.at = (unsigned)(base + tt);
         c.arow = slp[l] + tt;
-        const int *pc = ccode + ((size_t)PF * base + tt);          // slot u of this row: pc[u * n]
+        unsigned off = ((unsigned)PF * (unsigned)base + (unsigned)tt) * 4u;          // slot u of this row: + u * n * 4
+        const unsigned step = (unsigned)c.n * 4u;
 #pragma unroll
-        for (int u = 0; u < PF; ++u) { c.code[u] = *pc; pc += c.n; }
+        for (int u = 0; u < PF; ++u) { c.code[u] = *(const int *)at_bytes(ccode, off); off += step; }
         return c;
     };
     auto stage_b = [&](int q, const Codes &c) -> Stage {   // values, diagonal, right-hand side, settled operands
         Stage s;
         s.row = c.live ? c.arow : -1;
-        s.arow = c.arow;
+        s.arow8 = (unsigned)c.arow * 8u;
         s.lvl = l_first + level_of(min(q, nl - 1));
-        s.d = cdiag[c.at];
-        s.bb = b[c.arow];
-        s.xold = load_fresh(&x[c.arow]);           // what a row with a zero diagonal keeps (relaxation.h:58-60)
+        s.d = *(const double *)at_bytes(cdiag, c.at * 8u);
+        s.bb = *(const double *)at_bytes(b, s.arow8);
         const int tt = min(t, c.n - 1);
-        const double *pv = cval + ((size_t)PF * (c.at - tt) + tt);
+        unsigned off = ((unsigned)PF * (c.at - (unsigned)tt) + (unsigned)tt) * 8u;
+        const unsigned step = (unsigned)c.n * 8u;
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
             s.code[u] = c.code[u];
-            s.val[u] = *pv; pv += c.n;                                               // padded slots hold 0 and are never summed
-            s.xv[u] = load_fresh(&x[c.code[u] >= 0 ? c.code[u] : c.arow]);           // LDS / empty slots: a harmless address
+            if (KEEP_LA) s.la[u] = min(~(unsigned)c.code[u], RING_BYTES);     // where in the ring (the spare word if not there), off the critical path
+            s.val[u] = *(const double *)at_bytes(cval, off); off += step;
+            // a ring operand's slot requests position 0 (one line for the whole wave) and drops it
+            s.xv[u] = load_fresh((const double *)at_bytes(x, (unsigned)max(c.code[u], 0) * 8u));
         }
         return s;
     };
@@ -815,30 +826,28 @@ __global__ __launch_bounds__(WGS) void gs_chain2_kernel(const int *lp, const dou
     cq[0] = stage_a(3);
 
     auto compute = [&](Stage &cur) {
-        // operands produced by the last D levels come from the LDS ring (every lane reads, lanes without such an
-        // operand read slot 0 and drop it); no branch and no memory request in here besides the one store
-        double xo[PF];
+        // operands produced by the last D levels come from the LDS ring (every lane reads: a slot without one reads
+        // the spare word behind the ring and drops it); no branch and no memory request in here besides the one store
+        // (all ring reads are issued back to back and waited for once: one LDS latency per level, not one per slot)
+        double lv[PF], xo[PF];
+#pragma unroll
+        for (int u = 0; u < PF; ++u) lv[u] = *(const double *)((const char *)ring + (KEEP_LA ? cur.la[u] : min(~(unsigned)cur.code[u], RING_BYTES)));
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
-            const int code = cur.code[u];
-            const bool near = code < 0 && code != CHAIN2_EMPTY;
-            const double lv = ring[near ? (-1 - code) : 0];          // the code IS the ring slot (set at schedule build)
-            // a bitwise blend instead of `near ? lv : xv`: the compiler would sink the LDS read into a branch of its
-            // own (one read, one wait, per slot) if the value were only conditionally used
-            const long long m = near ? -1LL : 0LL;
-            xo[u] = __longlong_as_double((__double_as_longlong(lv) & m) | (__double_as_longlong(cur.xv[u]) & ~m));
+            // a bitwise blend instead of `code < 0 ? lv : xv`: the compiler would sink the LDS read into a branch of
+            // its own (one read, one wait, per slot) if the value were only conditionally used
+            const long long m = (long long)(cur.code[u] >> 31);
+            xo[u] = __longlong_as_double((__double_as_longlong(lv[u]) & m) | (__double_as_longlong(cur.xv[u]) & ~m));
         }
         double acc = BSR1 ? cur.bb : 0.0;
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
-            const double pr = cur.val[u] * xo[u];
-            const double nxt = BSR1 ? (acc - pr) : (acc + pr);
-            acc = (cur.code[u] == CHAIN2_EMPTY) ? acc : nxt;
+            const double pr = cur.val[u] * xo[u];                // padded slot: 0 * 0, the sum keeps its bits
+            acc = BSR1 ? (acc - pr) : (acc + pr);
         }
-        const double dd = (cur.d != 0.0) ? cur.d : 1.0;
-        const double q1 = BSR1 ? (acc / dd) : ((cur.bb - acc) / dd);
-        const double xn = (cur.d != 0.0) ? q1 : cur.xold;
-        double *dst = (cur.row >= 0) ? &x[cur.row] : &dummy[t];     // idle lanes store to a scratch line of their own
+        const double xn = BSR1 ? (acc / cur.d) : ((cur.bb - acc) / cur.d);      // no zero diagonals in a chained copy (declined at build)
+        double *dst = (cur.row >= 0) ? (double *)((char *)x + (size_t)cur.arow8) : &dummy[t];     // idle lanes store to a scratch line of their own
         *dst = xn;
         ring[(cur.lvl % NB) * CHAIN2_WG + t] = xn;
     };
