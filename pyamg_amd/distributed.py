@@ -37,6 +37,36 @@ def split_rows(n, world):
     return np.array([(n * p) // world for p in range(world + 1)], dtype=np.int64)
 
 
+def coarse_bounds(P, fine_bounds):
+    """Row partition of the next-coarser level that FOLLOWS the fine one through the prolongator: rank k's coarse
+    rows start at the coarse unknown its first fine row interpolates from most strongly (the aggregate that row sits
+    in for smoothed aggregation, the nearest C-point for classical interpolation).  Aggregates / C-points are numbered
+    in the order of the fine rows, so the fine rows [f_k, f_k+1) then interpolate almost only from [c_k, c_k+1) and
+    the halos of P, R and the coarse operator stay surface-sized, where an even split of the coarse rows drifts away
+    from the fine one by whole planes of the grid."""
+    Ap, Aj, Ax, _ = _csr_view(P)
+    n, nc = P.shape
+    world = len(fine_bounds) - 1
+    out = np.zeros(world + 1, dtype=np.int64)
+    out[world] = nc
+    for k in range(1, world):
+        f = int(fine_bounds[k])
+        c = nc
+        while f < n:                                   # first row at or after the cut that has entries
+            s, e = int(Ap[f]), int(Ap[f + 1])
+            if e > s:
+                c = int(Aj[s + int(np.argmax(np.abs(np.asarray(Ax[s:e]))))])
+                break
+            f += 1
+        out[k] = min(max(c, int(out[k - 1])), nc)
+    # where the coarse numbering does not follow the fine one (deep levels; aggregates formed in the clean-up pass
+    # are numbered last) the cut would starve some ranks: keep the even split there
+    even = split_rows(nc, world)
+    if np.any(np.abs(np.diff(out) - np.diff(even)) > 0.2 * np.maximum(np.diff(even), 1)):
+        return even
+    return out
+
+
 class _Lazy(object):
     """memory-mapped global CSR arrays with the small interface local_rows needs"""
 
@@ -196,7 +226,15 @@ class DistributedSolver(object):
         import os as _os
         self.overlap = _os.environ.get("AMG_DIST_OVERLAP", "1") != "0"
         self.nlevels = len(levels)
-        self.bounds = [split_rows(L["A"].shape[0], world) for L in levels]
+        # level 0 is cut evenly; every coarser level follows the cut of the level above through P (coarse_bounds).
+        # AMG_DIST_EVEN_SPLIT=1 cuts every level evenly instead (the round-1 behaviour, kept for A/B).
+        self.bounds = [split_rows(levels[0]["A"].shape[0], world)]
+        even = _os.environ.get("AMG_DIST_EVEN_SPLIT", "0") != "0"
+        for l in range(1, self.nlevels):
+            if even or levels[l - 1].get("P") is None:
+                self.bounds.append(split_rows(levels[l]["A"].shape[0], world))
+            else:
+                self.bounds.append(coarse_bounds(levels[l - 1]["P"], self.bounds[l - 1]))
         # Coarse levels at or below `replicate_below` unknowns are REPLICATED: every rank holds them
         # whole and computes them redundantly (bit-identical everywhere), so they need no halo
         # exchange at all -- one all-gather of the restricted right-hand side enters the replicated

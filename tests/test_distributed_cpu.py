@@ -156,7 +156,7 @@ def _worker_hybrid(rank, world, port, case, out_dir, rep=0):
 
 
 def hybrid_bounds(g, world, rep):
-    """partition of every level as DistributedSolver makes it: split rows, except that levels at or
+    """partition of every level as DistributedSolver makes it: contiguous row blocks, except that levels at or
     below `rep` unknowns (from the first such level down) are replicated = one block"""
     from pyamg_amd.distributed import split_rows
     sizes = [L["A"].shape[0] for L in g["levels"]]
@@ -166,7 +166,12 @@ def hybrid_bounds(g, world, rep):
             first_rep = l
         else:
             break
-    return [split_rows(n, world) if l < first_rep else np.array([0, n]) for l, n in enumerate(sizes)]
+    # level 0 evenly, every coarser partitioned level following the level above through P (distributed.coarse_bounds)
+    from pyamg_amd.distributed import coarse_bounds
+    bounds = [split_rows(sizes[0], world)]
+    for l in range(1, len(sizes)):
+        bounds.append(coarse_bounds(g["levels"][l - 1]["P"], bounds[l - 1]))
+    return [bounds[l] if l < first_rep else np.array([0, n]) for l, n in enumerate(sizes)]
 
 
 @pytest.mark.parametrize("case,rep", [("sa_gs_3d", 0), ("rs_gs_2d", 0), ("rs_gs_2d", 450)])
@@ -186,3 +191,26 @@ def test_hybrid_gauss_seidel_matches_partition_emulation(case, rep, tmp_path):
     xs, _ = H.solve(g["b"], tol=0.0, maxiter=3)
     assert not np.array_equal(x, xs)
     assert np.linalg.norm(x - xs) < 0.5 * np.linalg.norm(xs)
+
+
+def test_coarse_bounds_follow_the_prolongator():
+    """distributed.coarse_bounds: a coarse cut that follows the fine cut through P never needs more off-rank
+    columns of P than the even split does by more than a few rows, stays balanced, and degenerates to the even
+    split where the coarse numbering does not follow the fine one"""
+    import scipy.sparse as sp
+    from pyamg_amd.distributed import coarse_bounds, split_rows
+    g = golden_io.load_hier("sa_gs_3d")
+    P = g["levels"][0]["P"]
+    n, nc = P.shape
+    for world in (2, 3, 4):
+        fb = split_rows(n, world)
+        cb = coarse_bounds(P, fb)
+        assert cb[0] == 0 and cb[-1] == nc and np.all(np.diff(cb) >= 0)
+        even = split_rows(nc, world)
+        assert np.all(np.abs(np.diff(cb) - np.diff(even)) <= 0.2 * np.diff(even) + 1)
+    # a prolongator whose columns run AGAINST the rows: the cut falls back to the even split
+    Prev = sp.csr_matrix((np.ones(12), (np.arange(12), 5 - np.arange(12) // 2)), shape=(12, 6))
+    assert np.array_equal(coarse_bounds(Prev, split_rows(12, 3)), split_rows(6, 3))
+    # aggregates in row order: the cut is exactly the aggregate boundary of the first row of each rank
+    Pfwd = sp.csr_matrix((np.ones(12), (np.arange(12), np.arange(12) // 2)), shape=(12, 6))
+    assert np.array_equal(coarse_bounds(Pfwd, np.array([0, 4, 8, 12])), np.array([0, 2, 4, 6]))
