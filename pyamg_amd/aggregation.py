@@ -50,6 +50,14 @@ def host_lib():
         L.amgsetup_gauss_seidel.restype = None
         L.amgsetup_block_gauss_seidel.argtypes = [ip, ip, dp, dp, dp, dp, C.c_int, C.c_int, C.c_int, C.c_int]
         L.amgsetup_block_gauss_seidel.restype = None
+        L.amgsetup_csr_sort_rows.argtypes = [C.c_int, lp, ip, dp]
+        L.amgsetup_csr_sort_rows.restype = C.c_long
+        L.amgsetup_csr_diagonal_inv.argtypes = [C.c_int, lp, ip, dp, dp]
+        L.amgsetup_csr_diagonal_inv.restype = None
+        L.amgsetup_gauss_seidel_pipelined.argtypes = [ip, ip, dp, dp, dp, C.c_int, C.c_int, C.c_int]
+        L.amgsetup_gauss_seidel_pipelined.restype = C.c_int
+        L.amgsetup_block_gauss_seidel_pipelined.argtypes = [ip, ip, dp, dp, dp, dp, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.amgsetup_block_gauss_seidel_pipelined.restype = C.c_int
         L.amgsetup_csr_matmat_count.argtypes = [C.c_int, C.c_int, lp, ip, lp, ip, lp]
         L.amgsetup_csr_matmat_count.restype = C.c_int64
         L.amgsetup_csr_matmat_fill.argtypes = [C.c_int, C.c_int, lp, ip, dp, lp, ip, dp, lp, ip, dp]
@@ -399,22 +407,46 @@ def _improve(method, A, B):
                 L.amgsetup_block_gauss_seidel(_ip(Ap), _ip(Aj), _dp(Ax), _dp(x), _dp(b), _dp(Dinv), 0, nb, 1, bs)
     else:
         raise NotImplementedError("improve_candidates=%r on this matrix is outside the restated setup" % (fn,))
-    def relax_column(j):
-        x = np.ascontiguousarray(B[:, j], dtype=np.float64).copy()
-        for it in range(its):
-            if sw in ("forward", "symmetric"):
-                sweep(x, False)
-            if sw in ("backward", "symmetric"):
-                sweep(x, True)
-        out[:, j] = x
+    sweep_code = {"forward": 0, "backward": 1, "symmetric": 2}.get(sw)
 
-    if B.shape[1] > 1 and n > 100000:
+    def relax_column(j, pipelined_ok=False):
+        x = np.array(B[:, j], dtype=np.float64, order="C")
+        ran = 0
+        if pipelined_ok and sweep_code is not None:
+            # all sweeps of this column by several host threads that trail each other chunk by chunk
+            # (setup_host.cpp: pipelined_sweep) -- the sequential result; 0 = the operator does not qualify
+            if desc["name"] == "gauss_seidel":
+                ran = L.amgsetup_gauss_seidel_pipelined(_ip(Ap), _ip(Aj), _dp(Ax), _dp(x), _dp(b), n, sweep_code, its)
+            else:
+                ran = L.amgsetup_block_gauss_seidel_pipelined(_ip(Ap), _ip(Aj), _dp(Ax), _dp(x), _dp(b), _dp(Dinv),
+                                                              nb, bs, sweep_code, its)
+        if not ran:
+            for it in range(its):
+                if sw in ("forward", "symmetric"):
+                    sweep(x, False)
+                if sw in ("backward", "symmetric"):
+                    sweep(x, True)
+        out[:, j] = x
+        return ran
+
+    if n > 100000 and os.environ.get("AMG_SETUP_PIPELINED_GS", "1") != "0":
+        # first column through the pipelined sweep; if the operator qualifies, so do the others
+        if relax_column(0, True):
+            for j in range(1, B.shape[1]):
+                relax_column(j, True)
+            return out
+        first = 1
+    else:
+        first = 0
+    if first >= B.shape[1]:
+        return out
+    if B.shape[1] - first > 1 and n > 100000:
         # the candidates are relaxed independently (each sweep is sequential): one host thread per column
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(max_workers=min(B.shape[1], 8)) as pool:
-            list(pool.map(relax_column, range(B.shape[1])))
+            list(pool.map(relax_column, range(first, B.shape[1])))
     else:
-        for j in range(B.shape[1]):
+        for j in range(first, B.shape[1]):
             relax_column(j)
     return out
 
@@ -457,13 +489,20 @@ def smoothed_aggregation_solver(A, B=None, BH=None, symmetry="hermitian", streng
                                           else improve_candidates, max_levels)
     smooth = _levelize_smooth(smooth, max_levels)
 
+    verbose = os.environ.get("AMG_SETUP_VERBOSE", "0") != "0"
+    t0 = time.perf_counter()
     levels = [multilevel_solver.level()]
     levels[-1].A = A
     levels[-1].B = B
     while len(levels) < max_levels and int(levels[-1].A.shape[0] / blocksize(levels[-1].A)) > max_coarse:
         extend_hierarchy(levels, strength, aggregate, smooth, improve_candidates, keep or not fast)
+    t1 = time.perf_counter()
     ml = multilevel_solver(levels, **kwargs)
+    t2 = time.perf_counter()
     change_smoothers(ml, presmoother, postsmoother)
+    if verbose:
+        print("[setup] levels %.2fs, multilevel_solver (coarse solver) %.2fs, smoothers %.2fs"
+              % (t1 - t0, t2 - t1, time.perf_counter() - t2), flush=True)
     return ml
 
 
@@ -581,7 +620,18 @@ def _extend_scalar(levels, smooth_l, keep, rho_fn):
     fn, kw = unpack_arg(smooth_l)
     omega = kw.get("omega", 4.0 / 3.0)
     lap("tentative prolongator")
-    D_inv = get_diagonal(A, inv=True)
+    # get_diagonal(A, inv=True), row-parallel on the flat arrays -- including its side effect: the reference sorts
+    # A's rows in place here (util/utils.py:566), so everything from here on sees the sorted order
+    if Aj.ctypes.data == A.indices.ctypes.data and Ax.ctypes.data == A.data.ctypes.data and Ax.size == A.data.size \
+            and Aj.flags.writeable and Ax.flags.writeable:
+        L.amgsetup_csr_sort_rows(n, _lp(Ap), _ip(Aj), _dp(Ax))
+        A.has_sorted_indices = True
+    else:
+        A.sort_indices()
+        Ap, Aj, Ax = _csr_arrays64(A)
+    D_inv = np.empty(n, dtype=np.float64)
+    L.amgsetup_csr_diagonal_inv(n, _lp(Ap), _ip(Aj), _dp(Ax), _dp(D_inv))
+    lap("diagonal")
     rho = rho_fn(A, D_inv)
     lap("rho(D^-1 A)")
     w = omega / rho
@@ -618,6 +668,7 @@ def _extend_scalar(levels, smooth_l, keep, rho_fn):
     Anew.symmetry = A.symmetry
     levels[-1].A = Anew
     levels[-1].B = Bc.reshape(-1, 1)
+    lap("wrap as BSR(1,1)")
 
 
 def _block_fast_path_ok(A, B, strength_l, aggregate_l, smooth_l):

@@ -4,6 +4,7 @@
 // reference: they restate the setup kernels the BASELINE configurations need.
 // All reference paths relative to /root/reference.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -300,6 +301,204 @@ static void transpose_pattern(int n_row, int n_col, const int64_t *Ap, const int
             }
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Sequential sweeps (Gauss-Seidel family) run by several host threads with the SEQUENTIAL result.
+// The rows are cut into chunks of `chunk` consecutive rows which the threads claim in sweep order; inside a
+// chunk a thread runs the rows in sweep order, and before a row it waits until every row that comes EARLIER in
+// the sweep and shares an entry with it (a_ij != 0 with j in an earlier chunk) has been finished by its thread
+// (per-chunk progress counters, published every few rows).  On a structurally symmetric matrix those are all the
+// conflicts there are: an earlier row that READS x_i is one that row i reads, so it is waited for before x_i is
+// overwritten, and a later row that reads x_i waits for row i.  Every row therefore sees exactly the values the
+// one-thread loop would give it.  No deadlock: chunks are claimed in sweep order, a thread only ever waits for
+// chunks claimed before its own.
+// With chunk = the matrix bandwidth, the chunks of a lexicographically numbered grid operator are its planes (rows
+// of a 2-D grid): the thread on plane z+1 trails the thread on plane z by one publication interval.  On other
+// numberings the sweep is still exact, only less concurrent.
+// ---------------------------------------------------------------------------------------------------------
+template <class RowOp>
+static void pipelined_sweep(const int *Ap, const int *Aj, int n, bool reverse, int chunk, int nthreads, RowOp row_op)
+{
+    const int nchunks = (n + chunk - 1) / chunk;
+    std::vector<std::atomic<int>> done((size_t)nchunks);
+    for (auto &d : done) d.store(0, std::memory_order_relaxed);
+    std::atomic<int> next(0);
+    const int publish = std::max(8, std::min(256, chunk / 64));
+#pragma omp parallel num_threads(nthreads)
+    {
+        int seen_chunk[2] = {-1, -1}, seen_done[2] = {0, 0};          // what this thread last read of other chunks
+        for (;;) {
+            const int k = next.fetch_add(1, std::memory_order_relaxed);   // k-th chunk of the sweep
+            if (k >= nchunks) break;
+            const int c = reverse ? nchunks - 1 - k : k;
+            const int lo = c * chunk, hi = std::min(n, lo + chunk);
+            const int cnt = hi - lo;
+            for (int p = 0; p < cnt; ++p) {
+                const int i = reverse ? hi - 1 - p : lo + p;
+                for (int jj = Ap[i]; jj < Ap[i + 1]; ++jj) {
+                    const int j = Aj[jj];
+                    if (reverse ? (j < hi) : (j >= lo)) continue;           // own chunk, or later in the sweep
+                    const int cj = j / chunk;
+                    const int cj_hi = std::min(n, (cj + 1) * chunk);
+                    const int need = reverse ? cj_hi - j : j - cj * chunk + 1;   // rows of chunk cj that must be done
+                    int slot = (seen_chunk[0] == cj) ? 0 : ((seen_chunk[1] == cj) ? 1 : -1);
+                    if (slot < 0) { slot = (seen_chunk[0] == -1 || seen_done[0] >= chunk) ? 0 : 1; seen_chunk[slot] = cj; seen_done[slot] = 0; }
+                    while (seen_done[slot] < need) {
+                        seen_done[slot] = done[(size_t)cj].load(std::memory_order_acquire);
+                        if (seen_done[slot] < need) {
+#if defined(__x86_64__)
+                            __builtin_ia32_pause();
+#endif
+                        }
+                    }
+                }
+                row_op(i);
+                if (((p + 1) % publish) == 0) done[(size_t)c].store(p + 1, std::memory_order_release);
+            }
+            done[(size_t)c].store(cnt, std::memory_order_release);
+        }
+    }
+}
+
+// every entry (i, j) has its mirror (j, i): what the pipelined sweeps rely on
+static bool pattern_symmetric(const int *Ap, const int *Aj, int n)
+{
+    int bad = 0;
+#pragma omp parallel for schedule(static) reduction(| : bad)
+    for (int i = 0; i < n; ++i) {
+        if (bad) continue;
+        for (int jj = Ap[i]; jj < Ap[i + 1]; ++jj) {
+            const int j = Aj[jj];
+            if (j < 0 || j >= n) { bad = 1; break; }
+            if (j == i) continue;
+            bool found = false;
+            for (int kk = Ap[j]; kk < Ap[j + 1]; ++kk)
+                if (Aj[kk] == i) { found = true; break; }
+            if (!found) { bad = 1; break; }
+        }
+    }
+    return bad == 0;
+}
+
+static int bandwidth_of(const int *Ap, const int *Aj, int n)
+{
+    int bw = 0;
+#pragma omp parallel for schedule(static) reduction(max : bw)
+    for (int i = 0; i < n; ++i)
+        for (int jj = Ap[i]; jj < Ap[i + 1]; ++jj) bw = std::max(bw, std::abs(Aj[jj] - i));
+    return bw;
+}
+
+extern "C" {
+
+// get_diagonal(A, inv=True) (util/utils.py:526-588) on flat CSR arrays, row-parallel: duplicates of the diagonal
+// entry are summed in stored order as scipy's csr_diagonal does, a zero diagonal inverts to 0
+void amgsetup_csr_diagonal_inv(int n, const int64_t *Ap, const int *Aj, const double *Ax, double *dinv)
+{
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; ++i) {
+        double d = 0.0;
+        for (int64_t k = Ap[i]; k < Ap[i + 1]; ++k)
+            if (Aj[k] == i) d += Ax[k];
+        dinv[i] = (d != 0.0) ? 1.0 / d : 0.0;
+    }
+}
+
+// A.sort_indices() on flat CSR arrays (no duplicate columns), in place, row-parallel.  Returns the number of rows
+// that were out of order.
+long amgsetup_csr_sort_rows(int n, const int64_t *Ap, int *Aj, double *Ax)
+{
+    long unsorted = 0;
+#pragma omp parallel for schedule(dynamic, 4096) reduction(+ : unsorted)
+    for (int i = 0; i < n; ++i) {
+        const int64_t s = Ap[i], e = Ap[i + 1];
+        bool sorted = true;
+        for (int64_t k = s + 1; k < e; ++k)
+            if (Aj[k] < Aj[k - 1]) { sorted = false; break; }
+        if (sorted) continue;
+        ++unsorted;
+        for (int64_t k = s + 1; k < e; ++k) {               // insertion sort: rows are short
+            const int c = Aj[k];
+            const double v = Ax[k];
+            int64_t q = k - 1;
+            while (q >= s && Aj[q] > c) { Aj[q + 1] = Aj[q]; Ax[q + 1] = Ax[q]; --q; }
+            Aj[q + 1] = c; Ax[q + 1] = v;
+        }
+    }
+    return unsorted;
+}
+
+// `iterations` sweeps ("forward" 0, "backward" 1, "symmetric" 2 = forward then backward) of the block Gauss-Seidel
+// of relaxation.h:756-810 (bs = 1: Dinv holds the inverted diagonal) by several threads, bit-identical to the same
+// calls of amgsetup_block_gauss_seidel.  Returns 1 when it ran, 0 when the operator does not qualify (small,
+// narrow band or structurally unsymmetric): the caller then runs the one-thread loop.
+int amgsetup_block_gauss_seidel_pipelined(const int *Ap, const int *Aj, const double *Ax, double *x, const double *b,
+                                          const double *Dinv, int nb, int bs, int sweep, int iterations)
+{
+    const int T = std::min(omp_get_max_threads(), 32);
+    if (T < 2 || nb < 200000) return 0;
+    const int bw = bandwidth_of(Ap, Aj, nb);
+    if (bw < 256 || (long)bw * 2 > nb) return 0;              // at least two chunks in flight, chunks worth a hand-off
+    if (!pattern_symmetric(Ap, Aj, nb)) return 0;
+    const int B2 = bs * bs;
+    auto row_op = [&](int i) {
+        double rsum[16], v[16];
+        for (int k = 0; k < bs; ++k) rsum[k] = 0.0;
+        for (int jj = Ap[i]; jj < Ap[i + 1]; jj++) {
+            const int j = Aj[jj];
+            if (i == j) continue;
+            const double *blk = Ax + (int64_t)jj * B2;
+            const double *xj = x + (int64_t)j * bs;
+            for (int r = 0; r < bs; r++) {
+                double sacc = 0.0;
+                for (int c = 0; c < bs; c++) sacc += blk[r * bs + c] * xj[c];
+                v[r] = sacc;
+            }
+            for (int k = 0; k < bs; k++) rsum[k] += v[k];
+        }
+        const int64_t ib = (int64_t)i * bs;
+        for (int k = 0; k < bs; k++) rsum[k] = b[ib + k] - rsum[k];
+        const double *D = Dinv + (int64_t)i * B2;
+        for (int r = 0; r < bs; r++) {
+            double sacc = 0.0;
+            for (int c = 0; c < bs; c++) sacc += D[r * bs + c] * rsum[c];
+            x[ib + r] = sacc;
+        }
+    };
+    if (bs > 16) return 0;
+    for (int it = 0; it < iterations; ++it) {
+        if (sweep == 0 || sweep == 2) pipelined_sweep(Ap, Aj, nb, false, bw, T, row_op);
+        if (sweep == 1 || sweep == 2) pipelined_sweep(Ap, Aj, nb, true, bw, T, row_op);
+    }
+    return 1;
+}
+
+// the same for the point sweep of relaxation.h:34-62 (amgsetup_gauss_seidel)
+int amgsetup_gauss_seidel_pipelined(const int *Ap, const int *Aj, const double *Ax, double *x, const double *b,
+                                    int n, int sweep, int iterations)
+{
+    const int T = std::min(omp_get_max_threads(), 32);
+    if (T < 2 || n < 200000) return 0;
+    const int bw = bandwidth_of(Ap, Aj, n);
+    if (bw < 256 || (long)bw * 2 > n) return 0;
+    if (!pattern_symmetric(Ap, Aj, n)) return 0;
+    auto row_op = [&](int i) {
+        double rsum = 0, diag = 0;
+        for (int jj = Ap[i]; jj < Ap[i + 1]; jj++) {
+            const int j = Aj[jj];
+            if (i == j) diag = Ax[jj];
+            else rsum += Ax[jj] * x[j];
+        }
+        if (diag != 0.0) x[i] = (b[i] - rsum) / diag;
+    };
+    for (int it = 0; it < iterations; ++it) {
+        if (sweep == 0 || sweep == 2) pipelined_sweep(Ap, Aj, n, false, bw, T, row_op);
+        if (sweep == 1 || sweep == 2) pipelined_sweep(Ap, Aj, n, true, bw, T, row_op);
+    }
+    return 1;
+}
+
+}   // extern "C"
 
 extern "C" {
 

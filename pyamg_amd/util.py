@@ -312,9 +312,14 @@ def approximate_spectral_radius_device(A, dinv=None, tol=0.01, maxiter=15, resta
     Arnoldi iterations on the GPU.  Same restart logic and the same single np.random.rand(n, 1)
     draw as the reference; dots/norms are device reductions, so rho agrees to rounding, not bitwise."""
     _check_estimate_arguments(A, maxiter, restart)
+    import os, time
+    verbose = os.environ.get("AMG_SETUP_VERBOSE", "0") != "0"
+    t0 = time.perf_counter()
     op = device_operator(A)
+    t1 = time.perf_counter()
     n = A.shape[0]
     v0 = np.random.rand(n, 1).ravel()
+    t2 = time.perf_counter()
     breakdown_tol = np.finfo(float).eps * 1e6
     ev = None
     max_index = 0
@@ -332,4 +337,7 @@ def approximate_spectral_radius_device(A, dinv=None, tol=0.01, maxiter=15, resta
             coef = coef.real
         v0 = op.combine(coef)
     op.free_workspace()          # the Krylov basis ((maxiter + 1) n doubles) is only needed during the estimate
+    if verbose:
+        print("[setup]   spectral radius (%d rows): operator in HBM %.2fs, random start %.2fs, %d Arnoldi pass(es) %.2fs"
+              % (n, t1 - t0, t2 - t1, j + 1, time.perf_counter() - t2), flush=True)
     return float(np.abs(ev[max_index]))
