@@ -50,8 +50,6 @@ def host_lib():
         L.amgsetup_gauss_seidel.restype = None
         L.amgsetup_block_gauss_seidel.argtypes = [ip, ip, dp, dp, dp, dp, C.c_int, C.c_int, C.c_int, C.c_int]
         L.amgsetup_block_gauss_seidel.restype = None
-        L.amgsetup_csr_sort_rows.argtypes = [C.c_int, lp, ip, dp]
-        L.amgsetup_csr_sort_rows.restype = C.c_long
         L.amgsetup_csr_diagonal_inv.argtypes = [C.c_int, lp, ip, dp, dp]
         L.amgsetup_csr_diagonal_inv.restype = None
         L.amgsetup_gauss_seidel_pipelined.argtypes = [ip, ip, dp, dp, dp, C.c_int, C.c_int, C.c_int]
@@ -624,7 +622,7 @@ def _extend_scalar(levels, smooth_l, keep, rho_fn):
     # A's rows in place here (util/utils.py:566), so everything from here on sees the sorted order
     if Aj.ctypes.data == A.indices.ctypes.data and Ax.ctypes.data == A.data.ctypes.data and Ax.size == A.data.size \
             and Aj.flags.writeable and Ax.flags.writeable:
-        L.amgsetup_csr_sort_rows(n, _lp(Ap), _ip(Aj), _dp(Ax))
+        L.amgsetup_csr_sort_indices(n, _lp(Ap), _ip(Aj), _dp(Ax))
         A.has_sorted_indices = True
     else:
         A.sort_indices()

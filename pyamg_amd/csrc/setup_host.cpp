@@ -404,30 +404,6 @@ void amgsetup_csr_diagonal_inv(int n, const int64_t *Ap, const int *Aj, const do
     }
 }
 
-// A.sort_indices() on flat CSR arrays (no duplicate columns), in place, row-parallel.  Returns the number of rows
-// that were out of order.
-long amgsetup_csr_sort_rows(int n, const int64_t *Ap, int *Aj, double *Ax)
-{
-    long unsorted = 0;
-#pragma omp parallel for schedule(dynamic, 4096) reduction(+ : unsorted)
-    for (int i = 0; i < n; ++i) {
-        const int64_t s = Ap[i], e = Ap[i + 1];
-        bool sorted = true;
-        for (int64_t k = s + 1; k < e; ++k)
-            if (Aj[k] < Aj[k - 1]) { sorted = false; break; }
-        if (sorted) continue;
-        ++unsorted;
-        for (int64_t k = s + 1; k < e; ++k) {               // insertion sort: rows are short
-            const int c = Aj[k];
-            const double v = Ax[k];
-            int64_t q = k - 1;
-            while (q >= s && Aj[q] > c) { Aj[q + 1] = Aj[q]; Ax[q + 1] = Ax[q]; --q; }
-            Aj[q + 1] = c; Ax[q + 1] = v;
-        }
-    }
-    return unsorted;
-}
-
 // `iterations` sweeps ("forward" 0, "backward" 1, "symmetric" 2 = forward then backward) of the block Gauss-Seidel
 // of relaxation.h:756-810 (bs = 1: Dinv holds the inverted diagonal) by several threads, bit-identical to the same
 // calls of amgsetup_block_gauss_seidel.  Returns 1 when it ran, 0 when the operator does not qualify (small,
