@@ -270,29 +270,51 @@ static std::vector<int> split_by_entries(int n_row, const int64_t *Ap, int parts
 
 // Counting-sort transpose in parallel: thread p counts the columns of its row range, the per-column offsets are the
 // prefix over (column, thread) -- so entries of one output row still come in ascending source row (threads own
-// ascending row ranges), exactly csr_tocsc's order -- then every thread scatters its own rows.  width = values per entry.
+// ascending row ranges), exactly csr_tocsc's order -- then every thread scatters its own rows.
+// Each thread keeps counters only for the column WINDOW its rows touch (a prolongator's rows reach a narrow range of
+// aggregates), allocated and zeroed by the thread itself: about n_col counters in total instead of threads * n_col.
 template <class Scatter>
 static void transpose_pattern(int n_row, int n_col, const int64_t *Ap, const int *Aj, int64_t *Bp, int *Bi, Scatter put)
 {
     int parts = omp_get_max_threads();
-    if ((int64_t)parts * n_col > (int64_t)1 << 31) parts = std::max(1, (int)(((int64_t)1 << 31) / std::max(n_col, 1)));   // <= 16 GB of counters
     if (Ap[n_row] < 1000000) parts = 1;
     const std::vector<int> cut = split_by_entries(n_row, Ap, parts);
-    std::vector<int64_t> cnt((size_t)parts * (size_t)n_col, 0);
+    std::vector<std::vector<int64_t>> win((size_t)parts);
+    std::vector<int> wlo((size_t)parts, 0), whi((size_t)parts, 0);           // window [wlo, whi) of thread p
 #pragma omp parallel for schedule(static, 1) num_threads(parts)
     for (int p = 0; p < parts; p++) {
-        int64_t *c = cnt.data() + (size_t)p * n_col;
-        for (int64_t k = Ap[cut[(size_t)p]]; k < Ap[cut[(size_t)p + 1]]; k++) c[Aj[k]]++;
+        const int64_t k0 = Ap[cut[(size_t)p]], k1 = Ap[cut[(size_t)p + 1]];
+        int lo = n_col, hi = -1;
+        for (int64_t k = k0; k < k1; k++) { const int c = Aj[k]; lo = std::min(lo, c); hi = std::max(hi, c); }
+        if (hi < lo) { lo = 0; hi = -1; }
+        wlo[(size_t)p] = lo; whi[(size_t)p] = hi + 1;
+        win[(size_t)p].assign((size_t)(hi + 1 - lo), 0);
+        int64_t *c = win[(size_t)p].data() - lo;
+        for (int64_t k = k0; k < k1; k++) c[Aj[k]]++;
     }
+    // entries per output row, then the row pointer
     Bp[0] = 0;
-    for (int c = 0; c < n_col; c++) {                    // prefix over (column, thread); cnt becomes the start offset
+#pragma omp parallel for schedule(static)
+    for (int c = 0; c < n_col; c++) {
+        int64_t tot = 0;
+        for (int p = 0; p < parts; p++)
+            if (c >= wlo[(size_t)p] && c < whi[(size_t)p]) tot += win[(size_t)p][(size_t)(c - wlo[(size_t)p])];
+        Bp[c + 1] = tot;
+    }
+    for (int c = 0; c < n_col; c++) Bp[c + 1] += Bp[c];
+    // where thread p starts writing in output row c: after the threads with earlier rows
+#pragma omp parallel for schedule(static)
+    for (int c = 0; c < n_col; c++) {
         int64_t run = Bp[c];
-        for (int p = 0; p < parts; p++) { int64_t v = cnt[(size_t)p * n_col + c]; cnt[(size_t)p * n_col + c] = run; run += v; }
-        Bp[c + 1] = run;
+        for (int p = 0; p < parts; p++)
+            if (c >= wlo[(size_t)p] && c < whi[(size_t)p]) {
+                int64_t &w = win[(size_t)p][(size_t)(c - wlo[(size_t)p])];
+                const int64_t v = w; w = run; run += v;
+            }
     }
 #pragma omp parallel for schedule(static, 1) num_threads(parts)
     for (int p = 0; p < parts; p++) {
-        int64_t *cur = cnt.data() + (size_t)p * n_col;
+        int64_t *cur = win[(size_t)p].data() - wlo[(size_t)p];
         for (int i = cut[(size_t)p]; i < cut[(size_t)p + 1]; i++)
             for (int64_t k = Ap[i]; k < Ap[i + 1]; k++) {
                 const int64_t d = cur[Aj[k]]++;
