@@ -380,10 +380,10 @@ void amg_set_xcd_period(int on);
 /* 1 (default): operators whose rows are subsets of one stencil of <= 32 offsets are applied from
  * the stencil form (padded values + row masks, no indices); 0: from the pattern / CSR forms */
 void amg_set_stencil_form(int on);
-/* runs of narrow Gauss-Seidel dependency levels are swept by one workgroup in one launch: 1 (default) operands
- * gathered back from L2 after each barrier; 2 new values handed from level to level through LDS and everything else
- * requested two levels ahead (measured slower on MI355X: the per-level instruction stream, not latency, bounds it);
- * 0: one launch per level.  Same bits. */
+/* runs of narrow Gauss-Seidel dependency levels are swept by one workgroup in one launch: 2 (default) the sweep runs
+ * in level-order numbering, new values are handed from level to level through LDS and everything else is requested
+ * two levels ahead; 1 operands gathered back from L2 after each barrier (also what index lists and partitioned
+ * levels use); 0: one launch per level.  Same bits. */
 void amg_set_gs_chain(int on);
 /* A of a BSR(bs,bs) level can be applied straight from its blocks (8 B per entry + 4 B per block) instead
  * of from the CSR expansion (12 B per entry); same summation order, same bits.  0: never, 1 (default):

@@ -154,10 +154,11 @@ constexpr int CHAIN2_PF = 12;       // off-diagonal entries per row at most (cop
 constexpr int CHAIN2_D = 2;         // prefetch distance in levels = levels whose results are passed through LDS
 constexpr int CHAIN2_LMAX = 4096;   // levels per launch
 constexpr int CHAIN2_EMPTY = -2147483647 - 1;
-int launch_perm_gather(const int *rowmap, const double *x, const double *b, double *xp, double *bp, int n, hipStream_t st);
+int launch_perm_gather(const int *rowmap, const double *x, const double *b, const double *diag, double *xp, double *bp, double *bd,
+                       int n, hipStream_t st);
 int launch_perm_scatter(const int *rowmap, const double *xp, double *x, int n, hipStream_t st);
-int launch_gs_chain2(const int *lp, const double *diag, const double *val, const int *code, const int *off, double *dummy, int pf,
-                     int l_first, int nlevels, int width, bool reverse, bool bsr1, double *x, const double *b, hipStream_t st);
+int launch_gs_chain2(const int *lp, const double *val, const int *code, const int *off, double *dummy, int pf,
+                     int l_first, int nlevels, int width, bool reverse, bool bsr1, double *x, const double *bd, hipStream_t st);
 int gs_chain_max_rows();
 bool gs_chain_enabled();
 int gs_chain_generation();

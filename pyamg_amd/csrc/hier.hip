@@ -347,9 +347,9 @@ void Schedule::release()
     free_bsr(Gb);
     rowmap = diagpos = rows = level_ptr_dev = nullptr;
     for (int *p : {c2_code_f, c2_code_b, c2_off, perm_Aj}) if (p) hipFree(p);
-    for (double *p : {c2_diag, c2_val, c2_dummy, xp, bp}) if (p) hipFree(p);
+    for (double *p : {c2_diag, c2_val, c2_dummy, xp, bp, bd}) if (p) hipFree(p);
     c2_code_f = c2_code_b = c2_off = perm_Aj = nullptr;
-    c2_diag = c2_val = c2_dummy = xp = bp = nullptr;
+    c2_diag = c2_val = c2_dummy = xp = bp = bd = nullptr;
     chain2 = perm = false;
     chains.clear();
     chain_width.clear();
@@ -518,21 +518,23 @@ int build_csr_schedule(const int *Ap, const int *Aj, const double *Ax, int n, co
         if ((double)total * PFs * 8.0 >= 4.0e9 || (double)n * 8.0 >= 4.0e9) ok = false;     // the kernel addresses with 32-bit byte offsets
         // padded slots: value 0, operand = the permanent 0.0 kept behind the last unknown of xp
         std::vector<int> cf((size_t)total * PFs, n), cb((size_t)total * PFs, n);
-        std::vector<double> cd((size_t)total, 0.0), cv((size_t)total * PFs, 0.0);
+        std::vector<double> cd((size_t)n, 0.0), cv((size_t)total * PFs, 0.0);        // cd: the diagonal by level-order position
         for (int l = 0; l < nl && ok; ++l) {
             if (piece_of[(size_t)l] < 0) continue;
             const int base = coff[(size_t)l], cnt = S.level_ptr[l + 1] - S.level_ptr[l];
             for (int tt = 0; tt < cnt && ok; ++tt) {
                 const int k = S.level_ptr[l] + tt, i = rowmap[(size_t)k];
-                cd[(size_t)base + tt] = dpos[(size_t)k] >= 0 ? gx[(size_t)dpos[(size_t)k]] : 0.0;
-                if (cd[(size_t)base + tt] == 0.0) { ok = false; break; }    // a row that keeps its value (relaxation.h:58-60): first-generation chain
+                cd[(size_t)k] = dpos[(size_t)k] >= 0 ? gx[(size_t)dpos[(size_t)k]] : 0.0;
+                if (cd[(size_t)k] == 0.0) { ok = false; break; }    // a row that keeps its value (relaxation.h:58-60): first-generation chain
                 int u = 0;
                 for (int q = gp[(size_t)k]; q < gp[(size_t)k + 1]; ++q) {
                     const int c = gj[(size_t)q];
                     if (c == i) continue;                                   // the diagonal is not part of the sum
                     if (u >= PFs) { ok = false; break; }
-                    const size_t at = (size_t)PFs * base + (size_t)u * cnt + tt;
-                    cv[at] = gx[(size_t)q];
+                    // codes: QUADS of slots side by side (one 16-byte load fetches four): quad-major, then row, then slot % 4
+                    const size_t at = (size_t)PFs * base + (size_t)(u / 4) * 4 * cnt + 4 * (size_t)tt + (size_t)(u & 3);
+                    // values: PAIRS of slots side by side (one 16-byte load fetches two): pair-major, then row, then slot parity
+                    cv[(size_t)PFs * base + (size_t)(u / 2) * 2 * cnt + 2 * (size_t)tt + (size_t)(u & 1)] = gx[(size_t)q];
                     int f = inv[(size_t)c], bk = inv[(size_t)c];             // default: settled in memory, read at its level-order position
                     if (piece_of[(size_t)lvl_of[(size_t)c]] == piece_of[(size_t)l]) {
                         const int dl = l - lvl_of[(size_t)c];                // > 0: produced earlier in a forward sweep
@@ -548,7 +550,7 @@ int build_csr_schedule(const int *Ap, const int *Aj, const double *Ax, int n, co
             }
         }
         if (ok && total > 0) {
-            CHK(dev_alloc(&S.c2_diag, total, (long *)nullptr));
+            CHK(dev_alloc(&S.c2_diag, n, (long *)nullptr));
             CHK(dev_alloc(&S.c2_val, total * PFs, (long *)nullptr));
             CHK(dev_alloc(&S.c2_code_f, total * PFs, (long *)nullptr));
             CHK(dev_alloc(&S.c2_code_b, total * PFs, (long *)nullptr));
@@ -567,6 +569,7 @@ int build_csr_schedule(const int *Ap, const int *Aj, const double *Ax, int n, co
             CHK(dev_alloc(&S.xp, (long)n + 1, (long *)nullptr));
             AMG_HIP(hipMemset(S.xp, 0, sizeof(double) * ((size_t)n + 1)));       // xp[n] stays 0.0: the operand of padded slots
             CHK(dev_alloc(&S.bp, n, (long *)nullptr));
+            CHK(dev_alloc(&S.bd, 2 * (long)n, (long *)nullptr));
             AMG_HIP(hipMemcpy(S.perm_Aj, pj.data(), sizeof(int) * pj.size(), hipMemcpyHostToDevice));
             S.chain2 = true;
             S.perm = true;
@@ -686,7 +689,7 @@ int gs_sweep_csr(const Schedule &S, bool bsr1, double *x, const double *b, const
     double *xs = x;
     const double *bs = b;
     if (perm) {
-        CHK(launch_perm_gather(S.rowmap, x, b, S.xp, S.bp, S.ntasks, st));
+        CHK(launch_perm_gather(S.rowmap, x, b, S.c2_diag, S.xp, S.bp, S.bd, S.ntasks, st));
         G.Aj = S.perm_Aj; rowmap = nullptr; xs = S.xp; bs = S.bp;
     }
     StreamArgs a = base_args(G);
@@ -713,8 +716,8 @@ int gs_sweep_csr(const Schedule &S, bool bsr1, double *x, const double *b, const
             if (!reverse) { CHK(launches(pos, ch.first)); pos = ch.second; }
             else { CHK(launches(ch.second, pos)); pos = ch.first; }
             if (perm)
-                CHK(launch_gs_chain2(S.level_ptr_dev, S.c2_diag, S.c2_val, reverse ? S.c2_code_b : S.c2_code_f, S.c2_off, S.c2_dummy, S.c2_pf,
-                                     ch.first, ch.second - ch.first, width, reverse, bsr1, xs, bs, st));
+                CHK(launch_gs_chain2(S.level_ptr_dev, S.c2_val, reverse ? S.c2_code_b : S.c2_code_f, S.c2_off, S.c2_dummy, S.c2_pf,
+                                     ch.first, ch.second - ch.first, width, reverse, bsr1, xs, S.bd, st));
             else
                 CHK(launch_gs_chain(G, rowmap, S.diagpos, S.level_ptr_dev, ch.first, ch.second - ch.first, width, reverse, bsr1, xs, bs, st));
         }

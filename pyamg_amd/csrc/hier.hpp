@@ -35,12 +35,12 @@ struct Schedule {
     bool chain2 = false;
     int c2_pf = 0;                 // slots per row of the copy: 4, 8 or 12
     int *c2_code_f = nullptr, *c2_code_b = nullptr, *c2_off = nullptr;
-    double *c2_diag = nullptr, *c2_val = nullptr, *c2_dummy = nullptr;   // dummy: where idle lanes store (512 doubles)
+    double *c2_diag = nullptr, *c2_val = nullptr, *c2_dummy = nullptr;   // diag: by level-order position; dummy: where idle lanes store (512 doubles)
     // LEVEL-ORDER numbering (unknown k = k-th row of the schedule; only when the schedule lists every unknown once):
     // the sweeps of the second-generation chain run on xp = x[rowmap], bp = b[rowmap] with G's columns renumbered
     bool perm = false;
     int *perm_Aj = nullptr;
-    double *xp = nullptr, *bp = nullptr;
+    double *xp = nullptr, *bp = nullptr, *bd = nullptr;      // bd: (right-hand side, diagonal) pairs for the chained sweep
     // BSR flavour: block rows listed in level order
     int *rows = nullptr;          // device
     DevBsr Gb;                    // BSR flavour with values: block rows copied in level order (streamed)

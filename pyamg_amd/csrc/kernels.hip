@@ -741,9 +741,8 @@ __global__ __launch_bounds__(WGS) void gs_chain_kernel(const int *Ap, const int 
 // to relaxation.h:34-62 / :90-173 (bs = 1) and to the level-per-launch path.
 // ---------------------------------------------------------------------------
 template <bool BSR1, int PF, int WGS>
-__global__ __launch_bounds__(WGS) void gs_chain2_kernel(const int *lp, const double *cdiag, const double *cval,
-                                                       const int *ccode, const int *coff, double *x, const double *b,
-                                                       double *dummy, int l_first, int nl, int reverse)
+__global__ __launch_bounds__(WGS) void gs_chain2_kernel(const int *lp, const double *cval, const int *ccode, const int *coff,
+                                                       double *x, const double2 *bd, double *dummy, int l_first, int nl, int reverse)
 {
     constexpr int D = CHAIN2_D, NB = CHAIN2_D + 1;
     // Vector-memory results return in issue order, so whatever an iteration needs must have been requested at least
@@ -754,14 +753,17 @@ __global__ __launch_bounds__(WGS) void gs_chain2_kernel(const int *lp, const dou
     // Every request is UNCONDITIONAL (idle lanes and the steps past the last level read harmless addresses): a load
     // inside a branch makes the number of outstanding requests path-dependent and the compiler then waits for all.
     constexpr int A = 2;
-    // x and b are numbered in LEVEL ORDER (the sweep runs on the gathered copies Schedule::xp / bp): the rows of a
-    // level are lp[l] .. lp[l+1]-1, so the right-hand side and the store are contiguous over the lanes, and an operand
-    // from a neighbouring level sits at a neighbouring position.  (Addressed by original row these were one cache line
-    // per lane and per access: the vector L1's tag rate, not latency, set the cost of a level.)
-    // A level is bound by its INSTRUCTION STREAM (every wave issues the whole pipeline), so the per-slot work is kept
-    // minimal: all addresses are 32-bit byte offsets from uniform bases, a slot's code is either the operand's
-    // position (>= 0; padded slots point at the permanent 0.0 behind the last unknown and carry the value 0, which
-    // leaves the running sum untouched bit for bit) or ~(byte offset into the LDS ring) (< 0).
+    // x and the (right-hand side, diagonal) pairs are numbered in LEVEL ORDER (the sweep runs on the gathered copies
+    // Schedule::xp / bd): the rows of a level are lp[l] .. lp[l+1]-1, so they and the store are contiguous over the
+    // lanes, and an operand from a neighbouring level sits at a neighbouring position.  (Addressed by original row
+    // these were one cache line per lane and per access: the vector L1's tag rate set the cost of a level.)
+    // What a level costs now is the NUMBER of vector-memory instructions its waves issue (rocprofv3: ~16 cycles of the
+    // compute unit each, whatever their width), then the rest of the instruction stream.  So: a row's codes come four
+    // per 16-byte load and its values two per load (the copy keeps them side by side), right-hand side and diagonal in
+    // one load; addresses are 32-bit byte offsets from uniform bases; a slot's code is either the operand's position
+    // (>= 0; padded slots point at the permanent 0.0 behind the last unknown and carry the value 0, which leaves the
+    // running sum untouched bit for bit) or ~(byte offset into the LDS ring) (< 0).
+    static_assert(PF % 4 == 0, "codes are fetched four at a time, values two at a time");
     __shared__ int soff[CHAIN2_LMAX + 1];
     __shared__ int slp[CHAIN2_LMAX + 1];
     __shared__ double ring[NB * CHAIN2_WG + 1];               // + 1: what a slot without a ring operand reads
@@ -785,10 +787,13 @@ __global__ __launch_bounds__(WGS) void gs_chain2_kernel(const int *lp, const dou
         c.live = (q < nl) && (t < c.n);
         c.at = (unsigned)(base + tt);
         c.arow = slp[l] + tt;
-        unsigned off = ((unsigned)PF * (unsigned)base + (unsigned)tt) * 4u;          // slot u of this row: + u * n * 4
-        const unsigned step = (unsigned)c.n * 4u;
+        const unsigned step = (unsigned)c.n * 16u;
+        unsigned off = ((unsigned)PF * (unsigned)base + 4u * (unsigned)tt) * 4u;      // quad k of this row: + k * n * 16
 #pragma unroll
-        for (int u = 0; u < PF; ++u) { c.code[u] = *(const int *)at_bytes(ccode, off); off += step; }
+        for (int k = 0; k < PF / 4; ++k) {
+            const int4 v = *(const int4 *)at_bytes(ccode, off); off += step;
+            c.code[4 * k] = v.x; c.code[4 * k + 1] = v.y; c.code[4 * k + 2] = v.z; c.code[4 * k + 3] = v.w;
+        }
         return c;
     };
     auto stage_b = [&](int q, const Codes &c) -> Stage {   // values, diagonal, right-hand side, settled operands
@@ -796,16 +801,20 @@ __global__ __launch_bounds__(WGS) void gs_chain2_kernel(const int *lp, const dou
         s.row = c.live ? c.arow : -1;
         s.arow8 = (unsigned)c.arow * 8u;
         s.lvl = l_first + level_of(min(q, nl - 1));
-        s.d = *(const double *)at_bytes(cdiag, c.at * 8u);
-        s.bb = *(const double *)at_bytes(b, s.arow8);
+        const double2 rhs_diag = *(const double2 *)at_bytes(bd, (unsigned)c.arow * 16u);
+        s.bb = rhs_diag.x; s.d = rhs_diag.y;
         const int tt = min(t, c.n - 1);
-        unsigned off = ((unsigned)PF * (c.at - (unsigned)tt) + (unsigned)tt) * 8u;
-        const unsigned step = (unsigned)c.n * 8u;
+        const unsigned step = (unsigned)c.n * 16u;
+        unsigned off = ((unsigned)PF * (c.at - (unsigned)tt) + 2u * (unsigned)tt) * 8u;   // pair k of this row: + k * n * 16
+#pragma unroll
+        for (int k = 0; k < PF / 2; ++k) {
+            const double2 v = *(const double2 *)at_bytes(cval, off); off += step;
+            s.val[2 * k] = v.x; s.val[2 * k + 1] = v.y;
+        }
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
             s.code[u] = c.code[u];
             if (KEEP_LA) s.la[u] = min(~(unsigned)c.code[u], RING_BYTES);     // where in the ring (the spare word if not there), off the critical path
-            s.val[u] = *(const double *)at_bytes(cval, off); off += step;
             // a ring operand's slot requests position 0 (one line for the whole wave) and drops it
             s.xv[u] = load_fresh((const double *)at_bytes(x, (unsigned)max(c.code[u], 0) * 8u));
         }
@@ -874,15 +883,15 @@ __global__ __launch_bounds__(WGS) void gs_chain2_kernel(const int *lp, const dou
 // waves still issue every instruction of the pipeline, so a 40-row level is swept by ONE wave, not by eight)
 static int chain_threads(int width) { return width <= 64 ? 64 : (width <= 128 ? 128 : (width <= 256 ? 256 : 512)); }
 
-int launch_gs_chain2(const int *lp, const double *diag, const double *val, const int *code, const int *off, double *dummy, int pf,
-                     int l_first, int nlevels, int width, bool reverse, bool bsr1, double *x, const double *b, hipStream_t st)
+int launch_gs_chain2(const int *lp, const double *val, const int *code, const int *off, double *dummy, int pf,
+                     int l_first, int nlevels, int width, bool reverse, bool bsr1, double *x, const double *bd, hipStream_t st)
 {
     if (nlevels <= 0) return 0;
     if (nlevels > CHAIN2_LMAX) { set_error("gs_chain2: run longer than one launch holds"); return -4; }
     if (width > CHAIN2_WG) { set_error("gs_chain2: level wider than the workgroup"); return -4; }
     const int wg = chain_threads(width);
-#define C2_LAUNCH(B, P, W) hipLaunchKernelGGL((gs_chain2_kernel<B, P, W>), dim3(1), dim3(W), 0, st, lp, diag, val, code, off, x, b, \
-                                              dummy, l_first, nlevels, reverse ? 1 : 0)
+#define C2_LAUNCH(B, P, W) hipLaunchKernelGGL((gs_chain2_kernel<B, P, W>), dim3(1), dim3(W), 0, st, lp, val, code, off, x, \
+                                              (const double2 *)bd, dummy, l_first, nlevels, reverse ? 1 : 0)
 #define C2_WIDTH(B, P) do { if (wg == 64) C2_LAUNCH(B, P, 64); else if (wg == 128) C2_LAUNCH(B, P, 128); \
                             else if (wg == 256) C2_LAUNCH(B, P, 256); else C2_LAUNCH(B, P, 512); } while (0)
     if (pf == 4) { if (bsr1) C2_WIDTH(true, 4); else C2_WIDTH(false, 4); }
@@ -897,20 +906,27 @@ int launch_gs_chain2(const int *lp, const double *diag, const double *val, const
 }
 
 // level-order numbering of a scheduled sweep: xp[k] = x[rowmap[k]], bp[k] = b[rowmap[k]] before, x[rowmap[k]] = xp[k] after
-__global__ __launch_bounds__(256) void perm_gather_kernel(const int *rowmap, const double *x, const double *b, double *xp, double *bp, int n)
+__global__ __launch_bounds__(256) void perm_gather_kernel(const int *rowmap, const double *x, const double *b, const double *diag,
+                                                           double *xp, double *bp, double2 *bd, int n)
 {
     const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k < n) { const int i = rowmap[k]; xp[k] = x[i]; bp[k] = b[i]; }
+    if (k < n) {
+        const int i = rowmap[k];
+        const double bi = b[i];
+        xp[k] = x[i]; bp[k] = bi;
+        bd[k] = make_double2(bi, diag[k]);        // right-hand side and diagonal side by side: one load in the chained sweep
+    }
 }
 __global__ __launch_bounds__(256) void perm_scatter_kernel(const int *rowmap, const double *xp, double *x, int n)
 {
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k < n) x[rowmap[k]] = xp[k];
 }
-int launch_perm_gather(const int *rowmap, const double *x, const double *b, double *xp, double *bp, int n, hipStream_t st)
+int launch_perm_gather(const int *rowmap, const double *x, const double *b, const double *diag, double *xp, double *bp, double *bd,
+                       int n, hipStream_t st)
 {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(perm_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, st, rowmap, x, b, xp, bp, n);
+    hipLaunchKernelGGL(perm_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, st, rowmap, x, b, diag, xp, bp, (double2 *)bd, n);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "perm gather launch", __FILE__, __LINE__);
     return 0;

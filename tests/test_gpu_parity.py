@@ -862,7 +862,7 @@ def test_chained_gauss_seidel_equals_per_level_launches():
                     x = np.linspace(0.0, 1.0, n)
                     relaxation.gauss_seidel(M, x, b, iterations=2, sweep=sweep)
                     out[on] = x
-                _lib.lib().amg_set_gs_chain(1)
+                _lib.lib().amg_set_gs_chain(2)
                 assert np.array_equal(out[0], out[1]), (dims, type(M).__name__, sweep)
                 assert np.array_equal(out[0], out[2]), (dims, type(M).__name__, sweep)
                 xo = np.linspace(0.0, 1.0, n)
@@ -1173,8 +1173,8 @@ def test_chained_gauss_seidel_on_irregular_hierarchy_levels():
                 x = rng.rand(n) if False else np.cos(np.arange(n, dtype=float))
                 relaxation.gauss_seidel(M, x, b, iterations=2, sweep=sweep)
                 out[on] = x
-            _lib.lib().amg_set_gs_chain(1)
             assert np.array_equal(out[0], out[1]) and np.array_equal(out[0], out[2]), (n, sweep)
+            _lib.lib().amg_set_gs_chain(2)
     A = sps.csr_matrix(native((40, 30)))
     idx = np.concatenate([np.arange(0, 1200, 2), np.arange(0, 1200, 3)]).astype(np.intc)       # rows listed twice
     b = rng.rand(1200)
@@ -1184,7 +1184,7 @@ def test_chained_gauss_seidel_on_irregular_hierarchy_levels():
         x = np.sin(np.arange(1200.0))
         relaxation.gauss_seidel_indexed(A, x, b, idx, iterations=1, sweep="symmetric")
         out[on] = x
-    _lib.lib().amg_set_gs_chain(1)
+    _lib.lib().amg_set_gs_chain(2)
     assert np.array_equal(out[0], out[2])
 
 
