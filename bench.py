@@ -304,7 +304,7 @@ def partitioned_main(args, rank, local_rank, world, torch, dist):
                        "setup_seconds": {"matrix": round(t_gen, 1), "hierarchy": round(t_setup, 1)},
                        "residuals": [r0, float(warm[-1]), float(timed[-1])]},
             "roofline": {"bound": "hbm",
-                         "kernel": {0: "csr_stream_kernel", 1: "csr_pattern_kernel", 2: "stencil_kernel"}.get(form, "csr_stream_kernel") +
+                         "kernel": {0: "csr_stream_kernel", 1: "csr_pattern_kernel", 2: "stencil2_kernel"}.get(form, "csr_stream_kernel") +
                                    " (level-0 A-application on rank 0's row block)",
                          "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
@@ -443,7 +443,7 @@ def main():
         ach = spmv_bytes / (ms_resid * 1e-3) / 1e9
         form = L.amg_hier_operator_form(h, 0)
         moved = L.amg_hier_operator_bytes(h, 0, 1)
-        kname = {0: "csr_stream_kernel", 1: "csr_pattern_kernel", 2: "stencil_kernel"}[form]
+        kname = {0: "csr_stream_kernel", 1: "csr_pattern_kernel", 2: "stencil2_kernel"}[form]
         # `achieved` prices the launch at the CSR bytes of SURVEY.md 8(d) (12 B per stored entry), the figure
         # the reference's csr_matvec would have to stream; `moved_GBs` prices it at what this kernel's
         # storage form actually streams -- that one is bounded by the HBM peak.

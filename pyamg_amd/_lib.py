@@ -207,6 +207,8 @@ def lib():
     L.amg_set_gs_chain.restype = None
     L.amg_set_stencil_form.argtypes = [I]
     L.amg_set_stencil_form.restype = None
+    L.amg_set_stencil_pairs.argtypes = [I]
+    L.amg_set_stencil_pairs.restype = None
     L.amg_set_xcd_period.argtypes = [I]
     L.amg_set_xcd_period.restype = None
     L.amg_set_xcd_chunk.argtypes = [I]

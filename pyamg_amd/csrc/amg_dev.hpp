@@ -167,6 +167,7 @@ bool stencil_enabled();
 int launch_index16_build(DevCsr &M, int rpb, hipStream_t st);   // fills Aj16 / wg_base / wg_flag (already allocated)
 bool index16_enabled();
 void set_index16(int on);
+void set_stencil_pairs(int on);          // 1: two rows per lane in the stencil form (16-byte accesses), 0: one
 void set_stencil_form(int on);           // 0: dispatch pattern operators to csr_pattern_kernel instead
 void set_xcd_period(int on);             // plane-periodic block->XCD mapping of pattern operators (default on)
 int stream_blocks(const StreamArgs &a);   // workgroups launch_stream will use (partials of SM_RESIDUAL_SUMSQ)

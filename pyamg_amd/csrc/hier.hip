@@ -2385,6 +2385,7 @@ void amg_set_stream_pipe(int on) { amg::set_stream_pipe(on); }
 void amg_set_xcd_chunk(int c) { amg::set_xcd_chunk(c); }
 void amg_set_xcd_period(int on) { amg::set_xcd_period(on); }
 void amg_set_stencil_form(int on) { amg::set_stencil_form(on); }
+void amg_set_stencil_pairs(int on) { amg::set_stencil_pairs(on); }
 void amg_set_gs_chain(int on) { amg::set_gs_chain(on); }
 void amg_set_bsr_spmv(int on) { amg::set_bsr_spmv(on); }
 void amg_set_index16(int on) { amg::set_index16(on); }

@@ -1364,6 +1364,179 @@ __global__ __launch_bounds__(WG) void stencil_kernel(StreamArgs a, StencilArgs E
     }
 }
 
+// ---------------------------------------------------------------------------
+// The same application with TWO consecutive rows per lane (128 lanes per 256-row block): every streamed operand --
+// the values of a slot, the gathered x, the masks, right-hand side, result -- is one 16-byte access for two rows.
+// SQ counters of the one-row kernel at 500^3: 57 % of the wave cycles waiting for instruction ISSUE; the compute unit
+// takes ~16 cycles per wave-level memory instruction whatever its width, and that kernel issues 17 of them per 64
+// rows.  Half the instructions for the same bytes here; per-row arithmetic, order and results unchanged.
+// ---------------------------------------------------------------------------
+struct __attribute__((packed, aligned(8))) PairU { double x, y; };        // two doubles at 8-byte alignment (gathers at odd offsets)
+typedef unsigned long long v2ull __attribute__((ext_vector_type(2)));
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+constexpr int WG2 = WG / 2;
+
+template <int MODE, int NUB>
+__global__ __launch_bounds__(WG2) void stencil2_kernel(StreamArgs a, StencilArgs E, int xcd_chunk)
+{
+    using MT = ModeTraits<MODE>;
+    __shared__ double red[WG + 8];
+    __shared__ double sdict[256];
+    const int t = threadIdx.x;
+    int blk;
+    if (E.period_blocks > 0) {
+        const int k = blockIdx.x & 7, s = blockIdx.x >> 3;
+        const int p = s / E.seg_blocks, j = s - p * E.seg_blocks;
+        const int q = k * E.seg_blocks + j;
+        blk = p * E.period_blocks + q;
+        if (q >= E.period_blocks || blk >= E.nblocks) return;
+    } else {
+        blk = remap_block(blockIdx.x, gridDim.x, xcd_chunk);
+    }
+    blk += E.blk_lo;
+    const int i0 = blk * WG + 2 * t;                          // rows i0, i0 + 1
+    const bool live0 = (i0 >= a.row_lo && i0 < a.row_hi), live1 = (i0 + 1 >= a.row_lo && i0 + 1 < a.row_hi);
+    const bool both = live0 && live1, any = live0 || live1;
+    const bool vi = E.codes != nullptr;                       // uniform
+    const double *vp = E.vals + ((size_t)blk * E.nu) * WG + 2 * t;
+    constexpr int NW = NUB / 8;
+    const int nw = (E.nu + 7) >> 3;
+    const unsigned long long *cp = reinterpret_cast<const unsigned long long *>(E.codes) + ((size_t)blk * nw) * WG + 2 * t;
+    if (vi) { sdict[t] = (t < E.ndict) ? E.dict[t] : 0.0; sdict[t + WG2] = (t + WG2 < E.ndict) ? E.dict[t + WG2] : 0.0; }
+
+    double v[2][NUB], xv[2][NUB];
+    unsigned long long cw[2][NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        cw[0][w] = cw[1][w] = 0ULL;
+        if (vi && any && w < nw) {
+            const v2ull c2 = stream_load(reinterpret_cast<const v2ull *>(&cp[(size_t)w * WG]));
+            cw[0][w] = c2.x; cw[1][w] = c2.y;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < NUB; ++u) {
+        v[0][u] = v[1][u] = 0.0; xv[0][u] = xv[1][u] = 0.0;
+        if (u < E.nu && any) {
+            if (!vi) {
+                const v2d vv = stream_load(reinterpret_cast<const v2d *>(&vp[(size_t)u * WG]));
+                v[0][u] = vv.x; v[1][u] = vv.y;
+            }
+            const long j = (long)i0 + E.off[u];
+            if (j >= 0 && j + 1 < E.ncols) {
+                const PairU xx = *reinterpret_cast<const PairU *>(&a.xg[j]);
+                xv[0][u] = xx.x; xv[1][u] = xx.y;
+            } else {
+                if (j >= 0 && j < E.ncols) xv[0][u] = a.xg[j];
+                if (j + 1 >= 0 && j + 1 < E.ncols) xv[1][u] = a.xg[j + 1];
+            }
+        }
+    }
+    unsigned m[2] = {0, 0};
+    double bval[2] = {0.0, 0.0}, pre2[2] = {0.0, 0.0};
+    constexpr bool need_b = MT::sub || MODE == SM_RESIDUAL || MODE == SM_RESIDUAL_SUMSQ || MODE == SM_POLY_STEP ||
+                            MODE == SM_POLY_LAST || MODE == SM_JACOBI;
+    if (any) {
+        if (NUB == 8) {
+            const unsigned short mm = stream_load(reinterpret_cast<const unsigned short *>(static_cast<const unsigned char *>(E.mask) + i0));
+            m[0] = mm & 0xFFu; m[1] = mm >> 8;
+        } else {
+            const v2u mm = stream_load(reinterpret_cast<const v2u *>(static_cast<const unsigned *>(E.mask) + i0));
+            m[0] = mm.x; m[1] = mm.y;
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+            if (m[r] & ((NUB == 8) ? 0x80u : 0x80000000u)) m[r] = 0xFFFFFFFFu;          // not covered
+        if (need_b) {
+            const v2d bb = stream_load(reinterpret_cast<const v2d *>(&a.b[i0]));
+            bval[0] = bb.x; bval[1] = bb.y;
+        }
+        if (MODE == SM_MATVEC_ACC) { const v2d pp = *reinterpret_cast<const v2d *>(&a.out[i0]); pre2[0] = pp.x; pre2[1] = pp.y; }
+        else if (MODE == SM_POLY_LAST || MODE == SM_JACOBI || MODE == SM_JACOBI_BSR1) {
+            const v2d pp = *reinterpret_cast<const v2d *>(&a.v2[i0]); pre2[0] = pp.x; pre2[1] = pp.y;
+        }
+    }
+    bool covered[2] = {live0 && m[0] != 0xFFFFFFFFu, live1 && m[1] != 0xFFFFFFFFu};
+#pragma unroll
+    for (int r = 0; r < 2; ++r) if (!covered[r]) m[r] = 0;
+    if (vi) {
+        __syncthreads();                                      // dictionary in LDS
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int u = 0; u < NUB; ++u) v[r][u] = sdict[(unsigned)(cw[r][u >> 3] >> (8 * (u & 7))) & 0xFFu];
+    }
+    const double gscale = a.gscale;
+    double acc[2], diag[2] = {0.0, 0.0};
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        acc[r] = MT::sub ? bval[r] : 0.0;
+#pragma unroll
+        for (int u = 0; u < NUB; ++u) {
+            if (u < E.nu && ((m[r] >> u) & 1u)) {
+                if (MT::jac && u == E.u0) { diag[r] = v[r][u]; continue; }
+                const double pr = v[r][u] * (gscale * xv[r][u]);
+                acc[r] = MT::sub ? (acc[r] - pr) : (acc[r] + pr);
+            }
+        }
+    }
+
+    double res[2] = {0.0, 0.0};
+    if (MODE == SM_RESIDUAL_SUMSQ) {
+        double sq[2] = {0.0, 0.0};
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+            if (covered[r]) { res[r] = bval[r] - acc[r]; sq[r] = res[r] * res[r]; }
+        if (a.out) {
+            if (covered[0] && covered[1]) __builtin_nontemporal_store(v2d{res[0], res[1]}, reinterpret_cast<v2d *>(&a.out[i0]));
+            else { if (covered[0]) store_out(&a.out[i0], res[0]); if (covered[1]) store_out(&a.out[i0 + 1], res[1]); }
+        }
+        // the one-row kernel's summation tree, bit for bit: row r sits in lane r % 64 of wave r / 64, a shuffle tree per
+        // wave, the four wave sums added in order
+        *reinterpret_cast<v2d *>(&red[2 * t]) = v2d{sq[0], sq[1]};
+        __syncthreads();
+        double s0 = red[t], s1 = red[t + WG2];                // wave 0: rows 0..63 and 128..191, wave 1: 64..127 and 192..255
+        for (int off = 32; off > 0; off >>= 1) { s0 += __shfl_down(s0, off, 64); s1 += __shfl_down(s1, off, 64); }
+        __syncthreads();
+        if ((t & 63) == 0) { red[WG + (t >> 6)] = s0; red[WG + 2 + (t >> 6)] = s1; }
+        __syncthreads();
+        if (t == 0) {
+            double tot = 0.0;
+            for (int k = 0; k < 4; ++k) tot += red[WG + k];
+            a.out2[blk - E.blk_lo] = tot;
+        }
+        return;
+    }
+    bool wr[2] = {covered[0], covered[1]};
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        if (MODE == SM_MATVEC) res[r] = acc[r];
+        else if (MODE == SM_MATVEC_ACC) res[r] = pre2[r] + acc[r];
+        else if (MODE == SM_RESIDUAL) res[r] = bval[r] - acc[r];
+        else if (MODE == SM_POLY_STEP) { const double cr = a.c0 * bval[r]; res[r] = cr + acc[r]; }
+        else if (MODE == SM_POLY_LAST) { const double cr = a.c0 * bval[r]; const double h = cr + acc[r]; res[r] = pre2[r] + h; }
+        else if (MODE == SM_JACOBI) {
+            if (diag[r] != 0.0) { const double q = (bval[r] - acc[r]) / diag[r]; const double t1 = (1.0 - a.c0) * pre2[r]; const double t2 = a.c0 * q; res[r] = t1 + t2; }
+            else res[r] = pre2[r];
+        } else if (MODE == SM_JACOBI_BSR1) {
+            if (diag[r] != 0.0) { const double t1 = (1.0 - a.c0) * pre2[r]; const double t2 = (a.c0 * acc[r]) / diag[r]; res[r] = t1 + t2; }
+            else res[r] = pre2[r];
+        }
+    }
+    constexpr bool streamed = (MODE == SM_MATVEC || MODE == SM_MATVEC_ACC || MODE == SM_RESIDUAL || MODE == SM_POLY_LAST);
+    if (wr[0] && wr[1]) {
+        if (streamed) __builtin_nontemporal_store(v2d{res[0], res[1]}, reinterpret_cast<v2d *>(&a.out[i0]));
+        else *reinterpret_cast<v2d *>(&a.out[i0]) = v2d{res[0], res[1]};
+    } else {
+        if (wr[0]) { if (streamed) store_out(&a.out[i0], res[0]); else a.out[i0] = res[0]; }
+        if (wr[1]) { if (streamed) store_out(&a.out[i0 + 1], res[1]); else a.out[i0 + 1] = res[1]; }
+    }
+    (void)both;
+}
+
+static int g_stencil_pairs = 1;     // 1: two rows per lane (stencil2_kernel), 0: one row per lane
+void set_stencil_pairs(int on) { g_stencil_pairs = on; ++g_config_epoch; }
+
 struct StencilRanges { int n; int range[STENCIL_RANGES][2]; };
 
 // values of the CSR -> stencil layout; one thread per row
@@ -1507,7 +1680,15 @@ static int launch_stencil_mode(const StreamArgs &a, const DevCsr &M, hipStream_t
             grid = 8 * G * ((nb + S - 1) / S);
         }
     }
-    if (M.st_nu <= 7)
+    // two rows per lane needs the vectors it streams 16-byte aligned
+    // (the opt-in value index keeps one row per lane: measured faster there)
+    const bool pairs = g_stencil_pairs != 0 && M.st_nu <= 16 && E.codes == nullptr &&
+                       (((uintptr_t)b.b | (uintptr_t)b.out | (uintptr_t)b.v2 | (uintptr_t)b.xg) & 15u) == 0;
+    if (pairs && M.st_nu <= 7)
+        hipLaunchKernelGGL((stencil2_kernel<MODE, 8>), dim3(grid), dim3(WG2), 0, st, b, E, g_xcd_chunk);
+    else if (pairs)
+        hipLaunchKernelGGL((stencil2_kernel<MODE, 16>), dim3(grid), dim3(WG2), 0, st, b, E, g_xcd_chunk);
+    else if (M.st_nu <= 7)
         hipLaunchKernelGGL((stencil_kernel<MODE, 8>), dim3(grid), dim3(WG), 0, st, b, E, g_xcd_chunk);
     else if (M.st_nu <= 16)
         hipLaunchKernelGGL((stencil_kernel<MODE, 16>), dim3(grid), dim3(WG), 0, st, b, E, g_xcd_chunk);

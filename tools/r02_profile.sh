@@ -13,4 +13,5 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch_r0
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write_r02 -- python3 tools/pmc_spmv.py 500 1 32 1 > $O/r02_pmc_write.log 2>&1 && \
 cp $(ls $O/pmc_fetch_r02/*/*counter_collection.csv | head -1) $O/r02_pmc_fetch_stencil_500_counter_collection.csv && \
 cp $(ls $O/pmc_write_r02/*/*counter_collection.csv | head -1) $O/r02_pmc_write_stencil_500_counter_collection.csv && \
+python tools/pmc_summary.py $O/r02_pmc_fetch_stencil_500_counter_collection.csv $O/r02_pmc_write_stencil_500_counter_collection.csv 500 $O/r02_pmc_summary.json $O/r02_bench500.json > /dev/null && \
 head -30 $O/r02_bench500_timed_region.txt
