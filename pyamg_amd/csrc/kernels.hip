@@ -301,11 +301,20 @@ __global__ __launch_bounds__(WG) void csr_stream_kernel(StreamArgs a, int xcd_ch
         }
         __syncthreads();
         {
+            // the row's products, eight LDS reads in flight at a time (one read, one wait, one add per entry -- what
+            // the plain loop compiles to -- made this phase ~1.5 us of a workgroup's ~8 us on 27-entry rows), added
+            // strictly left to right
             const int s = max(my_s, tile_lo), e2 = min(my_e, tile_hi);
-            for (int k = s; k < e2; ++k) {
-                double p = sp[k - tile_lo];
-                if (MT::gs && k == dpos) continue;
-                acc = MT::sub ? (acc - p) : (acc + p);
+            for (int k = s; k < e2; k += 8) {
+                double p[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) p[u] = sp[min(k + u, e2 - 1) - tile_lo];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const bool take = (k + u < e2) && !(MT::gs && k + u == dpos);
+                    const double nxt = MT::sub ? (acc - p[u]) : (acc + p[u]);
+                    acc = take ? nxt : acc;
+                }
             }
         }
         __syncthreads();
@@ -2292,18 +2301,49 @@ __global__ __launch_bounds__(WG) void bsr_stream_kernel(BsrStreamArgs a, int rpb
             __syncthreads();
         }
         if (active) {
+            // (LDS reads four blocks at a time, then the adds strictly in order: a read, a wait and an add per
+            // operand -- what the plain loop compiles to -- serialises the LDS latency)
             const int s = max(my_s, tb), e = min(my_e, te);
-            for (int jj = s; jj < e; ++jj) {
-                if (BMODE == BM_SPMV) {
-                    // scipy bsr_matvec: ONE running sum per scalar row, across the blocks and the
-                    // columns inside each block -- the order of the expanded CSR row
+            if (BMODE == BM_SPMV && BS > 0) {
+                // scipy bsr_matvec: ONE running sum per scalar row, across the blocks and the
+                // columns inside each block -- the order of the expanded CSR row
+                for (int j0 = s; j0 < e; j0 += 4) {
+                    double q[4][BS > 0 ? BS : 1];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const double *p = &sp[(long)(min(j0 + u, e - 1) - tb) * B2 + r * bs];
+#pragma unroll
+                        for (int c = 0; c < (BS > 0 ? BS : 1); ++c) q[u][c] = p[c];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const bool take = j0 + u < e;
+#pragma unroll
+                        for (int c = 0; c < (BS > 0 ? BS : 1); ++c) { const double nxt = rsum + q[u][c]; rsum = take ? nxt : rsum; }
+                    }
+                }
+            } else if (BMODE == BM_SPMV) {
+                for (int jj = s; jj < e; ++jj) {
                     const double *p = &sp[(long)(jj - tb) * B2 + r * bs];
                     for (int c = 0; c < bs; ++c) rsum = rsum + p[c];
-                    continue;
                 }
-                if (sbj[jj - tb] == brow) { dptr = (long)jj * B2; continue; }
-                const double v = sp[(long)(jj - tb) * B2 + r * bs];
-                rsum = point ? (rsum - v) : (rsum + v);
+            } else {
+                for (int j0 = s; j0 < e; j0 += 4) {
+                    double v[4];
+                    int bc[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int lb = min(j0 + u, e - 1) - tb;
+                        bc[u] = sbj[lb];
+                        v[u] = sp[(long)lb * B2 + r * bs];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (j0 + u >= e) continue;
+                        if (bc[u] == brow) { dptr = (long)(j0 + u) * B2; continue; }
+                        rsum = point ? (rsum - v[u]) : (rsum + v[u]);
+                    }
+                }
             }
         }
         __syncthreads();
