@@ -399,6 +399,23 @@ void amg_set_index16(int on);
 /* products per workgroup aimed at when choosing rows per workgroup (default 2048 = one LDS tile) */
 void amg_set_tile_target(int t);
 
+/* ---- setup on the device: Galerkin products -------------------------------------------------------------------
+ * Ac = (R * A) * P with scipy's csr_matmat arithmetic and output order (what pyamg/aggregation/aggregation.py:425-426
+ * computes as R * A * P): per output row the products accumulate in the order (entry of the left row, entry of the
+ * right row), columns come out in reverse first-touch order, exact zeros are dropped -- bit-identical to scipy.
+ * A is level `level` of a hierarchy handle that already holds it in HBM as CSR (the handle behind the setup-time
+ * spectral-radius estimate); R, P are host CSR arrays with 64-bit row pointers.  Cp receives n_coarse + 1 offsets;
+ * amg_galerkin_fetch copies the Cp[n_coarse] columns / values to the host and releases the product.
+ * AMG_EINVAL (nothing allocated) when the operator is not held as CSR or a row needs more than 1024 products (one thread per
+ * row with a private table stops paying there). */
+typedef struct amg_galerkin amg_galerkin;
+int amg_hier_galerkin(amg_hier *h, int level, int n_coarse, const int64_t *Rp, const int *Rj, const double *Rx,
+                      const int64_t *Pp, const int *Pj, const double *Px, int64_t *Cp, amg_galerkin **out);
+int amg_galerkin_fetch(amg_galerkin *g, int *Cj, double *Cx);
+/* C = A * B for host CSR operands through the same kernels (n_row x n_inner times n_inner x n_col) */
+int amg_csr_matmat_device(int n_row, int n_inner, int n_col, const int64_t *Ap, const int *Aj, const double *Ax,
+                          const int64_t *Bp, const int *Bj, const double *Bx, int64_t *Cp, amg_galerkin **out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -134,6 +134,9 @@ def lib():
         "amg_hier_comm_check": [V],
         "amg_arnoldi": [V, I, c_dbl_p, c_dbl_p, I, D, c_dbl_p, c_int_p, c_int_p],
         "amg_arnoldi_combine": [V, c_dbl_p, I, c_dbl_p],
+        "amg_hier_galerkin": [V, I, I, V, V, V, V, V, V, V, C.POINTER(C.c_void_p)],
+        "amg_galerkin_fetch": [V, V, V],
+        "amg_csr_matmat_device": [I, I, I, V, V, V, V, V, V, V, C.POINTER(C.c_void_p)],
     }
     for name, args in sig.items():
         f = getattr(L, name)

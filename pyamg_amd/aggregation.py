@@ -598,6 +598,27 @@ def _extend_scalar(levels, smooth_l, keep, rho_fn):
             _t[0] = now
     Ap, Aj, Ax = _csr_arrays64(A)
     Ap32 = np.ascontiguousarray(A.indptr, dtype=np.intc)
+    # rho(D^-1 A) does not depend on the aggregation: when the rows are already sorted (level 0 of the gallery
+    # operators; get_diagonal's in-place sort below is then a no-op and the aggregation reads the same order either
+    # way) the estimate -- upload of A, Arnoldi on the GPU -- runs in a thread of its own beside aggregation and
+    # tentative prolongator.  Neither of those draws random numbers, so the estimate's single np.random.rand draw is the
+    # same draw.
+    early = None
+    if n >= 1000000 and rho_fn is _rho_D_inv_A_host and use_device_for(A) and getattr(A, "has_sorted_indices", False) \
+            and os.environ.get("AMG_SETUP_OVERLAP_RHO", "1") != "0":
+        import threading
+        box = {}
+
+        def estimate():
+            try:
+                d = np.empty(n, dtype=np.float64)
+                L.amgsetup_csr_diagonal_inv(n, _lp(Ap), _ip(Aj), _dp(Ax), _dp(d))
+                box["D_inv"] = d
+                box["rho"] = rho_fn(A, d)
+            except BaseException as e:      # noqa: BLE001 -- re-raised in the main thread
+                box["error"] = e
+        early = (threading.Thread(target=estimate), box)
+        early[0].start()
     # strength with theta = 0 keeps every entry: the aggregation only reads the pattern
     agg = np.empty(n, dtype=np.intc)
     cpts = np.empty(n, dtype=np.intc)
@@ -620,18 +641,25 @@ def _extend_scalar(levels, smooth_l, keep, rho_fn):
     lap("tentative prolongator")
     # get_diagonal(A, inv=True), row-parallel on the flat arrays -- including its side effect: the reference sorts
     # A's rows in place here (util/utils.py:566), so everything from here on sees the sorted order
-    if Aj.ctypes.data == A.indices.ctypes.data and Ax.ctypes.data == A.data.ctypes.data and Ax.size == A.data.size \
-            and Aj.flags.writeable and Ax.flags.writeable:
-        L.amgsetup_csr_sort_indices(n, _lp(Ap), _ip(Aj), _dp(Ax))
-        A.has_sorted_indices = True
+    if early is not None:
+        early[0].join()
+        if "error" in early[1]:
+            raise early[1]["error"]
+        D_inv, rho = early[1]["D_inv"], early[1]["rho"]
+        lap("rho(D^-1 A) (overlapped)")
     else:
-        A.sort_indices()
-        Ap, Aj, Ax = _csr_arrays64(A)
-    D_inv = np.empty(n, dtype=np.float64)
-    L.amgsetup_csr_diagonal_inv(n, _lp(Ap), _ip(Aj), _dp(Ax), _dp(D_inv))
-    lap("diagonal")
-    rho = rho_fn(A, D_inv)
-    lap("rho(D^-1 A)")
+        if Aj.ctypes.data == A.indices.ctypes.data and Ax.ctypes.data == A.data.ctypes.data and Ax.size == A.data.size \
+                and Aj.flags.writeable and Ax.flags.writeable:
+            L.amgsetup_csr_sort_indices(n, _lp(Ap), _ip(Aj), _dp(Ax))
+            A.has_sorted_indices = True
+        else:
+            A.sort_indices()
+            Ap, Aj, Ax = _csr_arrays64(A)
+        D_inv = np.empty(n, dtype=np.float64)
+        L.amgsetup_csr_diagonal_inv(n, _lp(Ap), _ip(Aj), _dp(Ax), _dp(D_inv))
+        lap("diagonal")
+        rho = rho_fn(A, D_inv)
+        lap("rho(D^-1 A)")
     w = omega / rho
     Pp = np.empty(n + 1, dtype=np.int64)
     dnull = C.POINTER(C.c_double)()
@@ -649,12 +677,20 @@ def _extend_scalar(levels, smooth_l, keep, rho_fn):
     lap("smoothed prolongator")
     L.amgsetup_csr_transpose(n, n_agg, _lp(Pp), _ip(Pj), _dp(Px), _lp(Rp), _ip(Rj), _dp(Rx))
     lap("R = P^T")
-    # Galerkin product (R*A)*P
-    RA = _matmat((Rp, Rj, Rx), (Ap, Aj, Ax), (n_agg, n))
-    lap("R*A")
-    Ac = _matmat(RA, (Pp, Pj, Px), (n_agg, n_agg))
-    del RA
-    lap("(R*A)*P")
+    # Galerkin product (R*A)*P: on the GPU when A already sits in HBM (the spectral-radius estimate uploaded it),
+    # else row-parallel on the host -- the same products in the same order either way
+    Ac = None
+    if os.environ.get("AMG_SETUP_DEVICE_GALERKIN", "1") != "0":
+        from .util import galerkin_device
+        Ac = galerkin_device(A, (Rp, Rj, Rx), (Pp, Pj, Px), n_agg)
+        if Ac is not None:
+            lap("(R*A)*P on the device")
+    if Ac is None:
+        RA = _matmat((Rp, Rj, Rx), (Ap, Aj, Ax), (n_agg, n))
+        lap("R*A")
+        Ac = _matmat(RA, (Pp, Pj, Px), (n_agg, n_agg))
+        del RA
+        lap("(R*A)*P")
     P = _as_bsr11((Pp, Pj, Px), (n, n_agg))
     R = _as_bsr11((Rp, Rj, Rx), (n_agg, n))
     Anew = _as_bsr11(Ac, (n_agg, n_agg))

@@ -2,6 +2,7 @@
 // Each call stages its operands in HBM, runs the same HIP kernels the resident
 // hierarchy uses, and copies the mutated vectors back -- the calling convention
 // of /root/reference/pyamg/amg_core (numpy arrays in, results in place).
+#include <algorithm>
 #include "hier.hpp"
 
 #include <cstdlib>
@@ -300,9 +301,16 @@ int amgcore_block_jacobi_f64(const int Ap[], int Ap_size, const int Aj[], int Aj
     CHK(dt.from_host(temp, sizeof(double) * (size_t)temp_size));
     CHK(dd.from_host(Tx, sizeof(double) * (size_t)Tx_size));
     // relaxation.h:686-688: temp[i*bs..] = x[i*bs..] for the swept block rows
-    for (int r : rows)
-        AMG_HIP(hipMemcpyAsync(dt.d() + (long)r * blocksize, dx.d() + (long)r * blocksize,
-                               sizeof(double) * (size_t)blocksize, hipMemcpyDeviceToDevice, nullptr));
+    if (row_step == 1 || row_step == -1) {
+        // a contiguous range of block rows: one copy (not one per block row)
+        const int lo = *std::min_element(rows.begin(), rows.end());
+        AMG_HIP(hipMemcpyAsync(dt.d() + (long)lo * blocksize, dx.d() + (long)lo * blocksize,
+                               sizeof(double) * (size_t)rows.size() * (size_t)blocksize, hipMemcpyDeviceToDevice, nullptr));
+    } else {
+        for (int r : rows)
+            AMG_HIP(hipMemcpyAsync(dt.d() + (long)r * blocksize, dx.d() + (long)r * blocksize,
+                                   sizeof(double) * (size_t)blocksize, hipMemcpyDeviceToDevice, nullptr));
+    }
     CHK(sweep_block_schedule(sh.S, BM_BLOCK_JACOBI, dd.d(), dt.d(), dx.d(), db.d(), omega[0], false, nullptr));
     AMG_HIP(hipDeviceSynchronize());
     CHK(dx.to_host(x, sizeof(double) * (size_t)x_size));

@@ -300,6 +300,31 @@ def release_device_operator(A):
             pass
 
 
+def galerkin_device(A, R, P, n_coarse):
+    """(R*A)*P on the GPU with scipy's csr_matmat arithmetic and output order (csrc/spgemm.hip), A being the HBM copy
+    the spectral-radius estimate left behind (device_operator); R, P = (indptr int64, indices int32, data f64).
+    Returns (Cp, Cj, Cx) or None when the device path does not apply (no HBM copy, operator not held as CSR, a row too
+    long for the device tables) -- the caller then runs its host products."""
+    import ctypes as C
+    op = getattr(A, "_amg_devop", None)
+    if op is None or not getattr(op, "h", None):
+        return None
+    from . import _lib
+    L = _lib.lib()
+    (Rp, Rj, Rx), (Pp, Pj, Px) = R, P
+    Cp = np.empty(n_coarse + 1, dtype=np.int64)
+    g = C.c_void_p()
+    rc = L.amg_hier_galerkin(op.h, 0, int(n_coarse), Rp.ctypes.data, Rj.ctypes.data, Rx.ctypes.data,
+                             Pp.ctypes.data, Pj.ctypes.data, Px.ctypes.data, Cp.ctypes.data, C.byref(g))
+    if rc != 0:
+        return None
+    nnz = int(Cp[n_coarse])
+    Cj = np.empty(nnz, dtype=np.intc)
+    Cx = np.empty(nnz, dtype=np.float64)
+    _lib.check(L.amg_galerkin_fetch(g, Cj.ctypes.data, Cx.ctypes.data))
+    return Cp, Cj, Cx
+
+
 def use_device_for(A):
     if A.shape[0] < DEVICE_RHO_MIN_ROWS:
         return False

@@ -1277,3 +1277,79 @@ def test_krylov_and_callable_coarse_solvers_and_smoothing_list():
         res = []
         ml.solve(b, tol=1e-8, maxiter=30, residuals=res)
         assert (res[-1] / res[0]) ** (1.0 / len(res)) < 0.95, (pre, post)
+
+
+# ---------------------------------------------------------------------------
+# setup on the device: Galerkin products (csrc/spgemm.hip)
+# ---------------------------------------------------------------------------
+def _device_matmat(A, B):
+    import ctypes as C
+    from pyamg_amd import _lib
+    L = _lib.lib()
+    A = sps.csr_matrix(A); B = sps.csr_matrix(B)
+    Ap = A.indptr.astype(np.int64); Aj = A.indices.astype(np.intc); Ax = A.data.astype(np.float64)
+    Bp = B.indptr.astype(np.int64); Bj = B.indices.astype(np.intc); Bx = B.data.astype(np.float64)
+    Cp = np.empty(A.shape[0] + 1, dtype=np.int64)
+    g = C.c_void_p()
+    _lib.check(L.amg_csr_matmat_device(A.shape[0], A.shape[1], B.shape[1], Ap.ctypes.data, Aj.ctypes.data, Ax.ctypes.data,
+                                       Bp.ctypes.data, Bj.ctypes.data, Bx.ctypes.data, Cp.ctypes.data, C.byref(g)))
+    Cj = np.empty(int(Cp[-1]), dtype=np.intc); Cx = np.empty(int(Cp[-1]))
+    _lib.check(L.amg_galerkin_fetch(g, Cj.ctypes.data, Cx.ctypes.data))
+    return Cp, Cj, Cx
+
+
+@pytest.mark.gpu
+def test_device_csr_matmat_is_scipys_bit_for_bit():
+    """C = A*B on the GPU (one thread per output row, private hash table in HBM): scipy's csr_matmat products in
+    scipy's order -- same row pointer, same (unsorted, reverse first-touch) column order, same bits, exact zeros
+    dropped; rectangular, empty rows, cancelling products, unsorted operands"""
+    from pyamg_amd.aggregation import poisson as native
+    rng = np.random.RandomState(5)
+
+    def rnd(n, m, k):
+        rows = np.repeat(np.arange(n), k); cols = rng.randint(0, m, size=n * k)
+        M = sps.csr_matrix((rng.randn(n * k), (rows, cols)), shape=(n, m)); M.sum_duplicates(); return M
+    cases = [(rnd(300, 200, 5), rnd(200, 150, 4)),
+             (native((17, 19, 13)), native((17, 19, 13))),
+             (rnd(1000, 50, 3), rnd(50, 4000, 40)),
+             (sps.csr_matrix((5, 7)), rnd(7, 3, 2))]
+    # exact cancellation: (1, -1) against equal rows -> the zero results must be dropped as scipy drops them
+    Z = sps.csr_matrix(np.array([[1.0, -1.0, 0.0], [2.0, 0.0, 1.0]]))
+    W = sps.csr_matrix(np.array([[3.0, 4.0], [3.0, 4.0], [0.0, 5.0]]))
+    cases.append((Z, W))
+    # unsorted operand (the product of two others, as scipy leaves it)
+    U = rnd(400, 300, 6) @ rnd(300, 350, 5)
+    cases.append((U, rnd(350, 200, 4)))
+    for A, B in cases:
+        Cp, Cj, Cx = _device_matmat(A, B)
+        ref = sps.csr_matrix(A) @ sps.csr_matrix(B)
+        assert np.array_equal(Cp, ref.indptr), (A.shape, B.shape)
+        assert np.array_equal(Cj, ref.indices)
+        assert np.array_equal(Cx, ref.data)
+
+
+@pytest.mark.gpu
+def test_device_galerkin_product_equals_the_host_products():
+    """util.galerkin_device: (R*A)*P from the HBM copy of A that the spectral-radius estimate leaves behind = the host
+    restatement (aggregation._matmat) = scipy, bit for bit, on a smoothed-aggregation level (A in CSR and as BSR(1,1))"""
+    from pyamg_amd import util
+    from pyamg_amd.aggregation import _matmat, _csr_arrays64
+    g = golden_io.load_hier("sa_cheb2_3d")
+    for l in (0, 1):
+        A = g["levels"][l]["A"]; P = sps.csr_matrix(g["levels"][l]["P"]); R = sps.csr_matrix(g["levels"][l]["R"])
+        nc = P.shape[1]
+        util.device_operator(A)
+        try:
+            Ra, Pa = _csr_arrays64(R), _csr_arrays64(P)
+            out = util.galerkin_device(A, Ra, Pa, nc)
+            if l == 1 and out is None:
+                continue              # rows of more than 1024 products stay with the host product (csrc/spgemm.hip)
+            assert out is not None
+            RA = _matmat(Ra, _csr_arrays64(A), (nc, A.shape[0]))
+            ref = _matmat(RA, Pa, (nc, nc))
+            for a, b in zip(out, ref):
+                assert np.array_equal(a, b)
+            sc = (R @ sps.csr_matrix(A)) @ P
+            assert np.array_equal(out[0], sc.indptr) and np.array_equal(out[1], sc.indices) and np.array_equal(out[2], sc.data)
+        finally:
+            util.release_device_operator(A)
