@@ -406,8 +406,8 @@ void amg_set_tile_target(int t);
  * A is level `level` of a hierarchy handle that already holds it in HBM as CSR (the handle behind the setup-time
  * spectral-radius estimate); R, P are host CSR arrays with 64-bit row pointers.  Cp receives n_coarse + 1 offsets;
  * amg_galerkin_fetch copies the Cp[n_coarse] columns / values to the host and releases the product.
- * AMG_EINVAL (nothing allocated) when the operator is not held as CSR or a row needs more than 1024 products (one thread per
- * row with a private table stops paying there). */
+ * AMG_EINVAL (nothing allocated) when the operator is not held as CSR or a row has more distinct result columns than
+ * the device tables hold (2048 for rows of more than 1024 products on large levels). */
 typedef struct amg_galerkin amg_galerkin;
 int amg_hier_galerkin(amg_hier *h, int level, int n_coarse, const int64_t *Rp, const int *Rj, const double *Rx,
                       const int64_t *Pp, const int *Pj, const double *Px, int64_t *Cp, amg_galerkin **out);

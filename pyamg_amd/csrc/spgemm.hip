@@ -3,8 +3,8 @@
 // R * A * P) -- per output row the products are accumulated in the order (entry of A's row, entry of B's row), the
 // output columns come out in REVERSE first-touch order, exact-zero results are dropped.
 //
-// One thread per output row, a private open-addressing table in HBM per resident thread (keys, running sums, the
-// insertion order).  The accesses of a row are sequential by construction -- that IS the summation order -- so there
+// Short rows: one thread per output row, a private open-addressing table in HBM per resident thread (keys, running
+// sums, the insertion order); long rows of large levels: one wave per row, table in LDS (spgemm_wave_kernel).  The accesses of a row are sequential by construction -- that IS the summation order -- so there
 // is nothing to share between lanes; what the GPU adds is ~10^5 rows in flight against the latency of the table
 // accesses.  Two passes (count the non-zero results of every row, then form them again and write them at their final
 // places): both do the full arithmetic, neither allocates per row.  Bit-identical to the host restatement
@@ -123,6 +123,82 @@ __global__ __launch_bounds__(256) void spgemm_rows_kernel(int n_row, const long 
     }
 }
 
+// Long rows (thousands of products, e.g. the Galerkin product of the second level of a 3-D hierarchy): one WAVE per
+// output row, the table in LDS.  The entries of the left-hand row are taken strictly one after the other; the lanes
+// take the entries of the right-hand row that entry selects -- distinct columns, so no two lanes ever add to the
+// same sum in one step and every sum still receives its products in the sequential order.  New columns of a step are
+// numbered in lane (= entry) order by a ballot, which is the sequential first-touch order.  A row whose distinct
+// columns do not fit the table raises `overflow` (the caller then takes its host path).
+constexpr int WCAP = 4096;                 // table entries per wave: 64 KB of LDS, two waves per compute unit
+template <bool FILL>
+__global__ __launch_bounds__(64) void spgemm_wave_kernel(int n_row, const long *Ap, const int *Aj, const double *Ax,
+                                                        const long *Bp, const int *Bj, const double *Bx, int *count,
+                                                        const long *Cp, int *Cj, double *Cx, int *overflow)
+{
+    __shared__ int key[WCAP];
+    __shared__ double sum[WCAP];
+    __shared__ int ord[WCAP];
+    const int lane = threadIdx.x;
+    const unsigned mask = WCAP - 1;
+    for (int q = lane; q < WCAP; q += 64) key[q] = -1;
+    __syncthreads();
+    for (long i = blockIdx.x; i < n_row; i += gridDim.x) {
+        int n_ins = 0;
+        bool bad = false;
+        for (long jj = Ap[i]; jj < Ap[i + 1] && !bad; ++jj) {
+            const int j = Aj[jj];
+            const double v = Ax[jj];
+            const long b0 = Bp[j], b1 = Bp[j + 1];
+            for (long base = b0; base < b1; base += 64) {
+                if (n_ins + 64 > WCAP / 2) { bad = true; break; }          // keep the table at most half full
+                const long kk = base + lane;
+                bool inserted = false;
+                int h = 0;
+                if (kk < b1) {
+                    const int c = Bj[kk];
+                    h = (int)(((unsigned)c * 2654435761u) & mask);
+                    for (;;) {
+                        const int k = atomicCAS(&key[h], -1, c);
+                        if (k == -1) { inserted = true; sum[h] = 0.0; break; }
+                        if (k == c) break;
+                        h = (h + 1) & (int)mask;
+                    }
+                    const double p = v * Bx[kk];
+                    sum[h] = sum[h] + p;
+                }
+                const unsigned long long m = __ballot(inserted);
+                if (inserted) ord[n_ins + __popcll(m & ((1ULL << lane) - 1ULL))] = h;
+                n_ins += __popcll(m);
+                __syncthreads();                                            // (one wave: orders the LDS accesses of the step)
+            }
+        }
+        if (bad) { if (lane == 0) *overflow = 1; }
+        if (FILL) {
+            long at = Cp[i];
+            for (int q0 = n_ins - 1; q0 >= 0; q0 -= 64) {                   // reverse first-touch order, zeros dropped
+                const int q = q0 - lane;
+                double sv = 0.0; int kv = 0;
+                if (q >= 0) { const int h = ord[q]; sv = sum[h]; kv = key[h]; }
+                const bool keep = (q >= 0) && sv != 0.0 && !bad;
+                const unsigned long long m = __ballot(keep);
+                if (keep) { const long w = at + __popcll(m & ((1ULL << lane) - 1ULL)); Cj[w] = kv; Cx[w] = sv; }
+                at += __popcll(m);
+            }
+        } else {
+            int nz = 0;
+            for (int q0 = 0; q0 < n_ins; q0 += 64) {
+                const int q = q0 + lane;
+                const bool keep = (q < n_ins) && sum[ord[q]] != 0.0;
+                nz += __popcll(__ballot(keep));
+            }
+            if (lane == 0) count[i] = nz;
+        }
+        __syncthreads();
+        for (int q = lane; q < n_ins; q += 64) key[ord[q]] = -1;
+        __syncthreads();
+    }
+}
+
 int upload_dcsr(DCsr &M, int n_row, int n_col, const long *Ap, const int *Aj, const double *Ax)
 {
     M.n_row = n_row; M.n_col = n_col; M.nnz = Ap[n_row];
@@ -148,11 +224,46 @@ int matmat(const DCsr &A, const DCsr &B, DCsr &C)
     AMG_HIP(hipMemcpy(hu.data(), upper, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
     hipFree(upper);
     const int max_upper = n ? *std::max_element(hu.begin(), hu.end()) : 0;
-    // one thread per row pays while the private tables stay small (and many threads fit): beyond ~1000 products per
-    // row the host's row-parallel product is faster (measured on the 15.6 M-row level of the 500^3 hierarchy)
-    if (max_upper > 1024) { set_error("spgemm: a row with more than 1024 products (host path)"); return AMG_EINVAL; }
     int cap = 64;
-    while (cap < 2 * max_upper) cap <<= 1;
+    while (cap < 2 * max_upper && cap < (1 << 30)) cap <<= 1;
+    // one thread per row (private table in HBM) pays while the tables stay small or the rows are few; long rows of a
+    // large level go one wave per row with the table in LDS
+    const bool by_thread = max_upper <= 1024 || (double)n * (double)cap * 16.0 <= 2.0e9;
+    if (!by_thread) {
+        int *count = nullptr, *overflow = nullptr;
+        AMG_HIP(hipMalloc((void **)&count, sizeof(int) * (size_t)std::max(n, 1)));
+        AMG_HIP(hipMalloc((void **)&overflow, sizeof(int)));
+        AMG_HIP(hipMemset(overflow, 0, sizeof(int)));
+        const int blocks = std::min(n, 256 * 2 * 4);
+        hipLaunchKernelGGL((spgemm_wave_kernel<false>), dim3(blocks), dim3(64), 0, nullptr, n, A.Ap, A.Aj, A.Ax, B.Ap, B.Aj, B.Ax,
+                           count, (const long *)nullptr, (int *)nullptr, (double *)nullptr, overflow);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return hip_fail(e, "spgemm wave count launch", __FILE__, __LINE__);
+        int ovf = 0;
+        AMG_HIP(hipMemcpy(&ovf, overflow, sizeof(int), hipMemcpyDeviceToHost));
+        if (ovf) {
+            hipFree(count); hipFree(overflow);
+            set_error("spgemm: a row with more distinct columns than the LDS table holds (host path)");
+            return AMG_EINVAL;
+        }
+        std::vector<int> hc((size_t)n);
+        AMG_HIP(hipMemcpy(hc.data(), count, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
+        std::vector<long> cp((size_t)n + 1);
+        cp[0] = 0;
+        for (int i = 0; i < n; ++i) cp[(size_t)i + 1] = cp[(size_t)i] + hc[(size_t)i];
+        C.nnz = cp[(size_t)n];
+        AMG_HIP(hipMalloc((void **)&C.Ap, sizeof(long) * ((size_t)n + 1)));
+        AMG_HIP(hipMalloc((void **)&C.Aj, sizeof(int) * (size_t)std::max(C.nnz, 1L)));
+        AMG_HIP(hipMalloc((void **)&C.Ax, sizeof(double) * (size_t)std::max(C.nnz, 1L)));
+        AMG_HIP(hipMemcpy(C.Ap, cp.data(), sizeof(long) * ((size_t)n + 1), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL((spgemm_wave_kernel<true>), dim3(blocks), dim3(64), 0, nullptr, n, A.Ap, A.Aj, A.Ax, B.Ap, B.Aj, B.Ax,
+                           count, C.Ap, C.Aj, C.Ax, overflow);
+        e = hipGetLastError();
+        if (e != hipSuccess) return hip_fail(e, "spgemm wave fill launch", __FILE__, __LINE__);
+        AMG_HIP(hipDeviceSynchronize());
+        hipFree(count); hipFree(overflow);
+        return 0;
+    }
     // resident threads: as many as 3 GB of tables allow, at most 512 per compute unit
     long threads = std::min<long>(256L * 512L, (3L << 30) / ((long)cap * 16L));
     threads = std::max<long>(256, std::min<long>(threads, ((long)n + 255) / 256 * 256));

@@ -1329,6 +1329,27 @@ def test_device_csr_matmat_is_scipys_bit_for_bit():
 
 
 @pytest.mark.gpu
+def test_device_csr_matmat_long_rows_one_wave_per_row():
+    """rows of ~2000 products on a level too large for per-thread tables go one wave per row with the table in LDS
+    (lanes over the right-hand row, left-hand entries in order): still scipy's bits and order; a row with more distinct
+    columns than the table holds is refused (AMG_EINVAL -> the caller's host path), not mis-computed"""
+    from pyamg_amd import _lib
+    rng = np.random.RandomState(11)
+
+    def rnd(n, m, k):
+        rows = np.repeat(np.arange(n), k); cols = rng.randint(0, m, size=n * k)
+        M = sps.csr_matrix((rng.randn(n * k), (rows, cols)), shape=(n, m)); M.sum_duplicates(); return M
+    A = rnd(40000, 500, 40)
+    B = rnd(500, 800, 50)
+    Cp, Cj, Cx = _device_matmat(A, B)
+    ref = A @ B
+    assert np.array_equal(Cp, ref.indptr) and np.array_equal(Cj, ref.indices) and np.array_equal(Cx, ref.data)
+    Bwide = rnd(500, 60000, 70)                                  # ~2700 distinct columns per output row
+    with pytest.raises(ValueError):
+        _device_matmat(A, Bwide)
+
+
+@pytest.mark.gpu
 def test_device_galerkin_product_equals_the_host_products():
     """util.galerkin_device: (R*A)*P from the HBM copy of A that the spectral-radius estimate leaves behind = the host
     restatement (aggregation._matmat) = scipy, bit for bit, on a smoothed-aggregation level (A in CSR and as BSR(1,1))"""
