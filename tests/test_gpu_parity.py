@@ -1320,6 +1320,10 @@ def test_device_csr_matmat_is_scipys_bit_for_bit():
     # unsorted operand (the product of two others, as scipy leaves it)
     U = rnd(400, 300, 6) @ rnd(300, 350, 5)
     cases.append((U, rnd(350, 200, 4)))
+    # rows of 2 products next to rows of ~600 products with ~550 distinct columns: the small first-tier tables (128
+    # distinct columns) overflow for the long rows only, which are redone with the large tables
+    mixed = sps.vstack([rnd(500, 200, 2), rnd(300, 200, 30), rnd(200, 200, 1)]).tocsr()
+    cases.append((mixed, rnd(200, 5000, 20)))
     for A, B in cases:
         Cp, Cj, Cx = _device_matmat(A, B)
         ref = sps.csr_matrix(A) @ sps.csr_matrix(B)
@@ -1347,6 +1351,16 @@ def test_device_csr_matmat_long_rows_one_wave_per_row():
     Bwide = rnd(500, 60000, 70)                                  # ~2700 distinct columns per output row
     with pytest.raises(ValueError):
         _device_matmat(A, Bwide)
+    # every lane-group width of the LDS kernel: right-hand rows of ~5, ~14, ~30 and ~60 entries (8 / 16 / 32 / 64
+    # lanes per output row), ragged left-hand rows incl. empty ones, more rows than one pass of the grid covers
+    for kb in (5, 14, 30, 60):
+        lens = rng.randint(0, 9, size=30000)
+        rows = np.repeat(np.arange(30000), lens); cols = rng.randint(0, 400, size=rows.size)
+        A2 = sps.csr_matrix((rng.randn(rows.size), (rows, cols)), shape=(30000, 400)); A2.sum_duplicates()
+        B2 = rnd(400, 300, kb)
+        Cp, Cj, Cx = _device_matmat(A2, B2)
+        ref = A2 @ B2
+        assert np.array_equal(Cp, ref.indptr) and np.array_equal(Cj, ref.indices) and np.array_equal(Cx, ref.data), kb
 
 
 @pytest.mark.gpu
