@@ -3,12 +3,13 @@
 // R * A * P) -- per output row the products are accumulated in the order (entry of A's row, entry of B's row), the
 // output columns come out in REVERSE first-touch order, exact-zero results are dropped.
 //
-// Short rows: one thread per output row, a private open-addressing table in HBM per resident thread (keys, running
-// sums, the insertion order); long rows of large levels: one wave per row, table in LDS (spgemm_wave_kernel).  The accesses of a row are sequential by construction -- that IS the summation order -- so there
-// is nothing to share between lanes; what the GPU adds is ~10^5 rows in flight against the latency of the table
-// accesses.  Two passes (count the non-zero results of every row, then form them again and write them at their final
-// places): both do the full arithmetic, neither allocates per row.  Bit-identical to the host restatement
-// (setup_host.cpp amgsetup_csr_matmat_*) and to scipy: same products, same order, separate multiply and add.
+// Main kernel (spgemm_group_kernel): G lanes per output row, every row with a table of its own in LDS; left-hand
+// entries strictly in order, the lanes over the right-hand row each entry selects.  Fall-backs for rows whose distinct
+// columns outgrow the LDS table: the whole wave per row, then one thread per row with private tables in HBM
+// (spgemm_rows_kernel, two tiers), then the caller's host path.  Every path runs a count pass (non-zero results per
+// row) and a fill pass (results written at their final places); both do the full arithmetic, neither allocates per
+// row.  Bit-identical to the host restatement (setup_host.cpp amgsetup_csr_matmat_*) and to scipy: same products, same
+// order, separate multiply and add.
 #include "hier.hpp"
 
 #include <algorithm>
