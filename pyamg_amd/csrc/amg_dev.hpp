@@ -158,7 +158,7 @@ int launch_perm_gather(const int *rowmap, const double *x, const double *b, cons
                        int n, hipStream_t st);
 int launch_perm_scatter(const int *rowmap, const double *xp, double *x, int n, hipStream_t st);
 int launch_gs_chain2(const int *lp, const double *val, const int *code, const int *off, double *dummy, int pf,
-                     int l_first, int nlevels, int width, bool reverse, bool bsr1, double *x, const double *bd, hipStream_t st);
+                     int l_first, int nlevels, int width, bool reverse, bool bsr1, double *x, const double *bd, int nzero, hipStream_t st);
 int gs_chain_max_rows();
 bool gs_chain_enabled();
 int gs_chain_generation();

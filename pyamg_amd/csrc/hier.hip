@@ -717,7 +717,7 @@ int gs_sweep_csr(const Schedule &S, bool bsr1, double *x, const double *b, const
             else { CHK(launches(ch.second, pos)); pos = ch.first; }
             if (perm)
                 CHK(launch_gs_chain2(S.level_ptr_dev, S.c2_val, reverse ? S.c2_code_b : S.c2_code_f, S.c2_off, S.c2_dummy, S.c2_pf,
-                                     ch.first, ch.second - ch.first, width, reverse, bsr1, xs, S.bd, st));
+                                     ch.first, ch.second - ch.first, width, reverse, bsr1, xs, S.bd, S.ntasks, st));
             else
                 CHK(launch_gs_chain(G, rowmap, S.diagpos, S.level_ptr_dev, ch.first, ch.second - ch.first, width, reverse, bsr1, xs, bs, st));
         }

@@ -751,7 +751,7 @@ __global__ __launch_bounds__(WGS) void gs_chain_kernel(const int *Ap, const int 
 // ---------------------------------------------------------------------------
 template <bool BSR1, int PF, int WGS>
 __global__ __launch_bounds__(WGS) void gs_chain2_kernel(const int *lp, const double *cval, const int *ccode, const int *coff,
-                                                       double *x, const double2 *bd, double *dummy, int l_first, int nl, int reverse)
+                                                       double *x, const double2 *bd, double *dummy, int nzero, int l_first, int nl, int reverse)
 {
     constexpr int D = CHAIN2_D, NB = CHAIN2_D + 1;
     // Vector-memory results return in issue order, so whatever an iteration needs must have been requested at least
@@ -824,8 +824,9 @@ __global__ __launch_bounds__(WGS) void gs_chain2_kernel(const int *lp, const dou
         for (int u = 0; u < PF; ++u) {
             s.code[u] = c.code[u];
             if (KEEP_LA) s.la[u] = min(~(unsigned)c.code[u], RING_BYTES);     // where in the ring (the spare word if not there), off the critical path
-            // a ring operand's slot requests position 0 (one line for the whole wave) and drops it
-            s.xv[u] = load_fresh((const double *)at_bytes(x, (unsigned)max(c.code[u], 0) * 8u));
+            // a ring operand's slot requests the permanent 0.0 behind the last unknown (one line for the whole wave):
+            // the operand is then `ring value | memory value`, one of the two being all zero bits
+            s.xv[u] = load_fresh((const double *)at_bytes(x, min((unsigned)c.code[u], (unsigned)nzero) * 8u));
         }
         return s;
     };
@@ -853,10 +854,10 @@ __global__ __launch_bounds__(WGS) void gs_chain2_kernel(const int *lp, const dou
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
-            // a bitwise blend instead of `code < 0 ? lv : xv`: the compiler would sink the LDS read into a branch of
-            // its own (one read, one wait, per slot) if the value were only conditionally used
-            const long long m = (long long)(cur.code[u] >> 31);
-            xo[u] = __longlong_as_double((__double_as_longlong(lv[u]) & m) | (__double_as_longlong(cur.xv[u]) & ~m));
+            // exactly one of the two is the operand, the other is +0.0 (the spare word behind the ring / the permanent
+            // zero behind x): a bitwise OR selects it without a test (a select on `code < 0` would also let the compiler
+            // sink the LDS read into a branch of its own: one read, one wait, per slot)
+            xo[u] = __longlong_as_double(__double_as_longlong(lv[u]) | __double_as_longlong(cur.xv[u]));
         }
         double acc = BSR1 ? cur.bb : 0.0;
 #pragma unroll
@@ -893,14 +894,14 @@ __global__ __launch_bounds__(WGS) void gs_chain2_kernel(const int *lp, const dou
 static int chain_threads(int width) { return width <= 64 ? 64 : (width <= 128 ? 128 : (width <= 256 ? 256 : 512)); }
 
 int launch_gs_chain2(const int *lp, const double *val, const int *code, const int *off, double *dummy, int pf,
-                     int l_first, int nlevels, int width, bool reverse, bool bsr1, double *x, const double *bd, hipStream_t st)
+                     int l_first, int nlevels, int width, bool reverse, bool bsr1, double *x, const double *bd, int nzero, hipStream_t st)
 {
     if (nlevels <= 0) return 0;
     if (nlevels > CHAIN2_LMAX) { set_error("gs_chain2: run longer than one launch holds"); return -4; }
     if (width > CHAIN2_WG) { set_error("gs_chain2: level wider than the workgroup"); return -4; }
     const int wg = chain_threads(width);
 #define C2_LAUNCH(B, P, W) hipLaunchKernelGGL((gs_chain2_kernel<B, P, W>), dim3(1), dim3(W), 0, st, lp, val, code, off, x, \
-                                              (const double2 *)bd, dummy, l_first, nlevels, reverse ? 1 : 0)
+                                              (const double2 *)bd, dummy, nzero, l_first, nlevels, reverse ? 1 : 0)
 #define C2_WIDTH(B, P) do { if (wg == 64) C2_LAUNCH(B, P, 64); else if (wg == 128) C2_LAUNCH(B, P, 128); \
                             else if (wg == 256) C2_LAUNCH(B, P, 256); else C2_LAUNCH(B, P, 512); } while (0)
     if (pf == 4) { if (bsr1) C2_WIDTH(true, 4); else C2_WIDTH(false, 4); }
