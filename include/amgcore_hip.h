@@ -380,8 +380,9 @@ void amg_set_xcd_period(int on);
 /* 1 (default): operators whose rows are subsets of one stencil of <= 32 offsets are applied from
  * the stencil form (padded values + row masks, no indices); 0: from the pattern / CSR forms */
 void amg_set_stencil_form(int on);
-/* stencil form: 1 (default) two consecutive rows per lane, every streamed operand a 16-byte access (half the
- * vector-memory instructions for the same bytes); 0: one row per lane.  Same bits. */
+/* stencil form: two consecutive rows per lane, every streamed operand a 16-byte access (half the vector-memory
+ * instructions for the same bytes): 1 (default) for launches of 30 M rows and more with stencils of up to 7 offsets
+ * (where it is measured faster), 2 always, 0 never (one row per lane).  Same bits. */
 void amg_set_stencil_pairs(int on);
 /* runs of narrow Gauss-Seidel dependency levels are swept by one workgroup in one launch: 2 (default) the sweep runs
  * in level-order numbering, new values are handed from level to level through LDS and everything else is requested

@@ -1691,8 +1691,12 @@ static int launch_stencil_mode(const StreamArgs &a, const DevCsr &M, hipStream_t
         }
     }
     // two rows per lane needs the vectors it streams 16-byte aligned
-    // (the opt-in value index keeps one row per lane: measured faster there)
-    const bool pairs = g_stencil_pairs != 0 && M.st_nu <= 16 && E.codes == nullptr &&
+    // Measured (tools/pairs_size_ab.py, tools/pairs_ab.py): faster from ~30 M rows up with stencils of up to 7 offsets
+    // (500^3: 1.74 vs 1.82 ms); slower on small levels (4 M rows, Jacobi mode: +12 %) and with the 16-slot
+    // instantiation on coarse levels (+40 % at 10 us), where a launch has too few waves to need fewer instructions.
+    // g_stencil_pairs = 2 forces it.  (The opt-in value index keeps one row per lane: measured faster there.)
+    const bool big = (long)(a.row_hi - a.row_lo) >= 30000000L && M.st_nu <= 7;
+    const bool pairs = (g_stencil_pairs >= 2 || (g_stencil_pairs == 1 && big)) && M.st_nu <= 16 && E.codes == nullptr &&
                        (((uintptr_t)b.b | (uintptr_t)b.out | (uintptr_t)b.v2 | (uintptr_t)b.xg) & 15u) == 0;
     if (pairs && M.st_nu <= 7)
         hipLaunchKernelGGL((stencil2_kernel<MODE, 8>), dim3(grid), dim3(WG2), 0, st, b, E, g_xcd_chunk);

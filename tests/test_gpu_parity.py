@@ -1388,3 +1388,34 @@ def test_device_galerkin_product_equals_the_host_products():
             assert np.array_equal(out[0], sc.indptr) and np.array_equal(out[1], sc.indices) and np.array_equal(out[2], sc.data)
         finally:
             util.release_device_operator(A)
+
+
+@pytest.mark.gpu
+def test_stencil_two_rows_per_lane_same_bits():
+    """stencil2_kernel (two rows per lane, 16-byte accesses; the default only from 30 M rows up) forced on small
+    hierarchies: every mode the cycle uses -- residual, fused norm, Chebyshev steps, Jacobi, prolongation add -- gives
+    the iterates and residual histories of the one-row kernel bit for bit, for 3-D / 2-D stencils, odd sizes (a last
+    block with a single live row) and the 16-slot instantiation of coarse 2-D levels"""
+    from pyamg_amd import _lib
+    from pyamg_amd.aggregation import poisson as native, smoothed_aggregation_solver
+    L = _lib.lib()
+    cheb = ("chebyshev", {"degree": 3})
+    jac = ("jacobi", {"omega": 4.0 / 3.0, "iterations": 2})
+    builds = [lambda: smoothed_aggregation_solver(native((33, 31, 29)), presmoother=cheb, postsmoother=cheb),
+              lambda: smoothed_aggregation_solver(native((41, 37, 23)), presmoother=jac, postsmoother=jac),
+              lambda: smoothed_aggregation_solver(native((301, 257)), presmoother=jac, postsmoother=cheb)]
+    try:
+        for build in builds:
+            np.random.seed(1)
+            ml = build()
+            b = np.random.rand(ml.levels[0].A.shape[0])
+            out = {}
+            for on in (2, 0):
+                L.amg_set_stencil_pairs(on)
+                res = []
+                x = ml.solve(b, tol=1e-30, maxiter=6, residuals=res, cycle="W" if on is None else "V")
+                out[on] = (x, np.array(res))
+            assert np.array_equal(out[0][0], out[2][0])
+            assert np.array_equal(out[0][1], out[2][1])
+    finally:
+        L.amg_set_stencil_pairs(1)
