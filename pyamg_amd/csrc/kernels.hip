@@ -130,8 +130,17 @@ template <int MODE> struct ModeTraits {
     static constexpr bool sub = (MODE == SM_JACOBI_BSR1 || MODE == SM_GS_BSR1);
 };
 
+// (A/B builds: -DAMG_ROWSUM_BATCH=4, -DAMG_STREAM_MIN_WAVES=8; tools/lib_ab.py)
+#ifndef AMG_ROWSUM_BATCH
+#define AMG_ROWSUM_BATCH 8
+#endif
+#ifdef AMG_STREAM_MIN_WAVES
+#define AMG_STREAM_BOUNDS __launch_bounds__(WG, AMG_STREAM_MIN_WAVES)
+#else
+#define AMG_STREAM_BOUNDS __launch_bounds__(WG)
+#endif
 template <int MODE, int VEC>
-__global__ __launch_bounds__(WG) void csr_stream_kernel(StreamArgs a, int xcd_chunk, int rpb)
+__global__ AMG_STREAM_BOUNDS void csr_stream_kernel(StreamArgs a, int xcd_chunk, int rpb)
 {
     const long nnz_total = a.nnz_total;
     const double gscale = a.gscale;      // 1.0 unless the operand is scaled on the fly (1.0*x is exact)
@@ -305,12 +314,13 @@ __global__ __launch_bounds__(WG) void csr_stream_kernel(StreamArgs a, int xcd_ch
             // the plain loop compiles to -- made this phase ~1.5 us of a workgroup's ~8 us on 27-entry rows), added
             // strictly left to right
             const int s = max(my_s, tile_lo), e2 = min(my_e, tile_hi);
-            for (int k = s; k < e2; k += 8) {
-                double p[8];
+            constexpr int RB = AMG_ROWSUM_BATCH;
+            for (int k = s; k < e2; k += RB) {
+                double p[RB];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) p[u] = sp[min(k + u, e2 - 1) - tile_lo];
+                for (int u = 0; u < RB; ++u) p[u] = sp[min(k + u, e2 - 1) - tile_lo];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < RB; ++u) {
                     const bool take = (k + u < e2) && !(MT::gs && k + u == dpos);
                     const double nxt = MT::sub ? (acc - p[u]) : (acc + p[u]);
                     acc = take ? nxt : acc;
