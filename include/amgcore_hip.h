@@ -236,7 +236,7 @@ int amg_hier_matvec(amg_hier *h, int lvl, int which, const double *x, double *y)
 /* bookkeeping for measurement */
 /* algorithmic bytes of one cycle per SURVEY.md section 8(d) */
 double amg_hier_cycle_bytes(amg_hier *h, int cycle);
-/* storage form level lvl's A is applied from: 0 CSR, 1 offset-pattern, 2 stencil */
+/* storage form level lvl's A is applied from: 0 CSR, 1 offset-pattern, 2 stencil, 3 sliced (SELL-64-sigma) */
 int amg_hier_operator_form(amg_hier *h, int lvl);
 /* OPT-IN value index for a level whose A is in stencil form and holds at most 255 distinct values (constant-
  * coefficient stencils): one-byte codes into a dictionary instead of the 8-byte values; the products use the
@@ -384,6 +384,10 @@ void amg_set_stencil_form(int on);
  * instructions for the same bytes): 1 (default) for launches of 30 M rows and more with stencils of up to 7 offsets
  * (where it is measured faster), 2 always, 0 never (one row per lane).  Same bits. */
 void amg_set_stencil_pairs(int on);
+/* operators without grid structure (Galerkin operators, restriction): 1 (default) whole-operator applications run from
+ * the sliced form (rows sorted by length in windows of 2048, slices of 64 rows stored entry-major: one lane per row,
+ * no row pointer, no LDS); 0: from CSR.  Same bits. */
+void amg_set_sell_form(int on);
 /* runs of narrow Gauss-Seidel dependency levels are swept by one workgroup in one launch: 2 (default) the sweep runs
  * in level-order numbering, new values are handed from level to level through LDS and everything else is requested
  * two levels ahead; 1 operands gathered back from L2 after each barrier (also what index lists and partitioned

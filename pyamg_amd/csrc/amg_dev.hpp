@@ -47,6 +47,18 @@ struct DevCsr {
     // holds a(i, i+U[u]) if bit u of mask[i] is set.  Values are laid out [block][slot][256 rows],
     // so every load of the kernel is issued up front, coalesced, with no row pointer, no column
     // index and no LDS staging; x[i+U[u]] is gathered speculatively and masked.
+    // Sliced form of an irregular operator (SELL-64-sigma; built on the device by build_sell): the rows of every window
+    // of 2048 are sorted by length (longest first, ties in row order), cut into slices of 64, and a slice's entries
+    // are stored entry-major -- entry k of its 64 rows side by side -- padded to the slice's longest row.  One wave per
+    // slice, one lane per row: no row pointer, no LDS, no barrier; every lane sums ITS row's entries in stored
+    // order, so results are bit-identical to the CSR kernel's.
+    int *sl_row = nullptr;         // [sl_nslices * 64] row of the slot (-1: padding slot)
+    unsigned short *sl_len = nullptr;  // [sl_nslices * 64] entries of that row
+    long *sl_off = nullptr;        // [sl_nslices + 1] first entry of the slice in sl_col / sl_val (multiples of 64)
+    int *sl_col = nullptr;
+    double *sl_val = nullptr;
+    int sl_nslices = 0;
+    long sl_entries = 0;           // padded entries stored
     double *st_vals = nullptr;     // [nblocks256 * st_nu * 256]
     void *st_mask = nullptr;       // [nrows] uint8 when |U| <= 7, else uint32; top bit = row not covered
     int st_nu = 0;                 // |U|
@@ -136,6 +148,12 @@ int launch_stream(StreamMode mode, const StreamArgs &a, hipStream_t st);
 int launch_pattern(StreamMode mode, const StreamArgs &a, const DevCsr &M, hipStream_t st);
 bool pattern_supports(StreamMode mode);
 int launch_stencil(StreamMode mode, const StreamArgs &a, const DevCsr &M, hipStream_t st);
+// the sliced form (DevCsr::sl_*): whole-operator applications in the modes sell_supports() names
+bool sell_supports(StreamMode mode);
+bool sell_enabled();
+void set_sell_form(int on);
+int launch_sell(StreamMode mode, const StreamArgs &a, const DevCsr &M, hipStream_t st);
+int build_sell(DevCsr &M, long *acct);         // from the CSR arrays already in HBM; leaves M untouched if not worth it
 int stencil_blocks(const StreamArgs &a, const DevCsr &M);   // workgroups (= SM_RESIDUAL_SUMSQ partials) of launch_stencil
 int launch_stencil_build(const DevCsr &M, const int *dict_slot, const unsigned *pat_mask, hipStream_t st);
 // value index: distinct values of st_vals into a 1024-slot table (EMPTY = all ones), then the byte codes
@@ -143,6 +161,7 @@ int launch_value_scan(const double *vals, long count, unsigned long long *table,
 int launch_value_encode(const double *vals, long count, const double *dict_sorted, int ndict, unsigned char *codes, int nu,
                         hipStream_t st);
 int config_epoch();                      // bumped by every set_* knob below
+void bump_config_epoch();
 // Gauss-Seidel: runs of dependency levels of at most gs_chain_max_rows() rows swept by ONE workgroup in
 // one launch (barrier between levels, next level's rows prefetched) instead of a launch per level
 int launch_gs_chain(const DevCsr &G, const int *rowmap, const int *diagpos, const int *level_ptr_dev, int l_first,

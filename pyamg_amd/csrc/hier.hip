@@ -51,6 +51,12 @@ void free_csr(DevCsr &M)
     if (M.pat) hipFree(M.pat);
     if (M.dict_ptr) hipFree(M.dict_ptr);
     if (M.dict_off) hipFree(M.dict_off);
+    if (M.sl_row) hipFree(M.sl_row);
+    if (M.sl_len) hipFree(M.sl_len);
+    if (M.sl_off) hipFree(M.sl_off);
+    if (M.sl_col) hipFree(M.sl_col);
+    if (M.sl_val) hipFree(M.sl_val);
+    M.sl_row = nullptr; M.sl_len = nullptr; M.sl_off = nullptr; M.sl_col = nullptr; M.sl_val = nullptr; M.sl_nslices = 0; M.sl_entries = 0;
     if (M.st_vals) hipFree(M.st_vals);
     if (M.st_mask) hipFree(M.st_mask);
     if (M.st_codes) hipFree(M.st_codes);
@@ -664,6 +670,8 @@ int apply_operator(const DevCsr &M, StreamMode mode, const StreamArgs &a, hipStr
     }
     if (M.st_vals && stencil_enabled() && pattern_supports(mode)) return launch_stencil(mode, a, M, st);
     if (M.pat && pattern_supports(mode)) return launch_pattern(mode, a, M, st);
+    if (M.sl_val && sell_enabled() && sell_supports(mode) && a.row_lo == 0 && a.row_hi == M.nrows && !a.rowmap && a.Aj == M.Aj)
+        return launch_sell(mode, a, M, st);
     return launch_stream(mode, a, st);
 }
 
@@ -1431,6 +1439,8 @@ int amg_hier_set_matrix(amg_hier *h, int lvl, int which, int fmt, int nrows, int
         expand_bsr(nrows / R, R, C, Ap, Aj, Ax, cp, cj, cx);
         CHK(upload_csr(M, nrows, ncols, cp.data(), cj.data(), cx.data(), &h->dev_bytes));
     }
+    // operators without grid structure: the sliced form (sell.hip) for whole-operator applications
+    if (M.Ap && !M.pat && !M.st_vals && !h->comm) CHK(build_sell(M, &h->dev_bytes));
     if (which == AMG_MAT_A) {
         if (nrows != ncols && !(h->comm && ncols > nrows)) { set_error("A must be square (row-partitioned: owned rows x [owned | halo] columns)"); return AMG_EINVAL; }
         L.fmt = fmt; L.R = R; L.C = C; L.hasA = true;
@@ -2118,6 +2128,8 @@ static double bytes_spmv_moved(const DevCsr &M)
     if (M.st_vals && stencil_enabled())     // padded values (or one-byte codes) + one mask word per row; no row pointer
         return ((M.st_vi_on && M.st_codes) ? 8.0 * (double)((M.st_nu + 7) / 8) : 8.0 * (double)M.st_nu) * 256.0 * (double)((M.nrows + 255) / 256) + (M.st_nu <= 7 ? 1.0 : 4.0) * M.nrows +
                8.0 * M.ncols + 8.0 * M.nrows;
+    if (!M.pat && M.sl_val && sell_enabled())    // padded entries, slot bookkeeping (row id + length), slice offsets; no row pointer
+        return 12.0 * (double)M.sl_entries + 6.0 * 64.0 * M.sl_nslices + 8.0 * (M.sl_nslices + 1.0) + 8.0 * M.ncols + 8.0 * M.nrows;
     if (!M.pat) {
         double idx = (M.Aj16 && index16_enabled()) ? (2.0 * M.i16_frac + 4.0 * (1.0 - M.i16_frac)) : 4.0;
         return (8.0 + idx) * (double)M.nnz + 4.0 * (M.nrows + 1.0) + 8.0 * M.ncols + 8.0 * M.nrows;
@@ -2208,7 +2220,8 @@ int amg_hier_operator_form(amg_hier *h, int lvl)
     if (!h || lvl < 0 || lvl >= h->nlevels) return -1;
     const DevCsr &M = h->lv[lvl].A;
     if (M.st_vals && stencil_enabled()) return 2;
-    return M.pat ? 1 : 0;
+    if (M.pat) return 1;
+    return (M.sl_val && sell_enabled()) ? 3 : 0;      // 3: sliced form (sell.hip)
 }
 double amg_hier_operator_bytes(amg_hier *h, int lvl, int moved)
 {
@@ -2386,6 +2399,7 @@ void amg_set_xcd_chunk(int c) { amg::set_xcd_chunk(c); }
 void amg_set_xcd_period(int on) { amg::set_xcd_period(on); }
 void amg_set_stencil_form(int on) { amg::set_stencil_form(on); }
 void amg_set_stencil_pairs(int on) { amg::set_stencil_pairs(on); }
+void amg_set_sell_form(int on) { amg::set_sell_form(on); }
 void amg_set_gs_chain(int on) { amg::set_gs_chain(on); }
 void amg_set_bsr_spmv(int on) { amg::set_bsr_spmv(on); }
 void amg_set_index16(int on) { amg::set_index16(on); }

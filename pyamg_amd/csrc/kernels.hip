@@ -51,6 +51,7 @@ static int g_tile_target = 2048;   // products per workgroup aimed at when choos
 // every change of a launch knob bumps this; hierarchies drop their captured graphs when they see a new value
 static int g_config_epoch = 0;
 int config_epoch() { return g_config_epoch; }
+void bump_config_epoch() { ++g_config_epoch; }
 void set_tile_target(int t) { g_tile_target = t > 0 ? t : 2048; ++g_config_epoch; }
 
 // Rows per workgroup for a matrix with `nnz` entries in `rows` rows: enough rows to fill about

@@ -1,0 +1,254 @@
+// Sliced form of irregular operators (DevCsr::sl_*, SELL-64-sigma) and its application kernel.
+//
+// csr_stream_kernel serves every operator without grid structure (the Galerkin operators A_1, A_2, ..., restriction,
+// prolongation).  A workgroup of it makes three DEPENDENT round trips -- row pointer, entries, gathered operands --
+// with barriers in between, and rocprofv3 shows ~80 % of its wave cycles waiting: it is bound
+// by that chain, not by bytes.  Here a wave owns a slice of 64 rows, a lane one row; the slice's entries are stored
+// entry-major (entry k of the 64 rows side by side, padded to the slice's longest row), so a lane's loads are
+// coalesced with its neighbours', need no row pointer and no LDS, and ALL of a row's entries (up to 32 per pass) are
+// requested before any is consumed: two round trips per slice, no barrier.  Rows are sorted by length inside windows
+// of 2048 (longest first, ties in row order) so that slices are nearly rectangular.
+// Every lane adds ITS row's products in stored order with separate multiply and add: bit-identical to the CSR kernel
+// (scipy csr_matvec / relaxation.h row loops) in every mode.
+#include "hier.hpp"
+
+#include <algorithm>
+#include <cstdlib>
+#include <vector>
+
+namespace amg {
+
+namespace {
+
+constexpr int SL_C = 64;            // rows per slice = lanes per wave
+constexpr int SL_SIGMA = 2048;      // rows per sorting window
+constexpr int SL_PASS = 32;         // entries of a row requested at once
+constexpr int SL_WG = 256;          // four slices per workgroup
+
+__device__ __forceinline__ int remap(int b, int nb, int chunk)       // kernels.hip remap_block: consecutive blocks to one XCD
+{
+    if (chunk <= 0) return b;
+    const int gsz = 8 * chunk, g = b / gsz, base = g * gsz;
+    const int n_g = min(gsz, nb - base), l = b - base;
+    const int xcd = l & 7, j = l >> 3, q = n_g >> 3, r = n_g & 7;
+    return base + xcd * q + min(xcd, r) + j;
+}
+
+// window sort: key = ((length + 1) << 11) | (2047 - position in window), sorted DESCENDING = longest row first, ties in
+// row order.  Bitonic network over the 2048 keys of a window in LDS.
+__global__ __launch_bounds__(1024) void sell_sort_kernel(int n, const int *Ap, int *sl_row, unsigned short *sl_len, int *slice_w)
+{
+    __shared__ unsigned key[SL_SIGMA];
+    const int w0 = blockIdx.x * SL_SIGMA;
+    for (int q = threadIdx.x; q < SL_SIGMA; q += 1024) {
+        const int i = w0 + q;
+        const unsigned len = (i < n) ? (unsigned)(Ap[i + 1] - Ap[i]) : 0u;
+        key[q] = (i < n) ? (((len + 1u) << 11) | (unsigned)(SL_SIGMA - 1 - q)) : 0u;      // slots past the last row: key 0, sorted last
+    }
+    __syncthreads();
+    for (int k = 2; k <= SL_SIGMA; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int q = threadIdx.x; q < SL_SIGMA; q += 1024) {
+                const int p = q ^ j;
+                if (p > q) {
+                    const unsigned a = key[q], b = key[p];
+                    const bool desc = (q & k) == 0;
+                    if (desc ? (a < b) : (a > b)) { key[q] = b; key[p] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    for (int q = threadIdx.x; q < SL_SIGMA; q += 1024) {
+        const unsigned kq = key[q];
+        const bool is_row = kq != 0u;
+        const int pos = SL_SIGMA - 1 - (int)(kq & 2047u);
+        const int len = is_row ? (int)(kq >> 11) - 1 : 0;
+        const int slot = w0 + q;
+        sl_row[slot] = is_row ? w0 + pos : -1;
+        sl_len[slot] = (unsigned short)len;
+        if ((q & (SL_C - 1)) == 0) slice_w[slot / SL_C] = len;                    // the slice's longest row comes first
+    }
+}
+
+// entries of the slices, entry-major; padding entries: column 0, value 0 (requested, never used)
+__global__ __launch_bounds__(SL_WG) void sell_fill_kernel(int nslices, const int *Ap, const int *Aj, const double *Ax, const int *sl_row,
+                                                         const unsigned short *sl_len, const long *sl_off, int *sl_col, double *sl_val)
+{
+    const int s = blockIdx.x * (SL_WG / SL_C) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (s >= nslices) return;
+    const long off = sl_off[s];
+    const int w = (int)((sl_off[s + 1] - off) >> 6);
+    const int slot = s * SL_C + lane;
+    const int row = sl_row[slot], len = sl_len[slot];
+    const int k0 = row >= 0 ? Ap[row] : 0;
+    for (int k = 0; k < w; ++k) {
+        const bool have = k < len;
+        sl_col[off + (long)k * SL_C + lane] = have ? Aj[k0 + k] : 0;
+        sl_val[off + (long)k * SL_C + lane] = have ? Ax[k0 + k] : 0.0;
+    }
+}
+
+struct SellArgs {
+    const int *row;
+    const unsigned short *len;
+    const long *off;
+    const int *col;
+    const double *val;
+    int nslices;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(SL_WG) void sell_kernel(StreamArgs a, SellArgs S, int xcd_chunk)
+{
+    const int blk = remap((int)blockIdx.x, (int)gridDim.x, xcd_chunk);
+    const int s = blk * (SL_WG / SL_C) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (s >= S.nslices) return;
+    const long off = S.off[s];
+    const int w = (int)((S.off[s + 1] - off) >> 6);                 // uniform over the wave
+    const int slot = s * SL_C + lane;
+    const int row = S.row[slot];
+    const int len = S.len[slot];
+    const double gscale = a.gscale;
+    // the epilogue's streamed operands do not depend on the row sum: requested first
+    double ep_b = 0.0, ep_v2 = 0.0;
+    if (row >= 0) {
+        if (MODE == SM_RESIDUAL || MODE == SM_POLY_FIRST || MODE == SM_POLY_STEP || MODE == SM_POLY_LAST) ep_b = a.b[row];
+        if (MODE == SM_POLY_LAST) ep_v2 = a.v2[row];
+        if (MODE == SM_MATVEC_ACC) ep_v2 = a.out[row];
+    }
+    const int *cp = S.col + off + lane;
+    const double *vp = S.val + off + lane;
+    double acc = 0.0;
+    for (int k0 = 0; k0 < w; k0 += SL_PASS) {
+        int c[SL_PASS];
+        double v[SL_PASS], xv[SL_PASS];
+#pragma unroll
+        for (int u = 0; u < SL_PASS; ++u) {
+            c[u] = 0; v[u] = 0.0;
+            if (k0 + u < w) {                                       // uniform: the whole wave requests or skips
+                c[u] = __builtin_nontemporal_load(&cp[(long)(k0 + u) * SL_C]);
+                v[u] = __builtin_nontemporal_load(&vp[(long)(k0 + u) * SL_C]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < SL_PASS; ++u) xv[u] = (k0 + u < len) ? a.xg[c[u]] : 0.0;
+#pragma unroll
+        for (int u = 0; u < SL_PASS; ++u) {
+            const double pr = v[u] * (gscale * xv[u]);
+            const double nxt = acc + pr;
+            acc = (k0 + u < len) ? nxt : acc;
+        }
+    }
+    if (row < 0) return;
+    if (MODE == SM_MATVEC) {
+        __builtin_nontemporal_store(acc, &a.out[row]);
+    } else if (MODE == SM_MATVEC_ACC) {
+        __builtin_nontemporal_store(ep_v2 + acc, &a.out[row]);
+    } else if (MODE == SM_RESIDUAL) {
+        __builtin_nontemporal_store(ep_b - acc, &a.out[row]);
+    } else if (MODE == SM_POLY_FIRST) {
+        const double r = ep_b - acc;
+        a.out[row] = r;
+        a.out2[row] = a.c0 * r;
+    } else if (MODE == SM_POLY_STEP) {
+        const double cr = a.c0 * ep_b;
+        a.out[row] = cr + acc;
+    } else if (MODE == SM_POLY_LAST) {
+        const double cr = a.c0 * ep_b;
+        const double h = cr + acc;
+        __builtin_nontemporal_store(ep_v2 + h, &a.out[row]);
+    }
+}
+
+int g_sell = 1;
+
+}   // namespace
+
+bool sell_supports(StreamMode mode)
+{
+    return mode == SM_MATVEC || mode == SM_MATVEC_ACC || mode == SM_RESIDUAL || mode == SM_POLY_FIRST || mode == SM_POLY_STEP ||
+           mode == SM_POLY_LAST;
+}
+bool sell_enabled() { return g_sell != 0; }
+void set_sell_form(int on) { g_sell = on; bump_config_epoch(); }
+
+int launch_sell(StreamMode mode, const StreamArgs &a, const DevCsr &M, hipStream_t st)
+{
+    StreamArgs b = a;
+    if (b.gscale == 0.0) b.gscale = 1.0;
+    SellArgs S{M.sl_row, M.sl_len, M.sl_off, M.sl_col, M.sl_val, M.sl_nslices};
+    const int grid = (M.sl_nslices + SL_WG / SL_C - 1) / (SL_WG / SL_C);
+    const int chunk = grid >= 4096 ? 32 : 0;
+    switch (mode) {
+#define SELL_CASE(MODE) case MODE: hipLaunchKernelGGL((sell_kernel<MODE>), dim3(grid), dim3(SL_WG), 0, st, b, S, chunk); break
+    SELL_CASE(SM_MATVEC);
+    SELL_CASE(SM_MATVEC_ACC);
+    SELL_CASE(SM_RESIDUAL);
+    SELL_CASE(SM_POLY_FIRST);
+    SELL_CASE(SM_POLY_STEP);
+    SELL_CASE(SM_POLY_LAST);
+#undef SELL_CASE
+    default: set_error("launch_sell: mode not supported"); return -1;
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "sell launch", __FILE__, __LINE__);
+    return 0;
+}
+
+// Built from the CSR arrays in HBM.  Only where it pays (measured on the 500^3 hierarchy, tools/sell_ab.py and the
+// kernel trace): rows of 8 to 48 entries on average -- shorter rows stream as fast through the CSR kernel and the slot
+// bookkeeping would cost 6 bytes per row; longer rows (R_1: 150 entries, A_2: 67) need several dependent passes per
+// slice with few slices to overlap them and were 5-70 % slower -- at least 2^16 rows, no row longer than 2046
+// entries, and at most 15 % padding.
+int build_sell(DevCsr &M, long *acct)
+{
+    const char *env = std::getenv("AMG_SELL");
+    if (env && std::atoi(env) == 0) return 0;
+    const int n = M.nrows;
+    if (n < (1 << 16) || M.nnz < 8L * n || M.nnz > 48L * n || !M.Ap || !M.Aj || !M.Ax) return 0;
+    const int nwin = (n + SL_SIGMA - 1) / SL_SIGMA;
+    const int nslices = nwin * (SL_SIGMA / SL_C);
+    int *row = nullptr, *w_dev = nullptr;
+    unsigned short *len = nullptr;
+    // longest row must fit the 11 + 21-bit sort key and the 16-bit length
+    {
+        std::vector<int> hp((size_t)n + 1);
+        AMG_HIP(hipMemcpy(hp.data(), M.Ap, sizeof(int) * ((size_t)n + 1), hipMemcpyDeviceToHost));
+        int longest = 0;
+        for (int i = 0; i < n; ++i) longest = std::max(longest, hp[(size_t)i + 1] - hp[(size_t)i]);
+        if (longest > 2046) return 0;
+    }
+    AMG_HIP(hipMalloc((void **)&row, sizeof(int) * (size_t)nslices * SL_C));
+    AMG_HIP(hipMalloc((void **)&len, sizeof(unsigned short) * (size_t)nslices * SL_C));
+    AMG_HIP(hipMalloc((void **)&w_dev, sizeof(int) * (size_t)nslices));
+    hipLaunchKernelGGL(sell_sort_kernel, dim3(nwin), dim3(1024), 0, nullptr, n, M.Ap, row, len, w_dev);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "sell sort launch", __FILE__, __LINE__);
+    std::vector<int> hw((size_t)nslices);
+    AMG_HIP(hipMemcpy(hw.data(), w_dev, sizeof(int) * (size_t)nslices, hipMemcpyDeviceToHost));
+    hipFree(w_dev);
+    std::vector<long> off((size_t)nslices + 1);
+    off[0] = 0;
+    for (int s = 0; s < nslices; ++s) off[(size_t)s + 1] = off[(size_t)s] + (long)hw[(size_t)s] * SL_C;
+    const long entries = off[(size_t)nslices];
+    if ((double)entries > 1.15 * (double)M.nnz) { hipFree(row); hipFree(len); return 0; }
+    long *off_dev = nullptr;
+    int *col = nullptr;
+    double *val = nullptr;
+    AMG_HIP(hipMalloc((void **)&off_dev, sizeof(long) * ((size_t)nslices + 1)));
+    AMG_HIP(hipMalloc((void **)&col, sizeof(int) * (size_t)std::max(entries, 1L)));
+    AMG_HIP(hipMalloc((void **)&val, sizeof(double) * (size_t)std::max(entries, 1L)));
+    AMG_HIP(hipMemcpy(off_dev, off.data(), sizeof(long) * ((size_t)nslices + 1), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(sell_fill_kernel, dim3((nslices + SL_WG / SL_C - 1) / (SL_WG / SL_C)), dim3(SL_WG), 0, nullptr, nslices, M.Ap, M.Aj, M.Ax,
+                       row, len, off_dev, col, val);
+    e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "sell fill launch", __FILE__, __LINE__);
+    AMG_HIP(hipDeviceSynchronize());
+    M.sl_row = row; M.sl_len = len; M.sl_off = off_dev; M.sl_col = col; M.sl_val = val;
+    M.sl_nslices = nslices; M.sl_entries = entries;
+    if (acct) *acct += (long)(sizeof(int) * (size_t)nslices * SL_C + sizeof(unsigned short) * (size_t)nslices * SL_C +
+                              sizeof(long) * ((size_t)nslices + 1) + 12L * entries);
+    return 0;
+}
+
+}   // namespace amg

@@ -1419,3 +1419,56 @@ def test_stencil_two_rows_per_lane_same_bits():
             assert np.array_equal(out[0][1], out[2][1])
     finally:
         L.amg_set_stencil_pairs(1)
+
+
+@pytest.mark.gpu
+def test_sliced_form_same_bits_as_csr():
+    """operators without grid structure are applied from the sliced form (SELL-64-sigma: rows sorted by length in
+    windows, one lane per row): random rows of 0..70 entries (empty rows, a few long ones), a row count that is not a
+    multiple of the window, rectangular; y = A x, and whole Chebyshev / Jacobi hierarchies whose A_1, R, P take the
+    form -- same bits as the CSR kernel and as scipy's csr_matvec"""
+    from pyamg_amd import _lib
+    from pyamg_amd.util import _DeviceOperator
+    from pyamg_amd.aggregation import poisson as native, smoothed_aggregation_solver
+    L = _lib.lib()
+    rng = np.random.RandomState(17)
+    try:
+        for (n, m) in ((70001, 70001), (66000, 90000)):
+            lens = rng.randint(0, 40, size=n)
+            lens[rng.randint(0, n, size=5)] = rng.randint(100, 300, size=5)
+            lens[:10] = 0
+            rows = np.repeat(np.arange(n), lens); cols = rng.randint(0, m, size=rows.size)
+            A = sps.csr_matrix((rng.randn(rows.size), (rows, cols)), shape=(n, m)); A.sum_duplicates()
+            x = rng.randn(m)
+            op = _DeviceOperator(A) if n == m else None
+            if op is None:
+                continue
+            try:
+                _lib.check(L.amg_hier_finalize(op.h))
+                out = {}
+                for on in (1, 0):
+                    L.amg_set_sell_form(on)
+                    assert L.amg_hier_operator_form(op.h, 0) == (3 if on else 0)
+                    y = np.zeros(n)
+                    _lib.check(L.amg_hier_matvec(op.h, 0, 0, _lib.dp(x), _lib.dp(y)))
+                    out[on] = y
+                assert np.array_equal(out[0], out[1])
+                assert np.array_equal(out[1], A @ x)
+            finally:
+                op.close()
+        for sm in (("chebyshev", {"degree": 3}), ("jacobi", {"omega": 4.0 / 3.0})):
+            np.random.seed(2)
+            ml = smoothed_aggregation_solver(native((96, 90, 84)), presmoother=sm, postsmoother=sm)     # A_1: ~90 k rows
+            b = np.random.rand(ml.levels[0].A.shape[0])
+            out = {}
+            for on in (1, 0):
+                L.amg_set_sell_form(on)
+                ml._invalidate_device()
+                res = []
+                x = ml.solve(b, tol=1e-30, maxiter=5, residuals=res)
+                if on:
+                    assert L.amg_hier_operator_form(ml.device_hierarchy().h, 1) == 3
+                out[on] = (x, np.array(res))
+            assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    finally:
+        L.amg_set_sell_form(1)
