@@ -196,8 +196,8 @@ int launch_sell(StreamMode mode, const StreamArgs &a, const DevCsr &M, hipStream
 }
 
 // Built from the CSR arrays in HBM.  Only where it pays (measured on the 500^3 hierarchy, tools/sell_ab.py and the
-// kernel trace): rows of 8 to 48 entries on average -- shorter rows stream as fast through the CSR kernel and the slot
-// bookkeeping would cost 6 bytes per row; longer rows (R_1: 150 entries, A_2: 67) need several dependent passes per
+// kernel trace): rows of 8 to 48 entries on average -- short rows (P_0: 3.4 entries) were 2x SLOWER here (a wave's 64 rows
+// carry too few entries for its scattered row bookkeeping and result accesses) and stream well through the CSR kernel; longer rows (R_1: 150 entries, A_2: 67) need several dependent passes per
 // slice with few slices to overlap them and were 5-70 % slower -- at least 2^16 rows, no row longer than 2046
 // entries, and at most 15 % padding.
 int build_sell(DevCsr &M, long *acct)
