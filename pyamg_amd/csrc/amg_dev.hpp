@@ -99,6 +99,16 @@ struct DevBsr {   // block rows, for the block / point-BSR relaxation kernels
     int *Ap = nullptr;
     int *Aj = nullptr;
     double *Ax = nullptr;
+    // Sliced form of the block operator (sell.hip build_bsell; bs = 2, 3): block rows sorted by block count inside
+    // windows, slices of 64 / bs block rows, one lane per SCALAR row; block k of the slice's rows side by side
+    // (columns [k][block row], values [k][c][lane]).  Whole passes (operator applications, block Jacobi sweeps) run
+    // from it without row pointer, LDS or barrier; same summation order, same bits as bsr_stream_kernel.
+    int *bsl_brow = nullptr;           // [nslices * (64 / bs)] block row of the slot (-1: padding)
+    unsigned short *bsl_len = nullptr; // blocks of that block row
+    long *bsl_off = nullptr;           // [nslices + 1] first block SLOT COLUMN of the slice: slice s holds (off[s+1]-off[s]) blocks per row
+    int *bsl_col = nullptr;            // [off[nslices] * (64 / bs)]
+    double *bsl_val = nullptr;         // [off[nslices] * bs * (64 / bs) * bs]
+    int bsl_nslices = 0;
 };
 
 // ---------------------------------------------------------------- stream kernel
@@ -250,5 +260,11 @@ bool bsr_spmv_supports(StreamMode mode);
 bool bsr_spmv_enabled(int bs);
 void set_bsr_spmv(int on);
 int launch_bsr_stream(BlockMode m, const BsrStreamArgs &a, long nblocks_hint, hipStream_t st);
+// the sliced block form (DevBsr::bsl_*): whole passes in BM_SPMV (epilogues MATVEC, MATVEC_ACC, RESIDUAL, POLY_STEP,
+// POLY_LAST) and BM_BLOCK_JACOBI
+int build_bsell(DevBsr &M, long *acct);
+void free_bsell(DevBsr &M);
+bool bsell_applies(const DevBsr &M, BlockMode m, const BsrStreamArgs &a);
+int launch_bsell(const DevBsr &M, BlockMode m, const BsrStreamArgs &a, hipStream_t st);
 
 }  // namespace amg

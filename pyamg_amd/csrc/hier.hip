@@ -68,6 +68,7 @@ void free_csr(DevCsr &M)
 }
 static void free_bsr(DevBsr &M)
 {
+    free_bsell(M);
     if (M.Ap) hipFree(M.Ap);
     if (M.Aj) hipFree(M.Aj);
     if (M.Ax) hipFree(M.Ax);
@@ -666,7 +667,9 @@ int apply_operator(const DevCsr &M, StreamMode mode, const StreamArgs &a, hipStr
             set_error("this operator is stored by blocks only: the requested application needs its scalar expansion");
             return AMG_ENOTIMPL;
         }
-        return launch_bsr_stream(BM_SPMV, block_spmv_args(*M.blk, mode, a), M.blk->nblocks, st);
+        const BsrStreamArgs q = block_spmv_args(*M.blk, mode, a);
+        if (bsell_applies(*M.blk, BM_SPMV, q)) return launch_bsell(*M.blk, BM_SPMV, q, st);
+        return launch_bsr_stream(BM_SPMV, q, M.blk->nblocks, st);
     }
     if (M.st_vals && stencil_enabled() && pattern_supports(mode)) return launch_stencil(mode, a, M, st);
     if (M.pat && pattern_supports(mode)) return launch_pattern(mode, a, M, st);
@@ -779,6 +782,7 @@ static int bsr_stream_all(const DevBsr &Ab, BlockMode mode, const double *Dinv, 
     a.Ap = Ab.Ap; a.Aj = Ab.Aj; a.Ax = Ab.Ax; a.bs = Ab.bs;
     a.brow_lo = 0; a.brow_hi = Ab.nbrows;
     a.xin = xin; a.xout = xout; a.b = b; a.Dinv = Dinv; a.omega = omega;
+    if (bsell_applies(Ab, mode, a)) return launch_bsell(Ab, mode, a, st);
     return launch_bsr_stream(mode, a, Ab.nblocks, st);
 }
 
@@ -1447,6 +1451,7 @@ int amg_hier_set_matrix(amg_hier *h, int lvl, int which, int fmt, int nrows, int
         free_bsr(L.Ab);
         if (fmt == AMG_FMT_BSR && R == C && R > 1) {
             CHK(upload_bsr(L.Ab, nrows / R, R, Ap, Aj, Ax, &h->dev_bytes));
+            if (!h->comm) CHK(build_bsell(L.Ab, &h->dev_bytes));        // whole passes run from the sliced block form (sell.hip)
             L.A.blk = &L.Ab;           // applications of A stream the blocks (levels live in a vector sized once)
         }
     } else if (which == AMG_MAT_P) {

@@ -251,4 +251,255 @@ int build_sell(DevCsr &M, long *acct)
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same for block operators (BASELINE configuration C5: BSR 3x3): DevBsr::bsl_*.  Block rows are sorted by block
+// count inside windows of 32 slices, a slice holds NBR = 64 / bs block rows, a lane one SCALAR row (lane = block row
+// in slice * bs + r).  Block k of the slice: its NBR block columns side by side, then its values as bs planes
+// [c][lane] -- a lane's loads are coalesced with its neighbours', the three lanes of a block row read the same column
+// and the same operands.  Arithmetic and order are bsr_stream_kernel's: BM_SPMV one running sum per scalar row across
+// blocks and columns (scipy bsr_matvec); block Jacobi v = sum_c a[r][c] x[c] from 0 per block, rsum += v block by
+// block, diagonal block skipped, then Dinv * (b - rsum) and the weighted update (relaxation.h:686-720).
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int BSL_WIN = 32;          // slices per sorting window
+constexpr int BSL_PASS = 8;          // blocks of a row requested at once
+
+template <int NBR>
+__global__ __launch_bounds__(1024) void bsell_sort_kernel(int nb, const int *Ap, int *brow, unsigned short *blen, int *slice_w)
+{
+    constexpr int WIN = BSL_WIN * NBR;            // block rows per window (<= 1024)
+    __shared__ unsigned key[1024];
+    const int w0 = blockIdx.x * WIN;
+    const int q = threadIdx.x;
+    {
+        const int i = w0 + q;
+        const bool real = q < WIN && i < nb;
+        const unsigned len = real ? (unsigned)(Ap[i + 1] - Ap[i]) : 0u;
+        key[q] = real ? (((len + 1u) << 10) | (unsigned)(1023 - q)) : 0u;
+    }
+    __syncthreads();
+    for (int k = 2; k <= 1024; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const int p = q ^ j;
+            if (p > q) {
+                const unsigned a = key[q], b = key[p];
+                const bool desc = (q & k) == 0;
+                if (desc ? (a < b) : (a > b)) { key[q] = b; key[p] = a; }
+            }
+            __syncthreads();
+        }
+    if (q < WIN) {
+        const unsigned kq = key[q];
+        const bool is_row = kq != 0u;
+        const int pos = 1023 - (int)(kq & 1023u);
+        const int len = is_row ? (int)(kq >> 10) - 1 : 0;
+        const int slot = blockIdx.x * WIN + q;
+        brow[slot] = is_row ? w0 + pos : -1;
+        blen[slot] = (unsigned short)len;
+        if (q % NBR == 0) slice_w[slot / NBR] = len;
+    }
+}
+
+template <int BS>
+__global__ __launch_bounds__(256) void bsell_fill_kernel(int nslices, const int *Ap, const int *Aj, const double *Ax, const int *brow,
+                                                         const unsigned short *blen, const long *off, int *col, double *val)
+{
+    constexpr int NBR = 64 / BS, LW = NBR * BS;
+    const int s = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (s >= nslices || lane >= LW) return;
+    const long o = off[s];
+    const int w = (int)(off[s + 1] - o);
+    const int br = lane / BS, r = lane - br * BS;
+    const int row = brow[s * NBR + br], len = blen[s * NBR + br];
+    const long k0 = row >= 0 ? Ap[row] : 0;
+    for (int k = 0; k < w; ++k) {
+        const bool have = k < len;
+        if (r == 0) col[(o + k) * NBR + br] = have ? Aj[k0 + k] : 0;
+        for (int c = 0; c < BS; ++c)
+            val[((o + k) * BS + c) * LW + lane] = have ? Ax[(k0 + k) * (BS * BS) + r * BS + c] : 0.0;
+    }
+}
+
+struct BsellArgs {
+    const int *brow; const unsigned short *blen; const long *off; const int *col; const double *val; int nslices;
+};
+
+template <int BMODE, int BS>
+__global__ __launch_bounds__(256) void bsell_kernel(BsrStreamArgs a, BsellArgs S, int xcd_chunk)
+{
+    constexpr int NBR = 64 / BS, LW = NBR * BS, B2 = BS * BS;
+    const int blk = remap((int)blockIdx.x, (int)gridDim.x, xcd_chunk);
+    const int s = blk * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (s >= S.nslices) return;
+    const long o = S.off[s];
+    const int w = (int)(S.off[s + 1] - o);                          // uniform over the wave
+    const bool lane_ok = lane < LW;
+    const int br = lane_ok ? lane / BS : 0, r = lane_ok ? lane - br * BS : 0;
+    const int brow = lane_ok ? S.brow[s * NBR + br] : -1;
+    const int len = lane_ok ? (int)S.blen[s * NBR + br] : 0;
+    const bool active = brow >= 0;
+    const long ib = (long)brow * BS;
+    const double gscale = (a.gscale == 0.0) ? 1.0 : a.gscale;
+    double ep_b = 0.0, ep_v2 = 0.0, ep_x = 0.0;
+    if (active) {
+        if (BMODE == BM_BLOCK_JACOBI) { ep_b = a.b[ib + r]; ep_x = a.xin[ib + r]; }
+        else {
+            if (a.smode == SM_RESIDUAL || a.smode == SM_POLY_STEP || a.smode == SM_POLY_LAST) ep_b = a.b[ib + r];
+            if (a.smode == SM_POLY_LAST) ep_v2 = a.v2[ib + r];
+            if (a.smode == SM_MATVEC_ACC) ep_v2 = a.xout[ib + r];
+        }
+    }
+    const int *cp = S.col + o * NBR + br;
+    const double *vp = S.val + o * BS * LW + lane;
+    double rsum = 0.0;
+    for (int k0 = 0; k0 < w; k0 += BSL_PASS) {
+        int bc[BSL_PASS];
+        double v[BSL_PASS][BS], xv[BSL_PASS][BS];
+#pragma unroll
+        for (int u = 0; u < BSL_PASS; ++u) {
+            bc[u] = 0;
+#pragma unroll
+            for (int c = 0; c < BS; ++c) v[u][c] = 0.0;
+            if (k0 + u < w && lane_ok) {                            // (k0 + u < w is uniform)
+                bc[u] = cp[(long)(k0 + u) * NBR];
+#pragma unroll
+                for (int c = 0; c < BS; ++c) v[u][c] = __builtin_nontemporal_load(&vp[((long)(k0 + u) * BS + c) * LW]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < BSL_PASS; ++u)
+#pragma unroll
+            for (int c = 0; c < BS; ++c) xv[u][c] = (k0 + u < len) ? a.xin[(long)bc[u] * BS + c] : 0.0;
+#pragma unroll
+        for (int u = 0; u < BSL_PASS; ++u) {
+            const bool take = k0 + u < len;
+            if (BMODE == BM_SPMV) {
+#pragma unroll
+                for (int c = 0; c < BS; ++c) { const double nxt = rsum + v[u][c] * (gscale * xv[u][c]); rsum = take ? nxt : rsum; }
+            } else {
+                double vb = 0.0;
+#pragma unroll
+                for (int c = 0; c < BS; ++c) vb = vb + v[u][c] * xv[u][c];
+                const double nxt = rsum + vb;
+                rsum = (take && bc[u] != brow) ? nxt : rsum;        // the diagonal block is not part of the sum
+            }
+        }
+    }
+    if (BMODE == BM_SPMV) {
+        if (!active) return;
+        const long i = ib + r;
+        if (a.smode == SM_MATVEC) a.xout[i] = rsum;
+        else if (a.smode == SM_MATVEC_ACC) a.xout[i] = ep_v2 + rsum;
+        else if (a.smode == SM_RESIDUAL) a.xout[i] = ep_b - rsum;
+        else if (a.smode == SM_POLY_STEP) { const double cr = a.c0 * ep_b; a.xout[i] = cr + rsum; }
+        else if (a.smode == SM_POLY_LAST) { const double cr = a.c0 * ep_b; const double h = cr + rsum; a.xout[i] = ep_v2 + h; }
+        return;
+    }
+    // block Jacobi: x_i = (1 - omega) temp_i + omega * Dinv_i (b_i - rsum); the lanes of a block row exchange their t
+    const double t = ep_b - rsum;
+    double vD = 0.0;
+#pragma unroll
+    for (int c = 0; c < BS; ++c) {
+        const double tc = __shfl(t, br * BS + c, 64);
+        const double d = active ? a.Dinv[(long)brow * B2 + r * BS + c] : 0.0;
+        vD = vD + d * tc;
+    }
+    if (active) {
+        const double t1 = (1.0 - a.omega) * ep_x;
+        const double t2 = a.omega * vD;
+        a.xout[ib + r] = t1 + t2;
+    }
+}
+
+template <int BS>
+int build_bsell_bs(DevBsr &M, long *acct)
+{
+    constexpr int NBR = 64 / BS, WIN = BSL_WIN * NBR;
+    const int nb = M.nbrows;
+    const int nwin = (nb + WIN - 1) / WIN;
+    const int nslices = nwin * BSL_WIN;
+    {
+        std::vector<int> hp((size_t)nb + 1);
+        AMG_HIP(hipMemcpy(hp.data(), M.Ap, sizeof(int) * ((size_t)nb + 1), hipMemcpyDeviceToHost));
+        int longest = 0;
+        for (int i = 0; i < nb; ++i) longest = std::max(longest, hp[(size_t)i + 1] - hp[(size_t)i]);
+        if (longest > 60000) return 0;
+    }
+    int *brow = nullptr, *w_dev = nullptr;
+    unsigned short *blen = nullptr;
+    AMG_HIP(hipMalloc((void **)&brow, sizeof(int) * (size_t)nslices * NBR));
+    AMG_HIP(hipMalloc((void **)&blen, sizeof(unsigned short) * (size_t)nslices * NBR));
+    AMG_HIP(hipMalloc((void **)&w_dev, sizeof(int) * (size_t)nslices));
+    hipLaunchKernelGGL((bsell_sort_kernel<NBR>), dim3(nwin), dim3(1024), 0, nullptr, nb, M.Ap, brow, blen, w_dev);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "bsell sort launch", __FILE__, __LINE__);
+    std::vector<int> hw((size_t)nslices);
+    AMG_HIP(hipMemcpy(hw.data(), w_dev, sizeof(int) * (size_t)nslices, hipMemcpyDeviceToHost));
+    hipFree(w_dev);
+    std::vector<long> off((size_t)nslices + 1);
+    off[0] = 0;
+    for (int s = 0; s < nslices; ++s) off[(size_t)s + 1] = off[(size_t)s] + hw[(size_t)s];
+    const long cols = off[(size_t)nslices];                          // block slot columns
+    if ((double)cols * NBR > 1.15 * (double)M.nblocks) { hipFree(brow); hipFree(blen); return 0; }
+    long *off_dev = nullptr; int *col = nullptr; double *val = nullptr;
+    AMG_HIP(hipMalloc((void **)&off_dev, sizeof(long) * ((size_t)nslices + 1)));
+    AMG_HIP(hipMalloc((void **)&col, sizeof(int) * (size_t)std::max(cols * NBR, 1L)));
+    AMG_HIP(hipMalloc((void **)&val, sizeof(double) * (size_t)std::max(cols * BS * NBR * BS, 1L)));
+    AMG_HIP(hipMemcpy(off_dev, off.data(), sizeof(long) * ((size_t)nslices + 1), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL((bsell_fill_kernel<BS>), dim3((nslices + 3) / 4), dim3(256), 0, nullptr, nslices, M.Ap, M.Aj, M.Ax, brow, blen, off_dev, col, val);
+    e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "bsell fill launch", __FILE__, __LINE__);
+    AMG_HIP(hipDeviceSynchronize());
+    M.bsl_brow = brow; M.bsl_len = blen; M.bsl_off = off_dev; M.bsl_col = col; M.bsl_val = val; M.bsl_nslices = nslices;
+    if (acct) *acct += (long)(6L * nslices * NBR + 8L * (nslices + 1) + 4L * cols * NBR + 8L * cols * BS * NBR * BS);
+    return 0;
+}
+
+}   // namespace
+
+void free_bsell(DevBsr &M)
+{
+    if (M.bsl_brow) hipFree(M.bsl_brow);
+    if (M.bsl_len) hipFree(M.bsl_len);
+    if (M.bsl_off) hipFree(M.bsl_off);
+    if (M.bsl_col) hipFree(M.bsl_col);
+    if (M.bsl_val) hipFree(M.bsl_val);
+    M.bsl_brow = nullptr; M.bsl_len = nullptr; M.bsl_off = nullptr; M.bsl_col = nullptr; M.bsl_val = nullptr; M.bsl_nslices = 0;
+}
+
+// from the BSR arrays in HBM; blocks of 2x2 and 3x3, at least 2^15 block rows of 4 to 48 blocks on average
+int build_bsell(DevBsr &M, long *acct)
+{
+    const char *env = std::getenv("AMG_SELL");
+    if (env && std::atoi(env) == 0) return 0;
+    if (M.nbrows < (1 << 15) || M.nblocks < 4L * M.nbrows || M.nblocks > 48L * M.nbrows || !M.Ap) return 0;
+    if (M.bs == 3) return build_bsell_bs<3>(M, acct);
+    if (M.bs == 2) return build_bsell_bs<2>(M, acct);
+    return 0;
+}
+
+bool bsell_applies(const DevBsr &M, BlockMode m, const BsrStreamArgs &a)
+{
+    if (!M.bsl_val || !g_sell || a.rowmap || a.brow_lo != 0 || a.brow_hi != M.nbrows || a.Aj != M.Aj) return false;
+    if (m == BM_BLOCK_JACOBI) return true;
+    if (m != BM_SPMV) return false;
+    return a.smode == SM_MATVEC || a.smode == SM_MATVEC_ACC || a.smode == SM_RESIDUAL || a.smode == SM_POLY_STEP || a.smode == SM_POLY_LAST;
+}
+
+int launch_bsell(const DevBsr &M, BlockMode m, const BsrStreamArgs &a, hipStream_t st)
+{
+    BsellArgs S{M.bsl_brow, M.bsl_len, M.bsl_off, M.bsl_col, M.bsl_val, M.bsl_nslices};
+    const int grid = (M.bsl_nslices + 3) / 4;
+    const int chunk = grid >= 4096 ? 32 : 0;
+    if (M.bs == 3 && m == BM_SPMV) hipLaunchKernelGGL((bsell_kernel<BM_SPMV, 3>), dim3(grid), dim3(256), 0, st, a, S, chunk);
+    else if (M.bs == 3) hipLaunchKernelGGL((bsell_kernel<BM_BLOCK_JACOBI, 3>), dim3(grid), dim3(256), 0, st, a, S, chunk);
+    else if (M.bs == 2 && m == BM_SPMV) hipLaunchKernelGGL((bsell_kernel<BM_SPMV, 2>), dim3(grid), dim3(256), 0, st, a, S, chunk);
+    else if (M.bs == 2) hipLaunchKernelGGL((bsell_kernel<BM_BLOCK_JACOBI, 2>), dim3(grid), dim3(256), 0, st, a, S, chunk);
+    else { set_error("launch_bsell: block size not supported"); return -1; }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "bsell launch", __FILE__, __LINE__);
+    return 0;
+}
+
 }   // namespace amg

@@ -1472,3 +1472,36 @@ def test_sliced_form_same_bits_as_csr():
             assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
     finally:
         L.amg_set_sell_form(1)
+
+
+@pytest.mark.gpu
+def test_sliced_block_form_same_bits_as_block_stream():
+    """BSR(3,3) and BSR(2,2) level operators of 2^15 and more block rows run their whole passes -- r = b - A x from the
+    blocks, block Jacobi sweeps -- from the sliced block form (one lane per scalar row): same iterates and residual
+    histories as bsr_stream_kernel, bit for bit, on the C5-shaped tet-mesh operator (irregular block rows) and a 2x2
+    elasticity-like operator"""
+    from pyamg_amd import _lib
+    from pyamg_amd.aggregation import poisson as native, smoothed_aggregation_solver
+    from pyamg_amd.gallery import tet_diffusion
+    L = _lib.lib()
+    rng = np.random.RandomState(4)
+    A3 = tet_diffusion(51, blocksize=3)                                   # 44 217 block rows
+    M2 = np.array([[2.0, -0.5], [-0.5, 1.5]])
+    A2 = sps.kron(native((36, 35, 33)), M2).tobsr((2, 2)); A2.sort_indices()        # 41 580 block rows
+    try:
+        for A, bs in ((A3, 3), (A2, 2)):
+            sm = ("block_jacobi", {"omega": 0.6, "blocksize": bs})
+            np.random.seed(3)
+            ml = smoothed_aggregation_solver(A, presmoother=sm, postsmoother=sm, max_levels=3)
+            b = rng.rand(A.shape[0])
+            out = {}
+            for on in (1, 0):
+                L.amg_set_sell_form(on)
+                ml._invalidate_device()
+                res = []
+                x = ml.solve(b, tol=1e-30, maxiter=4, residuals=res)
+                out[on] = (x, np.array(res))
+            assert np.array_equal(out[0][0], out[1][0]), bs
+            assert np.array_equal(out[0][1], out[1][1]), bs
+    finally:
+        L.amg_set_sell_form(1)
