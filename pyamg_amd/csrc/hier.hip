@@ -4,6 +4,7 @@
 // one HIP stream; one 8-byte copy per iteration brings the residual norm back
 // when a tolerance has to be checked.
 #include <array>
+#include <thread>
 #include "hier.hpp"
 
 #include <algorithm>
@@ -253,35 +254,93 @@ int try_patterns(DevCsr &M, const int *Ap, const int *Aj, long *acct)
     if (n > M.ncols || n < 1024) return 0;      // square, or a rank-local [owned | halo] operator
     std::vector<int> pat((size_t)n), dptr(1, 0), doff;
     std::vector<long> pcount;
-    // open-addressing table: hash of the offset tuple -> pattern id
-    const int TBL = 1024;
-    std::vector<int> tbl((size_t)TBL, -1);
-    std::vector<uint64_t> thash((size_t)TBL, 0);
-    for (int i = 0; i < n; ++i) {
-        const int s = Ap[i], e = Ap[i + 1], len = e - s;
-        uint64_t hsh = 1469598103934665603ULL ^ (uint64_t)len;
-        for (int k = s; k < e; ++k) { hsh ^= (uint64_t)(uint32_t)(Aj[k] - i); hsh *= 1099511628211ULL; }
-        int slot = (int)(hsh & (TBL - 1)), id = -1;
-        for (int probe = 0; probe < TBL; ++probe, slot = (slot + 1) & (TBL - 1)) {
-            if (tbl[slot] < 0) break;
-            if (thash[slot] != hsh) continue;
-            const int c = tbl[slot];
-            if (dptr[c + 1] - dptr[c] != len) continue;
-            bool same = true;
-            for (int q = 0; q < len && same; ++q) same = (doff[dptr[c] + q] == Aj[s + q] - i);
-            if (same) { id = c; break; }
+    // Row ranges are analysed by host threads, each with a dictionary of its own (open-addressing table: hash of the
+    // offset tuple -> local pattern id, in order of first occurrence); the dictionaries are then merged in range order,
+    // which gives the ids the one-thread loop would give, and the rows' ids are renumbered in parallel.
+    struct Local {
+        std::vector<int> dptr{0}, doff;
+        std::vector<long> count;
+        bool overflow = false;
+    };
+    int nthreads = (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (n < (1 << 20)) nthreads = 1;
+    std::vector<Local> loc((size_t)nthreads);
+    auto analyse = [&](int t) {
+        Local &Lc = loc[(size_t)t];
+        const int lo = (int)((long)n * t / nthreads), hi = (int)((long)n * (t + 1) / nthreads);
+        const int TBL = 1024;
+        std::vector<int> tbl((size_t)TBL, -1);
+        std::vector<uint64_t> thash((size_t)TBL, 0);
+        for (int i = lo; i < hi; ++i) {
+            const int s = Ap[i], e = Ap[i + 1], len = e - s;
+            uint64_t hsh = 1469598103934665603ULL ^ (uint64_t)len;
+            for (int k = s; k < e; ++k) { hsh ^= (uint64_t)(uint32_t)(Aj[k] - i); hsh *= 1099511628211ULL; }
+            int slot = (int)(hsh & (TBL - 1)), id = -1;
+            for (int probe = 0; probe < TBL; ++probe, slot = (slot + 1) & (TBL - 1)) {
+                if (tbl[slot] < 0) break;
+                if (thash[slot] != hsh) continue;
+                const int c = tbl[slot];
+                if (Lc.dptr[c + 1] - Lc.dptr[c] != len) continue;
+                bool same = true;
+                for (int q = 0; q < len && same; ++q) same = (Lc.doff[Lc.dptr[c] + q] == Aj[s + q] - i);
+                if (same) { id = c; break; }
+            }
+            if (id < 0) {
+                id = (int)Lc.dptr.size() - 1;
+                if (id >= PAT_MAX || (int)Lc.doff.size() + len > PAT_DICT_MAX) { Lc.overflow = true; return; }   // not a stencil operator
+                for (int k = s; k < e; ++k) Lc.doff.push_back(Aj[k] - i);
+                Lc.dptr.push_back((int)Lc.doff.size());
+                tbl[slot] = id;
+                thash[slot] = hsh;
+                Lc.count.push_back(0);
+            }
+            pat[i] = id;
+            ++Lc.count[(size_t)id];
         }
-        if (id < 0) {
-            id = (int)dptr.size() - 1;
-            if (id >= PAT_MAX || (int)doff.size() + len > PAT_DICT_MAX) return 0;   // not a stencil operator
-            for (int k = s; k < e; ++k) doff.push_back(Aj[k] - i);
-            dptr.push_back((int)doff.size());
-            tbl[slot] = id;
-            thash[slot] = hsh;
-            pcount.push_back(0);
+    };
+    {
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nthreads; ++t) pool.emplace_back(analyse, t);
+        analyse(0);
+        for (auto &th : pool) th.join();
+    }
+    for (const Local &Lc : loc) if (Lc.overflow) return 0;
+    // merge in range order
+    std::vector<std::vector<int>> remap((size_t)nthreads);
+    for (int t = 0; t < nthreads; ++t) {
+        const Local &Lc = loc[(size_t)t];
+        const int np = (int)Lc.dptr.size() - 1;
+        remap[(size_t)t].resize((size_t)np);
+        for (int c = 0; c < np; ++c) {
+            const int len = Lc.dptr[c + 1] - Lc.dptr[c];
+            int id = -1;
+            for (int g = 0; g + 1 < (int)dptr.size() && id < 0; ++g) {
+                if (dptr[g + 1] - dptr[g] != len) continue;
+                bool same = true;
+                for (int q = 0; q < len && same; ++q) same = (doff[dptr[g] + q] == Lc.doff[Lc.dptr[c] + q]);
+                if (same) id = g;
+            }
+            if (id < 0) {
+                id = (int)dptr.size() - 1;
+                if (id >= PAT_MAX || (int)doff.size() + len > PAT_DICT_MAX) return 0;
+                for (int q = 0; q < len; ++q) doff.push_back(Lc.doff[Lc.dptr[c] + q]);
+                dptr.push_back((int)doff.size());
+                pcount.push_back(0);
+            }
+            remap[(size_t)t][(size_t)c] = id;
+            pcount[(size_t)id] += Lc.count[(size_t)c];
         }
-        pat[i] = id;
-        ++pcount[id];
+    }
+    if (nthreads > 1) {
+        auto renumber = [&](int t) {
+            const int lo = (int)((long)n * t / nthreads), hi = (int)((long)n * (t + 1) / nthreads);
+            const std::vector<int> &rm = remap[(size_t)t];
+            for (int i = lo; i < hi; ++i) pat[i] = rm[(size_t)pat[i]];
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nthreads; ++t) pool.emplace_back(renumber, t);
+        renumber(0);
+        for (auto &th : pool) th.join();
     }
     M.npat = (int)dptr.size() - 1;
     M.ndict = (int)doff.size();

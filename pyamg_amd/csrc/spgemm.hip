@@ -153,32 +153,37 @@ __global__ __launch_bounds__(256) void spgemm_rows_kernel(int n_work, const int 
 // `overflow`: the caller retries with the whole wave per row, then with the one-thread-per-row kernel (tables in HBM),
 // then hands the product back to its host path.
 constexpr int WCAP = 4096;                 // table entries per wave (64 KB of LDS, two waves per compute unit)
-template <bool FILL, int G>
+// HBM = true (G = 64 only): the table of the wave's row lives in HBM instead (gcap entries per workgroup, keys preset
+// to -1 by the host) -- rows of tens of thousands of products on small coarse levels, where a few hundred waves with
+// 2 MB tables each are plenty.
+template <bool FILL, int G, bool HBM>
 __global__ __launch_bounds__(64) void spgemm_group_kernel(int n_row, const long *Ap, const int *Aj, const double *Ax,
                                                          const long *Bp, const int *Bj, const double *Bx, int *count,
-                                                         const long *Cp, int *Cj, double *Cx, int *overflow)
+                                                         const long *Cp, int *Cj, double *Cx, int *overflow,
+                                                         int *gkey, double *gsum, int *gord, int gcap)
 {
+    static_assert(!HBM || G == 64, "tables in HBM: one row per wave");
     constexpr int NG = 64 / G;             // rows per wave
-    constexpr int CAP = WCAP / NG;         // table entries per row
     constexpr int LB = 64;                 // left-hand entries staged per batch and row
-    __shared__ int key_s[WCAP];
-    __shared__ double sum_s[WCAP];
-    __shared__ int ord_s[WCAP];
+    __shared__ int key_s[HBM ? 1 : WCAP];
+    __shared__ double sum_s[HBM ? 1 : WCAP];
+    __shared__ int ord_s[HBM ? 1 : WCAP];
     __shared__ double stv_s[NG * LB];
     __shared__ long stb_s[NG * LB];
     __shared__ int stl_s[NG * LB];
     const int lane = threadIdx.x;
     const int g = lane / G, gl = lane % G;                          // group (row slot) and lane within the group
-    int *key = key_s + g * CAP;
-    double *sum = sum_s + g * CAP;
-    int *ord = ord_s + g * CAP;
+    const int CAP = HBM ? gcap : WCAP / NG;                         // table entries per row
+    int *key = HBM ? gkey + (long)blockIdx.x * gcap : key_s + g * CAP;
+    double *sum = HBM ? gsum + (long)blockIdx.x * gcap : sum_s + g * CAP;
+    int *ord = HBM ? gord + (long)blockIdx.x * gcap : ord_s + g * CAP;
     double *st_v = stv_s + g * LB;
     long *st_b0 = stb_s + g * LB;
     int *st_len = stl_s + g * LB;
-    const unsigned mask = CAP - 1;
+    const unsigned mask = (unsigned)CAP - 1u;
     const unsigned long long gmask = (G == 64) ? ~0ULL : (((1ULL << G) - 1ULL) << (g * G));
     const unsigned long long below = (G == 64 ? ((1ULL << lane) - 1ULL) : (((1ULL << gl) - 1ULL) << (g * G)));
-    for (int q = lane; q < WCAP; q += 64) key_s[q] = -1;
+    if (!HBM) for (int q = lane; q < WCAP; q += 64) key_s[q] = -1;
     __syncthreads();
     const long stride = (long)gridDim.x * NG;
     const long first = (long)blockIdx.x * NG + g;
@@ -334,8 +339,9 @@ int matmat(const DCsr &A, const DCsr &B, DCsr &C)
         AMG_HIP(hipMemset(overflow, 0, sizeof(int)));
         const int rows_per_wave = 64 / G;
         const int blocks = (int)std::min<long>(((long)n + rows_per_wave - 1) / rows_per_wave, 256L * 2 * 8);
-#define GROUP_LAUNCH(FILL, GG) hipLaunchKernelGGL((spgemm_group_kernel<FILL, GG>), dim3(blocks), dim3(64), 0, nullptr, n, A.Ap, A.Aj, A.Ax, \
-                                                  B.Ap, B.Aj, B.Ax, count, (const long *)C.Ap, C.Aj, C.Ax, overflow)
+#define GROUP_LAUNCH(FILL, GG) hipLaunchKernelGGL((spgemm_group_kernel<FILL, GG, false>), dim3(blocks), dim3(64), 0, nullptr, n, A.Ap, A.Aj, A.Ax, \
+                                                  B.Ap, B.Aj, B.Ax, count, (const long *)C.Ap, C.Aj, C.Ax, overflow, (int *)nullptr, \
+                                                  (double *)nullptr, (int *)nullptr, 0)
 #define GROUP_DISPATCH(FILL) do { if (G == 8) GROUP_LAUNCH(FILL, 8); else if (G == 16) GROUP_LAUNCH(FILL, 16); \
                                   else if (G == 32) GROUP_LAUNCH(FILL, 32); else GROUP_LAUNCH(FILL, 64); } while (0)
         C.Ap = nullptr; C.Aj = nullptr; C.Ax = nullptr;
@@ -368,6 +374,53 @@ int matmat(const DCsr &A, const DCsr &B, DCsr &C)
 #undef GROUP_DISPATCH
 #undef GROUP_LAUNCH
         hipFree(count); hipFree(overflow);
+    }
+    // whole wave per row with the row's table in HBM: long rows on a small level (a few thousand rows of tens of
+    // thousands of products -- the coarse Galerkin products)
+    if (max_upper > 1024 && max_upper <= (1 << 22)) {
+        long distinct_bound = std::min<long>(max_upper, (long)B.n_col);
+        int gcap = 1024;
+        while (gcap < 2 * distinct_bound + 256) gcap <<= 1;
+        const int blocks = (int)std::max<long>(1, std::min<long>(std::min<long>(n, 1024), (4L << 30) / ((long)gcap * 16L)));
+        int *count = nullptr, *overflow = nullptr, *gkey = nullptr, *gord = nullptr;
+        double *gsum = nullptr;
+        AMG_HIP(hipMalloc((void **)&count, sizeof(int) * (size_t)std::max(n, 1)));
+        AMG_HIP(hipMalloc((void **)&overflow, sizeof(int)));
+        AMG_HIP(hipMemset(overflow, 0, sizeof(int)));
+        AMG_HIP(hipMalloc((void **)&gkey, sizeof(int) * (size_t)blocks * gcap));
+        AMG_HIP(hipMalloc((void **)&gord, sizeof(int) * (size_t)blocks * gcap));
+        AMG_HIP(hipMalloc((void **)&gsum, sizeof(double) * (size_t)blocks * gcap));
+        AMG_HIP(hipMemset(gkey, 0xFF, sizeof(int) * (size_t)blocks * gcap));
+        C.Ap = nullptr; C.Aj = nullptr; C.Ax = nullptr;
+        hipLaunchKernelGGL((spgemm_group_kernel<false, 64, true>), dim3(blocks), dim3(64), 0, nullptr, n, A.Ap, A.Aj, A.Ax, B.Ap, B.Aj, B.Ax,
+                           count, (const long *)nullptr, (int *)nullptr, (double *)nullptr, overflow, gkey, gsum, gord, gcap);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return hip_fail(e, "spgemm HBM-table count launch", __FILE__, __LINE__);
+        int ovf = 0;
+        AMG_HIP(hipMemcpy(&ovf, overflow, sizeof(int), hipMemcpyDeviceToHost));
+        if (std::getenv("AMG_SETUP_VERBOSE") && std::getenv("AMG_SETUP_VERBOSE")[0] != '0')
+            std::fprintf(stderr, "[setup]     device product %d x %d: one wave per row, %d-entry tables in HBM%s\n", A.n_row, B.n_col, gcap,
+                         ovf ? " -- overflow" : "");
+        int rc = 0;
+        if (!ovf) {
+            std::vector<int> hc((size_t)n);
+            AMG_HIP(hipMemcpy(hc.data(), count, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
+            std::vector<long> cp((size_t)n + 1);
+            cp[0] = 0;
+            for (int i = 0; i < n; ++i) cp[(size_t)i + 1] = cp[(size_t)i] + hc[(size_t)i];
+            C.nnz = cp[(size_t)n];
+            AMG_HIP(hipMalloc((void **)&C.Ap, sizeof(long) * ((size_t)n + 1)));
+            AMG_HIP(hipMalloc((void **)&C.Aj, sizeof(int) * (size_t)std::max(C.nnz, 1L)));
+            AMG_HIP(hipMalloc((void **)&C.Ax, sizeof(double) * (size_t)std::max(C.nnz, 1L)));
+            AMG_HIP(hipMemcpy(C.Ap, cp.data(), sizeof(long) * ((size_t)n + 1), hipMemcpyHostToDevice));
+            hipLaunchKernelGGL((spgemm_group_kernel<true, 64, true>), dim3(blocks), dim3(64), 0, nullptr, n, A.Ap, A.Aj, A.Ax, B.Ap, B.Aj, B.Ax,
+                               count, (const long *)C.Ap, C.Aj, C.Ax, overflow, gkey, gsum, gord, gcap);
+            e = hipGetLastError();
+            if (e != hipSuccess) rc = hip_fail(e, "spgemm HBM-table fill launch", __FILE__, __LINE__);
+            if (hipDeviceSynchronize() != hipSuccess && rc == 0) rc = AMG_ENODEV;
+        }
+        hipFree(count); hipFree(overflow); hipFree(gkey); hipFree(gord); hipFree(gsum);
+        if (!ovf) return rc;
     }
     if (!(max_upper <= 1024 || (double)n * (double)cap * 16.0 <= 2.0e9)) {
         set_error("spgemm: rows with more distinct columns than the LDS tables hold on a level too large for per-thread tables (host path)");

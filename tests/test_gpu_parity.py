@@ -1335,8 +1335,8 @@ def test_device_csr_matmat_is_scipys_bit_for_bit():
 @pytest.mark.gpu
 def test_device_csr_matmat_long_rows_one_wave_per_row():
     """rows of ~2000 products on a level too large for per-thread tables go one wave per row with the table in LDS
-    (lanes over the right-hand row, left-hand entries in order): still scipy's bits and order; a row with more distinct
-    columns than the table holds is refused (AMG_EINVAL -> the caller's host path), not mis-computed"""
+    (lanes over the right-hand row, left-hand entries in order): still scipy's bits and order; rows with more distinct
+    columns than the LDS table holds keep their table in HBM instead"""
     from pyamg_amd import _lib
     rng = np.random.RandomState(11)
 
@@ -1348,9 +1348,11 @@ def test_device_csr_matmat_long_rows_one_wave_per_row():
     Cp, Cj, Cx = _device_matmat(A, B)
     ref = A @ B
     assert np.array_equal(Cp, ref.indptr) and np.array_equal(Cj, ref.indices) and np.array_equal(Cx, ref.data)
-    Bwide = rnd(500, 60000, 70)                                  # ~2700 distinct columns per output row
-    with pytest.raises(ValueError):
-        _device_matmat(A, Bwide)
+    # ~2700 distinct columns per output row: more than a wave's LDS table holds -> the row's table moves to HBM
+    Bwide = rnd(500, 60000, 70)
+    Cp, Cj, Cx = _device_matmat(A[:6000], Bwide)
+    ref = A[:6000] @ Bwide
+    assert np.array_equal(Cp, ref.indptr) and np.array_equal(Cj, ref.indices) and np.array_equal(Cx, ref.data)
     # every lane-group width of the LDS kernel: right-hand rows of ~5, ~14, ~30 and ~60 entries (8 / 16 / 32 / 64
     # lanes per output row), ragged left-hand rows incl. empty ones, more rows than one pass of the grid covers
     for kb in (5, 14, 30, 60):
