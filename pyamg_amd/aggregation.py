@@ -580,7 +580,7 @@ def _default_options(B, strength_l, aggregate_l, smooth_l):
     return True
 
 
-def _extend_scalar(levels, smooth_l, keep, rho_fn, B_job=None):
+def _extend_scalar(levels, smooth_l, keep, rho_fn):
     """extend_hierarchy for scalar problems with one candidate (the BASELINE Poisson
     configurations), on flat arrays with the host helpers: same arithmetic as the generic
     path below, sized for 10^8 unknowns."""
@@ -627,13 +627,6 @@ def _extend_scalar(levels, smooth_l, keep, rho_fn, B_job=None):
     lap("aggregation")
     if n_agg == 0:
         raise ValueError("aggregation produced no aggregates")
-    if B_job is not None:                                   # the improved candidates (extend_hierarchy started them)
-        B_job[0].join()
-        if "error" in B_job[1]:
-            raise B_job[1]["error"]
-        B = B_job[1]["B"]
-        levels[-1].B = B
-        lap("candidate improvement (overlapped)")
     # tentative prolongator
     Bv = np.ascontiguousarray(B.ravel(), dtype=np.float64)
     Tp = np.empty(n + 1, dtype=np.int64)
@@ -838,21 +831,8 @@ def extend_hierarchy(levels, strength, aggregate, smooth, improve_candidates, ke
 
     li = len(levels) - 1
     fn, kwargs = unpack_arg(improve_candidates[li])
-    if fn is not None and not keep and A.shape[0] >= 1000000 and _scalar_fast_path_ok(A, B, strength[li], aggregate[li], smooth[li]) \
-            and os.environ.get("AMG_SETUP_OVERLAP_IMPROVE", "1") != "0":
-        # the candidate improvement (host threads) does not depend on the aggregation (one host thread, pattern only):
-        # it runs beside it and is joined where the tentative prolongator needs the candidates
-        import threading
-        box = {}
-
-        def improve():
-            try:
-                box["B"] = _improve((fn, kwargs), A, B)
-            except BaseException as e:      # noqa: BLE001 -- re-raised in the main thread
-                box["error"] = e
-        th = threading.Thread(target=improve)
-        th.start()
-        return _extend_scalar(levels, smooth[li], keep, rho_fn or _rho_D_inv_A_host, B_job=(th, box))
+    # (running the candidate improvement beside the aggregation was tried: both are bound by host memory bandwidth and
+    # the pair took longer than one after the other)
     if fn is not None:
         B = _improve((fn, kwargs), A, B)
         levels[-1].B = B
