@@ -473,7 +473,10 @@ def smoothed_aggregation_solver(A, B=None, BH=None, symmetry="hermitian", streng
     if A.shape[0] != A.shape[1]:
         raise ValueError("expected square matrix")
     if B is None:
-        B = np.kron(np.ones((int(A.shape[0] / blocksize(A)), 1), dtype=A.dtype), np.eye(blocksize(A)))
+        if blocksize(A) == 1:
+            B = np.ones((A.shape[0], 1), dtype=A.dtype)         # = the kron below for 1x1 blocks, without its temporaries
+        else:
+            B = np.kron(np.ones((int(A.shape[0] / blocksize(A)), 1), dtype=A.dtype), np.eye(blocksize(A)))
     else:
         B = np.asarray(B, dtype=A.dtype)
         if len(B.shape) == 1:

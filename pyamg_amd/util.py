@@ -340,11 +340,30 @@ def approximate_spectral_radius_device(A, dinv=None, tol=0.01, maxiter=15, resta
     import os, time
     verbose = os.environ.get("AMG_SETUP_VERBOSE", "0") != "0"
     t0 = time.perf_counter()
-    op = device_operator(A)
-    t1 = time.perf_counter()
     n = A.shape[0]
-    v0 = np.random.rand(n, 1).ravel()
-    t2 = time.perf_counter()
+    if getattr(A, "_amg_devop", None) is None and n >= 1000000:
+        # the upload of A (and its structure analysis) and the random start vector are independent: side by side
+        import threading
+        box = {}
+
+        def upload():
+            try:
+                box["op"] = device_operator(A)
+            except BaseException as e:      # noqa: BLE001 -- re-raised below
+                box["error"] = e
+        th = threading.Thread(target=upload)
+        th.start()
+        v0 = np.random.rand(n, 1).ravel()
+        th.join()
+        if "error" in box:
+            raise box["error"]
+        op = box["op"]
+        t1 = t2 = time.perf_counter()
+    else:
+        op = device_operator(A)
+        t1 = time.perf_counter()
+        v0 = np.random.rand(n, 1).ravel()
+        t2 = time.perf_counter()
     breakdown_tol = np.finfo(float).eps * 1e6
     ev = None
     max_index = 0
