@@ -411,6 +411,34 @@ static int bandwidth_of(const int *Ap, const int *Aj, int n)
     return bw;
 }
 
+// Chunk length for pipelined_sweep: rows whose nearest earlier neighbour is far away (more than half the bandwidth) or
+// absent start a "plane" of a lexicographically numbered mesh; if those rows are 0, S, 2S, ... the chunks are cut
+// there -- the first rows of a chunk then do not depend on the last rows of the chunk before it (with chunks of one
+// bandwidth that holds for the 7-point grid operator, whose bandwidth IS its plane, but not e.g. for a tetrahedral
+// mesh, whose bandwidth is a plane plus a grid line: every chunk would wait for the whole chunk before it).
+static int plane_stride(const int *Ap, const int *Aj, int n, int bw)
+{
+    std::vector<int> starts;
+    const int T = std::max(1, omp_get_max_threads());
+    std::vector<std::vector<int>> part((size_t)T);
+#pragma omp parallel num_threads(T)
+    {
+        std::vector<int> &mine = part[(size_t)omp_get_thread_num()];
+#pragma omp for schedule(static)
+        for (int i = 0; i < n; ++i) {
+            int nearest = -1;
+            for (int jj = Ap[i]; jj < Ap[i + 1]; ++jj) { const int j = Aj[jj]; if (j < i && j > nearest) nearest = j; }
+            if (nearest < 0 || i - nearest > bw / 2) mine.push_back(i);
+        }
+    }
+    for (auto &v : part) starts.insert(starts.end(), v.begin(), v.end());      // static schedule: already in row order
+    if (starts.size() < 3 || starts[0] != 0) return bw;
+    const int S = starts[1] - starts[0];
+    if (S < bw / 2 || S > bw) return bw;
+    for (size_t k = 1; k < starts.size(); ++k) if (starts[k] - starts[k - 1] != S) return bw;
+    return S;
+}
+
 extern "C" {
 
 // get_diagonal(A, inv=True) (util/utils.py:526-588) on flat CSR arrays, row-parallel: duplicates of the diagonal
@@ -464,9 +492,10 @@ int amgsetup_block_gauss_seidel_pipelined(const int *Ap, const int *Aj, const do
         }
     };
     if (bs > 16) return 0;
+    const int chunk = plane_stride(Ap, Aj, nb, bw);
     for (int it = 0; it < iterations; ++it) {
-        if (sweep == 0 || sweep == 2) pipelined_sweep(Ap, Aj, nb, false, bw, T, row_op);
-        if (sweep == 1 || sweep == 2) pipelined_sweep(Ap, Aj, nb, true, bw, T, row_op);
+        if (sweep == 0 || sweep == 2) pipelined_sweep(Ap, Aj, nb, false, chunk, T, row_op);
+        if (sweep == 1 || sweep == 2) pipelined_sweep(Ap, Aj, nb, true, chunk, T, row_op);
     }
     return 1;
 }
@@ -489,9 +518,10 @@ int amgsetup_gauss_seidel_pipelined(const int *Ap, const int *Aj, const double *
         }
         if (diag != 0.0) x[i] = (b[i] - rsum) / diag;
     };
+    const int chunk = plane_stride(Ap, Aj, n, bw);
     for (int it = 0; it < iterations; ++it) {
-        if (sweep == 0 || sweep == 2) pipelined_sweep(Ap, Aj, n, false, bw, T, row_op);
-        if (sweep == 1 || sweep == 2) pipelined_sweep(Ap, Aj, n, true, bw, T, row_op);
+        if (sweep == 0 || sweep == 2) pipelined_sweep(Ap, Aj, n, false, chunk, T, row_op);
+        if (sweep == 1 || sweep == 2) pipelined_sweep(Ap, Aj, n, true, chunk, T, row_op);
     }
     return 1;
 }
