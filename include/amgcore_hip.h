@@ -385,7 +385,7 @@ void amg_set_stencil_form(int on);
  * (where it is measured faster), 2 always, 0 never (one row per lane).  Same bits. */
 void amg_set_stencil_pairs(int on);
 /* operators without grid structure (Galerkin operators, restriction): 1 (default) whole-operator applications run from
- * the sliced form (rows sorted by length in windows of 2048, slices of 64 rows stored entry-major: one lane per row,
+ * the sliced form (rows sorted by length in windows of 256 -- restrictions 64 --, slices of 64 rows stored entry-major: one lane per row,
  * no row pointer, no LDS); 0: from CSR.  Same bits. */
 void amg_set_sell_form(int on);
 /* runs of narrow Gauss-Seidel dependency levels are swept by one workgroup in one launch: 2 (default) the sweep runs

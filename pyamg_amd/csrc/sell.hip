@@ -7,7 +7,7 @@
 // entry-major (entry k of the 64 rows side by side, padded to the slice's longest row), so a lane's loads are
 // coalesced with its neighbours', need no row pointer and no LDS, and ALL of a row's entries (up to 32 per pass) are
 // requested before any is consumed: two round trips per slice, no barrier.  Rows are sorted by length inside windows
-// of 2048 (longest first, ties in row order) so that slices are nearly rectangular.
+// of 256 (restrictions: 64) rows (longest first, ties in row order) so that slices are nearly rectangular.
 // Every lane adds ITS row's products in stored order with separate multiply and add: bit-identical to the CSR kernel
 // (scipy csr_matvec / relaxation.h row loops) in every mode.
 #include "hier.hpp"
@@ -21,8 +21,9 @@ namespace amg {
 namespace {
 
 constexpr int SL_C = 64;            // rows per slice = lanes per wave
-constexpr int SL_SIGMA = 2048;      // rows per sorting window
-constexpr int SL_PASS = 32;         // entries of a row requested at once
+constexpr int SL_SIGMA_SQUARE = 256;   // rows per sorting window: square operators (A_l)
+constexpr int SL_SIGMA_RECT = 64;      //                          restrictions (the gathers reach into the finer level: keep neighbours together)
+constexpr int SL_PASS = 32;         // entries of a row requested at once (16: measured slower)
 constexpr int SL_WG = 256;          // four slices per workgroup
 
 __device__ __forceinline__ int remap(int b, int nb, int chunk)       // kernels.hip remap_block: consecutive blocks to one XCD
@@ -34,13 +35,19 @@ __device__ __forceinline__ int remap(int b, int nb, int chunk)       // kernels.
     return base + xcd * q + min(xcd, r) + j;
 }
 
-// window sort: key = ((length + 1) << 11) | (2047 - position in window), sorted DESCENDING = longest row first, ties in
-// row order.  Bitonic network over the 2048 keys of a window in LDS.
+// window sort: key = ((length + 1) << 11) | (window size - 1 - position in window), sorted DESCENDING = longest row
+// first, ties in row order.  Bitonic network over the keys of a window in LDS.
+// Window size (tools/sell_ab.py with differently compiled libraries, 300^3 / 400^3 / 500^3): the wider the window, the
+// less padding but the further apart the rows that end up side by side in a slice -- their gathers then share fewer
+// cache lines.  2048: A_1 -11 % at 500^3 but +2 % / +10 % at 400^3 / 300^3 against the CSR kernel and R_0 up to +46 %;
+// 256: A_1 -9 .. -12 % at all three sizes; restrictions (which gather from the finer level) want 64.
+template <int SL_SIGMA>
 __global__ __launch_bounds__(1024) void sell_sort_kernel(int n, const int *Ap, int *sl_row, unsigned short *sl_len, int *slice_w)
 {
     __shared__ unsigned key[SL_SIGMA];
+    static_assert(SL_SIGMA <= 2048 && (SL_SIGMA & (SL_SIGMA - 1)) == 0, "window: a power of two up to 2048 (11-bit position in the sort key)");
     const int w0 = blockIdx.x * SL_SIGMA;
-    for (int q = threadIdx.x; q < SL_SIGMA; q += 1024) {
+    for (int q = threadIdx.x; q < SL_SIGMA; q += (int)blockDim.x) {
         const int i = w0 + q;
         const unsigned len = (i < n) ? (unsigned)(Ap[i + 1] - Ap[i]) : 0u;
         key[q] = (i < n) ? (((len + 1u) << 11) | (unsigned)(SL_SIGMA - 1 - q)) : 0u;      // slots past the last row: key 0, sorted last
@@ -48,7 +55,7 @@ __global__ __launch_bounds__(1024) void sell_sort_kernel(int n, const int *Ap, i
     __syncthreads();
     for (int k = 2; k <= SL_SIGMA; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int q = threadIdx.x; q < SL_SIGMA; q += 1024) {
+            for (int q = threadIdx.x; q < SL_SIGMA; q += (int)blockDim.x) {
                 const int p = q ^ j;
                 if (p > q) {
                     const unsigned a = key[q], b = key[p];
@@ -58,7 +65,7 @@ __global__ __launch_bounds__(1024) void sell_sort_kernel(int n, const int *Ap, i
             }
             __syncthreads();
         }
-    for (int q = threadIdx.x; q < SL_SIGMA; q += 1024) {
+    for (int q = threadIdx.x; q < SL_SIGMA; q += (int)blockDim.x) {
         const unsigned kq = key[q];
         const bool is_row = kq != 0u;
         const int pos = SL_SIGMA - 1 - (int)(kq & 2047u);
@@ -178,7 +185,8 @@ int launch_sell(StreamMode mode, const StreamArgs &a, const DevCsr &M, hipStream
     if (b.gscale == 0.0) b.gscale = 1.0;
     SellArgs S{M.sl_row, M.sl_len, M.sl_off, M.sl_col, M.sl_val, M.sl_nslices};
     const int grid = (M.sl_nslices + SL_WG / SL_C - 1) / (SL_WG / SL_C);
-    const int chunk = grid >= 4096 ? 32 : 0;
+    static const int chunk_env = std::getenv("AMG_SELL_CHUNK") ? std::atoi(std::getenv("AMG_SELL_CHUNK")) : 32;
+    const int chunk = grid >= 4096 ? chunk_env : 0;
     switch (mode) {
 #define SELL_CASE(MODE) case MODE: hipLaunchKernelGGL((sell_kernel<MODE>), dim3(grid), dim3(SL_WG), 0, st, b, S, chunk); break
     SELL_CASE(SM_MATVEC);
@@ -206,8 +214,9 @@ int build_sell(DevCsr &M, long *acct)
     if (env && std::atoi(env) == 0) return 0;
     const int n = M.nrows;
     if (n < (1 << 16) || M.nnz < 8L * n || M.nnz > 48L * n || !M.Ap || !M.Aj || !M.Ax) return 0;
-    const int nwin = (n + SL_SIGMA - 1) / SL_SIGMA;
-    const int nslices = nwin * (SL_SIGMA / SL_C);
+    const int sigma = (M.ncols >= 2L * n) ? SL_SIGMA_RECT : SL_SIGMA_SQUARE;
+    const int nwin = (n + sigma - 1) / sigma;
+    const int nslices = nwin * (sigma / SL_C);
     int *row = nullptr, *w_dev = nullptr;
     unsigned short *len = nullptr;
     // longest row must fit the 11 + 21-bit sort key and the 16-bit length
@@ -221,7 +230,8 @@ int build_sell(DevCsr &M, long *acct)
     AMG_HIP(hipMalloc((void **)&row, sizeof(int) * (size_t)nslices * SL_C));
     AMG_HIP(hipMalloc((void **)&len, sizeof(unsigned short) * (size_t)nslices * SL_C));
     AMG_HIP(hipMalloc((void **)&w_dev, sizeof(int) * (size_t)nslices));
-    hipLaunchKernelGGL(sell_sort_kernel, dim3(nwin), dim3(1024), 0, nullptr, n, M.Ap, row, len, w_dev);
+    if (sigma == SL_SIGMA_RECT) hipLaunchKernelGGL((sell_sort_kernel<SL_SIGMA_RECT>), dim3(nwin), dim3(64), 0, nullptr, n, M.Ap, row, len, w_dev);
+    else hipLaunchKernelGGL((sell_sort_kernel<SL_SIGMA_SQUARE>), dim3(nwin), dim3(256), 0, nullptr, n, M.Ap, row, len, w_dev);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "sell sort launch", __FILE__, __LINE__);
     std::vector<int> hw((size_t)nslices);
