@@ -59,6 +59,7 @@ struct DevCsr {
     double *sl_val = nullptr;
     int sl_nslices = 0;
     long sl_entries = 0;           // padded entries stored
+    int sl_lo = 0, sl_hi = 0;      // rows the sliced form covers (all of them; a partitioned level: its interior rows)
     double *st_vals = nullptr;     // [nblocks256 * st_nu * 256]
     void *st_mask = nullptr;       // [nrows] uint8 when |U| <= 7, else uint32; top bit = row not covered
     int st_nu = 0;                 // |U|
@@ -163,7 +164,8 @@ bool sell_supports(StreamMode mode);
 bool sell_enabled();
 void set_sell_form(int on);
 int launch_sell(StreamMode mode, const StreamArgs &a, const DevCsr &M, hipStream_t st);
-int build_sell(DevCsr &M, long *acct);         // from the CSR arrays already in HBM; leaves M untouched if not worth it
+int build_sell(DevCsr &M, long *acct, int row_lo = 0, int row_hi = -1);   // from the CSR arrays already in HBM (rows [lo, hi), default all); leaves M untouched if not worth it
+void free_sell(DevCsr &M);
 int stencil_blocks(const StreamArgs &a, const DevCsr &M);   // workgroups (= SM_RESIDUAL_SUMSQ partials) of launch_stencil
 int launch_stencil_build(const DevCsr &M, const int *dict_slot, const unsigned *pat_mask, hipStream_t st);
 // value index: distinct values of st_vals into a 1024-slot table (EMPTY = all ones), then the byte codes

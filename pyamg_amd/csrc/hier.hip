@@ -52,12 +52,7 @@ void free_csr(DevCsr &M)
     if (M.pat) hipFree(M.pat);
     if (M.dict_ptr) hipFree(M.dict_ptr);
     if (M.dict_off) hipFree(M.dict_off);
-    if (M.sl_row) hipFree(M.sl_row);
-    if (M.sl_len) hipFree(M.sl_len);
-    if (M.sl_off) hipFree(M.sl_off);
-    if (M.sl_col) hipFree(M.sl_col);
-    if (M.sl_val) hipFree(M.sl_val);
-    M.sl_row = nullptr; M.sl_len = nullptr; M.sl_off = nullptr; M.sl_col = nullptr; M.sl_val = nullptr; M.sl_nslices = 0; M.sl_entries = 0;
+    free_sell(M);
     if (M.st_vals) hipFree(M.st_vals);
     if (M.st_mask) hipFree(M.st_mask);
     if (M.st_codes) hipFree(M.st_codes);
@@ -732,7 +727,7 @@ int apply_operator(const DevCsr &M, StreamMode mode, const StreamArgs &a, hipStr
     }
     if (M.st_vals && stencil_enabled() && pattern_supports(mode)) return launch_stencil(mode, a, M, st);
     if (M.pat && pattern_supports(mode)) return launch_pattern(mode, a, M, st);
-    if (M.sl_val && sell_enabled() && sell_supports(mode) && a.row_lo == 0 && a.row_hi == M.nrows && !a.rowmap && a.Aj == M.Aj)
+    if (M.sl_val && sell_enabled() && sell_supports(mode) && a.row_lo == M.sl_lo && a.row_hi == M.sl_hi && !a.rowmap && a.Aj == M.Aj)
         return launch_sell(mode, a, M, st);
     return launch_stream(mode, a, st);
 }
@@ -1503,7 +1498,8 @@ int amg_hier_set_matrix(amg_hier *h, int lvl, int which, int fmt, int nrows, int
         CHK(upload_csr(M, nrows, ncols, cp.data(), cj.data(), cx.data(), &h->dev_bytes));
     }
     // operators without grid structure: the sliced form (sell.hip) for whole-operator applications
-    if (M.Ap && !M.pat && !M.st_vals && !h->comm) CHK(build_sell(M, &h->dev_bytes));
+    // (a partitioned level's A gets it in amg_hier_set_partition, for the interior rows that run beside the exchange)
+    if (M.Ap && !M.pat && !M.st_vals && !(h->comm && which == AMG_MAT_A)) CHK(build_sell(M, &h->dev_bytes));
     if (which == AMG_MAT_A) {
         if (nrows != ncols && !(h->comm && ncols > nrows)) { set_error("A must be square (row-partitioned: owned rows x [owned | halo] columns)"); return AMG_EINVAL; }
         L.fmt = fmt; L.R = R; L.C = C; L.hasA = true;
@@ -1822,6 +1818,16 @@ int amg_hier_set_partition(amg_hier *h, int lvl, int n_own, int n_halo, int chan
     if (i0 < 0 || i1 > n_own || i1 < i0) { i0 = 0; i1 = 0; }
     P.i0 = i0; P.i1 = i1;
     P.overlap = channel >= 0 && n_halo > 0 && (double)(i1 - i0) >= 0.5 * (double)std::max(n_own, 1);
+    {
+        // the sliced form of this level's A: the rows one application covers in ONE launch -- the interior rows when
+        // they run beside the exchange, else all of them
+        DevCsr &A = h->lv[lvl].A;
+        free_sell(A);
+        if (A.Ap && !A.pat && !A.st_vals) {
+            if (h->overlap && P.overlap) CHK(build_sell(A, &h->dev_bytes, i0, i1));
+            else CHK(build_sell(A, &h->dev_bytes));
+        }
+    }
     h->finalized = false;
     return 0;
 }
@@ -2192,7 +2198,7 @@ static double bytes_spmv_moved(const DevCsr &M)
     if (M.st_vals && stencil_enabled())     // padded values (or one-byte codes) + one mask word per row; no row pointer
         return ((M.st_vi_on && M.st_codes) ? 8.0 * (double)((M.st_nu + 7) / 8) : 8.0 * (double)M.st_nu) * 256.0 * (double)((M.nrows + 255) / 256) + (M.st_nu <= 7 ? 1.0 : 4.0) * M.nrows +
                8.0 * M.ncols + 8.0 * M.nrows;
-    if (!M.pat && M.sl_val && sell_enabled())    // padded entries, slot bookkeeping (row id + length), slice offsets; no row pointer
+    if (!M.pat && M.sl_val && sell_enabled() && M.sl_lo == 0 && M.sl_hi == M.nrows)    // padded entries, slot bookkeeping (row id + length), slice offsets; no row pointer
         return 12.0 * (double)M.sl_entries + 6.0 * 64.0 * M.sl_nslices + 8.0 * (M.sl_nslices + 1.0) + 8.0 * M.ncols + 8.0 * M.nrows;
     if (!M.pat) {
         double idx = (M.Aj16 && index16_enabled()) ? (2.0 * M.i16_frac + 4.0 * (1.0 - M.i16_frac)) : 4.0;

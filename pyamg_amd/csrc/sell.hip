@@ -42,14 +42,14 @@ __device__ __forceinline__ int remap(int b, int nb, int chunk)       // kernels.
 // cache lines.  2048: A_1 -11 % at 500^3 but +2 % / +10 % at 400^3 / 300^3 against the CSR kernel and R_0 up to +46 %;
 // 256: A_1 -9 .. -12 % at all three sizes; restrictions (which gather from the finer level) want 64.
 template <int SL_SIGMA>
-__global__ __launch_bounds__(1024) void sell_sort_kernel(int n, const int *Ap, int *sl_row, unsigned short *sl_len, int *slice_w)
-{
+__global__ __launch_bounds__(1024) void sell_sort_kernel(int row_lo, int n, const int *Ap, int *sl_row, unsigned short *sl_len, int *slice_w)
+{          // rows row_lo .. row_lo + n - 1
     __shared__ unsigned key[SL_SIGMA];
     static_assert(SL_SIGMA <= 2048 && (SL_SIGMA & (SL_SIGMA - 1)) == 0, "window: a power of two up to 2048 (11-bit position in the sort key)");
     const int w0 = blockIdx.x * SL_SIGMA;
     for (int q = threadIdx.x; q < SL_SIGMA; q += (int)blockDim.x) {
         const int i = w0 + q;
-        const unsigned len = (i < n) ? (unsigned)(Ap[i + 1] - Ap[i]) : 0u;
+        const unsigned len = (i < n) ? (unsigned)(Ap[row_lo + i + 1] - Ap[row_lo + i]) : 0u;
         key[q] = (i < n) ? (((len + 1u) << 11) | (unsigned)(SL_SIGMA - 1 - q)) : 0u;      // slots past the last row: key 0, sorted last
     }
     __syncthreads();
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(1024) void sell_sort_kernel(int n, const int *Ap, i
         const int pos = SL_SIGMA - 1 - (int)(kq & 2047u);
         const int len = is_row ? (int)(kq >> 11) - 1 : 0;
         const int slot = w0 + q;
-        sl_row[slot] = is_row ? w0 + pos : -1;
+        sl_row[slot] = is_row ? row_lo + w0 + pos : -1;
         sl_len[slot] = (unsigned short)len;
         if ((q & (SL_C - 1)) == 0) slice_w[slot / SL_C] = len;                    // the slice's longest row comes first
     }
@@ -171,6 +171,17 @@ int g_sell = 1;
 
 }   // namespace
 
+void free_sell(DevCsr &M)
+{
+    if (M.sl_row) hipFree(M.sl_row);
+    if (M.sl_len) hipFree(M.sl_len);
+    if (M.sl_off) hipFree(M.sl_off);
+    if (M.sl_col) hipFree(M.sl_col);
+    if (M.sl_val) hipFree(M.sl_val);
+    M.sl_row = nullptr; M.sl_len = nullptr; M.sl_off = nullptr; M.sl_col = nullptr; M.sl_val = nullptr;
+    M.sl_nslices = 0; M.sl_entries = 0; M.sl_lo = M.sl_hi = 0;
+}
+
 bool sell_supports(StreamMode mode)
 {
     return mode == SM_MATVEC || mode == SM_MATVEC_ACC || mode == SM_RESIDUAL || mode == SM_POLY_FIRST || mode == SM_POLY_STEP ||
@@ -208,30 +219,34 @@ int launch_sell(StreamMode mode, const StreamArgs &a, const DevCsr &M, hipStream
 // carry too few entries for its scattered row bookkeeping and result accesses) and stream well through the CSR kernel; longer rows (R_1: 150 entries, A_2: 67) need several dependent passes per
 // slice with few slices to overlap them and were 5-70 % slower -- at least 2^16 rows, no row longer than 2046
 // entries, and at most 15 % padding.
-int build_sell(DevCsr &M, long *acct)
+int build_sell(DevCsr &M, long *acct, int row_lo, int row_hi)
 {
     const char *env = std::getenv("AMG_SELL");
     if (env && std::atoi(env) == 0) return 0;
-    const int n = M.nrows;
-    if (n < (1 << 16) || M.nnz < 8L * n || M.nnz > 48L * n || !M.Ap || !M.Aj || !M.Ax) return 0;
-    const int sigma = (M.ncols >= 2L * n) ? SL_SIGMA_RECT : SL_SIGMA_SQUARE;
+    if (row_hi < 0) row_hi = M.nrows;
+    if (row_lo < 0 || row_hi > M.nrows || row_hi <= row_lo || !M.Ap || !M.Aj || !M.Ax) return 0;
+    const int n = row_hi - row_lo;
+    const int sigma = (M.ncols >= 2L * M.nrows) ? SL_SIGMA_RECT : SL_SIGMA_SQUARE;
     const int nwin = (n + sigma - 1) / sigma;
     const int nslices = nwin * (sigma / SL_C);
     int *row = nullptr, *w_dev = nullptr;
     unsigned short *len = nullptr;
-    // longest row must fit the 11 + 21-bit sort key and the 16-bit length
+    // longest row must fit the 11 + 21-bit sort key and the 16-bit length; average row length 8 .. 48 (see above)
+    long nnz_range = 0;
     {
         std::vector<int> hp((size_t)n + 1);
-        AMG_HIP(hipMemcpy(hp.data(), M.Ap, sizeof(int) * ((size_t)n + 1), hipMemcpyDeviceToHost));
+        AMG_HIP(hipMemcpy(hp.data(), M.Ap + row_lo, sizeof(int) * ((size_t)n + 1), hipMemcpyDeviceToHost));
         int longest = 0;
         for (int i = 0; i < n; ++i) longest = std::max(longest, hp[(size_t)i + 1] - hp[(size_t)i]);
         if (longest > 2046) return 0;
+        nnz_range = (long)hp[(size_t)n] - hp[0];
     }
+    if (n < (1 << 16) || nnz_range < 8L * n || nnz_range > 48L * n) return 0;
     AMG_HIP(hipMalloc((void **)&row, sizeof(int) * (size_t)nslices * SL_C));
     AMG_HIP(hipMalloc((void **)&len, sizeof(unsigned short) * (size_t)nslices * SL_C));
     AMG_HIP(hipMalloc((void **)&w_dev, sizeof(int) * (size_t)nslices));
-    if (sigma == SL_SIGMA_RECT) hipLaunchKernelGGL((sell_sort_kernel<SL_SIGMA_RECT>), dim3(nwin), dim3(64), 0, nullptr, n, M.Ap, row, len, w_dev);
-    else hipLaunchKernelGGL((sell_sort_kernel<SL_SIGMA_SQUARE>), dim3(nwin), dim3(256), 0, nullptr, n, M.Ap, row, len, w_dev);
+    if (sigma == SL_SIGMA_RECT) hipLaunchKernelGGL((sell_sort_kernel<SL_SIGMA_RECT>), dim3(nwin), dim3(64), 0, nullptr, row_lo, n, M.Ap, row, len, w_dev);
+    else hipLaunchKernelGGL((sell_sort_kernel<SL_SIGMA_SQUARE>), dim3(nwin), dim3(256), 0, nullptr, row_lo, n, M.Ap, row, len, w_dev);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "sell sort launch", __FILE__, __LINE__);
     std::vector<int> hw((size_t)nslices);
@@ -241,7 +256,7 @@ int build_sell(DevCsr &M, long *acct)
     off[0] = 0;
     for (int s = 0; s < nslices; ++s) off[(size_t)s + 1] = off[(size_t)s] + (long)hw[(size_t)s] * SL_C;
     const long entries = off[(size_t)nslices];
-    if ((double)entries > 1.15 * (double)M.nnz) { hipFree(row); hipFree(len); return 0; }
+    if ((double)entries > 1.15 * (double)nnz_range) { hipFree(row); hipFree(len); return 0; }
     long *off_dev = nullptr;
     int *col = nullptr;
     double *val = nullptr;
@@ -255,7 +270,7 @@ int build_sell(DevCsr &M, long *acct)
     if (e != hipSuccess) return hip_fail(e, "sell fill launch", __FILE__, __LINE__);
     AMG_HIP(hipDeviceSynchronize());
     M.sl_row = row; M.sl_len = len; M.sl_off = off_dev; M.sl_col = col; M.sl_val = val;
-    M.sl_nslices = nslices; M.sl_entries = entries;
+    M.sl_nslices = nslices; M.sl_entries = entries; M.sl_lo = row_lo; M.sl_hi = row_hi;
     if (acct) *acct += (long)(sizeof(int) * (size_t)nslices * SL_C + sizeof(unsigned short) * (size_t)nslices * SL_C +
                               sizeof(long) * ((size_t)nslices + 1) + 12L * entries);
     return 0;

@@ -127,6 +127,46 @@ def test_rank_local_stencil_form_with_halos(world, transport, tmp_path):
     assert np.allclose(res, res1, rtol=1e-12, atol=1e-13 * res1[0])
 
 
+def _worker_sliced(rank, world, port, grid, out_dir, transport):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    _transport_env(rank, transport)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    S = None
+    try:
+        from pyamg_amd.distributed import DistributedSolver, HipBackend, split_rows, levels_from_ml
+        ml, b = _own_hierarchy(grid)
+        levels, coarse = levels_from_ml(ml)
+        S = DistributedSolver(levels, coarse, HipBackend(0), rank, world, replicate_below=600)
+        assert S.operator_form(1) == 3, "A_1 of the slab should have its interior rows in the sliced form"
+        bnd = split_rows(len(b), world)
+        lo, hi = int(bnd[rank]), int(bnd[rank + 1])
+        x, res = S.solve(b[lo:hi], None, tol=0.0, maxiter=4, cycle="V", fixed=True)
+        np.save(os.path.join(out_dir, "x_%d.npy" % rank), x)
+        if rank == 0:
+            np.save(os.path.join(out_dir, "res.npy"), np.array(res))
+    finally:
+        if S is not None:
+            S.close()
+        dist.destroy_process_group()
+
+
+def test_partitioned_level_applies_interior_rows_from_the_sliced_form(tmp_path):
+    """A partitioned level whose interior rows (the ones that run beside the halo exchange) number 2^16 and more gets
+    the sliced form for exactly that row range; boundary rows, restriction and prolongation as before.  Two ranks on
+    the GPU: gathered iterate bit-identical to the single-GPU solve."""
+    grid = (128, 126, 122)
+    world = 2
+    ml, b = _own_hierarchy(grid)
+    res1 = []
+    x1 = ml.solve(b, tol=0.0, maxiter=4, residuals=res1)
+    mp.spawn(_worker_sliced, args=(world, _free_port(), grid, str(tmp_path), "peer"), nprocs=world, join=True)
+    x = np.concatenate([np.load(tmp_path / ("x_%d.npy" % r)) for r in range(world)])
+    res = np.load(tmp_path / "res.npy")
+    assert np.array_equal(x, x1), np.abs(x - x1).max()
+    assert np.allclose(res, res1, rtol=1e-12, atol=1e-13 * res1[0])
+
+
 def _worker_hybrid(rank, world, port, case, out_dir, rep=0, transport="peer"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
