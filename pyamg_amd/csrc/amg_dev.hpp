@@ -268,5 +268,9 @@ int build_bsell(DevBsr &M, long *acct);
 void free_bsell(DevBsr &M);
 bool bsell_applies(const DevBsr &M, BlockMode m, const BsrStreamArgs &a);
 int launch_bsell(const DevBsr &M, BlockMode m, const BsrStreamArgs &a, hipStream_t st);
+// level-ordered copy of a block Gauss-Seidel schedule: slices cut at level boundaries, one launch per level
+int build_bsell_levels(DevBsr &M, const std::vector<int> &level_ptr, const int *rowmap_dev, std::vector<int> &level_slice, long *acct);
+int launch_bsell_level(const DevBsr &M, BlockMode m, const BsrStreamArgs &a, int slice_lo, int slice_hi, hipStream_t st);
+bool bsell_level_enabled();
 
 }  // namespace amg

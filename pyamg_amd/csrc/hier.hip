@@ -412,6 +412,7 @@ void Schedule::release()
     c2_code_f = c2_code_b = c2_off = perm_Aj = nullptr;
     c2_diag = c2_val = c2_dummy = xp = bp = bd = nullptr;
     chain2 = perm = false;
+    gb_level_slice.clear();
     chains.clear();
     chain_width.clear();
 }
@@ -676,6 +677,8 @@ int build_block_schedule(const int *Ap, const int *Aj, int nb, const int *tasks,
             std::memcpy(gx.data() + (long)gp[k] * B2, Ax + (long)Ap[i] * B2, sizeof(double) * (size_t)(len * B2));
         }
         CHK(upload_bsr(S.Gb, ntasks, bs, gp.data(), gj.data(), gx.data(), nullptr));
+        // block Gauss-Seidel levels of a large operator: one launch per level from the sliced block form
+        if (!independent) CHK(build_bsell_levels(S.Gb, S.level_ptr, S.rows, S.gb_level_slice, nullptr));
     }
     return 0;
 }
@@ -812,11 +815,13 @@ int sweep_block_schedule(const Schedule &S, BlockMode mode, const double *Dinv, 
     a.Ap = S.Gb.Ap; a.Aj = S.Gb.Aj; a.Ax = S.Gb.Ax; a.bs = S.Gb.bs;
     a.rowmap = S.rows; a.intra_reverse = reverse ? 1 : 0;
     a.xin = xin; a.xout = x; a.b = b; a.Dinv = Dinv; a.omega = omega;
+    const bool sliced = mode == BM_BLOCK_GS && !S.gb_level_slice.empty() && S.Gb.bsl_val && bsell_level_enabled();
     for (int q = 0; q < nl; ++q) {
         int l = reverse ? nl - 1 - q : q;
         a.brow_lo = S.level_ptr[l];
         a.brow_hi = S.level_ptr[l + 1];
-        CHK(launch_bsr_stream(mode, a, (long)S.Gb.nblocks * (a.brow_hi - a.brow_lo) / (S.ntasks ? S.ntasks : 1), st));
+        if (sliced) CHK(launch_bsell_level(S.Gb, mode, a, S.gb_level_slice[(size_t)l], S.gb_level_slice[(size_t)l + 1], st));
+        else CHK(launch_bsr_stream(mode, a, (long)S.Gb.nblocks * (a.brow_hi - a.brow_lo) / (S.ntasks ? S.ntasks : 1), st));
     }
     return 0;
 }

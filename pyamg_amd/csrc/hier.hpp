@@ -44,6 +44,7 @@ struct Schedule {
     // BSR flavour: block rows listed in level order
     int *rows = nullptr;          // device
     DevBsr Gb;                    // BSR flavour with values: block rows copied in level order (streamed)
+    std::vector<int> gb_level_slice;   // sliced block form of Gb (sell.hip): first slice of every level (empty: not built)
     int nlevels() const { return (int)level_ptr.size() - 1; }
     void release();
 };

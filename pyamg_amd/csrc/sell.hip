@@ -292,16 +292,20 @@ namespace {
 constexpr int BSL_WIN = 32;          // slices per sorting window
 constexpr int BSL_PASS = 8;          // blocks of a row requested at once
 
+// windows: consecutive runs of WIN block rows, or (win_start / win_len given) listed runs of at most WIN block rows --
+// the level-ordered copy of a Gauss-Seidel schedule is cut so that no window, hence no slice, straddles two levels
 template <int NBR>
-__global__ __launch_bounds__(1024) void bsell_sort_kernel(int nb, const int *Ap, int *brow, unsigned short *blen, int *slice_w)
+__global__ __launch_bounds__(1024) void bsell_sort_kernel(int nb, const int *Ap, int *brow, unsigned short *blen, int *slice_w,
+                                                          const int *win_start, const int *win_len)
 {
     constexpr int WIN = BSL_WIN * NBR;            // block rows per window (<= 1024)
     __shared__ unsigned key[1024];
-    const int w0 = blockIdx.x * WIN;
+    const int w0 = win_start ? win_start[blockIdx.x] : blockIdx.x * WIN;
+    const int cnt = win_start ? win_len[blockIdx.x] : min(WIN, nb - w0);
     const int q = threadIdx.x;
     {
         const int i = w0 + q;
-        const bool real = q < WIN && i < nb;
+        const bool real = q < cnt && i < nb;
         const unsigned len = real ? (unsigned)(Ap[i + 1] - Ap[i]) : 0u;
         key[q] = real ? (((len + 1u) << 10) | (unsigned)(1023 - q)) : 0u;
     }
@@ -353,12 +357,13 @@ struct BsellArgs {
 };
 
 template <int BMODE, int BS>
-__global__ __launch_bounds__(256) void bsell_kernel(BsrStreamArgs a, BsellArgs S, int xcd_chunk)
+__global__ __launch_bounds__(256) void bsell_kernel(BsrStreamArgs a, BsellArgs S, int xcd_chunk, int slice_lo, int slice_n)
 {
     constexpr int NBR = 64 / BS, LW = NBR * BS, B2 = BS * BS;
     const int blk = remap((int)blockIdx.x, (int)gridDim.x, xcd_chunk);
-    const int s = blk * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (s >= S.nslices) return;
+    const int sl = blk * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (sl >= slice_n) return;
+    const int s = slice_lo + sl;
     const long o = S.off[s];
     const int w = (int)(S.off[s + 1] - o);                          // uniform over the wave
     const bool lane_ok = lane < LW;
@@ -371,6 +376,7 @@ __global__ __launch_bounds__(256) void bsell_kernel(BsrStreamArgs a, BsellArgs S
     double ep_b = 0.0, ep_v2 = 0.0, ep_x = 0.0;
     if (active) {
         if (BMODE == BM_BLOCK_JACOBI) { ep_b = a.b[ib + r]; ep_x = a.xin[ib + r]; }
+        else if (BMODE == BM_BLOCK_GS) ep_b = a.b[ib + r];
         else {
             if (a.smode == SM_RESIDUAL || a.smode == SM_POLY_STEP || a.smode == SM_POLY_LAST) ep_b = a.b[ib + r];
             if (a.smode == SM_POLY_LAST) ep_v2 = a.v2[ib + r];
@@ -433,19 +439,49 @@ __global__ __launch_bounds__(256) void bsell_kernel(BsrStreamArgs a, BsellArgs S
         vD = vD + d * tc;
     }
     if (active) {
-        const double t1 = (1.0 - a.omega) * ep_x;
-        const double t2 = a.omega * vD;
-        a.xout[ib + r] = t1 + t2;
+        if (BMODE == BM_BLOCK_GS) a.xout[ib + r] = vD;                  // relaxation.h:756-810: x_i = Dinv_i (b_i - rsum)
+        else {
+            const double t1 = (1.0 - a.omega) * ep_x;
+            const double t2 = a.omega * vD;
+            a.xout[ib + r] = t1 + t2;
+        }
     }
 }
 
+__global__ void bsell_remap_kernel(int nslots, const int *rowmap, int *brow)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < nslots && brow[k] >= 0) brow[k] = rowmap[brow[k]];
+}
+
 template <int BS>
-int build_bsell_bs(DevBsr &M, long *acct)
+int build_bsell_bs(DevBsr &M, long *acct, const std::vector<int> *level_ptr = nullptr, const int *rowmap_dev = nullptr,
+                   std::vector<int> *level_slice = nullptr)
 {
     constexpr int NBR = 64 / BS, WIN = BSL_WIN * NBR;
     const int nb = M.nbrows;
-    const int nwin = (nb + WIN - 1) / WIN;
+    std::vector<int> ws, wl;
+    if (level_ptr) {
+        const int nl = (int)level_ptr->size() - 1;
+        level_slice->assign((size_t)nl + 1, 0);
+        for (int l = 0; l < nl; ++l) {
+            (*level_slice)[(size_t)l] = (int)ws.size() * BSL_WIN;
+            for (int w0 = (*level_ptr)[(size_t)l]; w0 < (*level_ptr)[(size_t)l + 1]; w0 += WIN) {
+                ws.push_back(w0);
+                wl.push_back(std::min(WIN, (*level_ptr)[(size_t)l + 1] - w0));
+            }
+        }
+        (*level_slice)[(size_t)nl] = (int)ws.size() * BSL_WIN;
+    }
+    const int nwin = level_ptr ? (int)ws.size() : (nb + WIN - 1) / WIN;
     const int nslices = nwin * BSL_WIN;
+    int *ws_dev = nullptr, *wl_dev = nullptr;
+    if (level_ptr && nwin > 0) {
+        AMG_HIP(hipMalloc((void **)&ws_dev, sizeof(int) * (size_t)nwin));
+        AMG_HIP(hipMalloc((void **)&wl_dev, sizeof(int) * (size_t)nwin));
+        AMG_HIP(hipMemcpy(ws_dev, ws.data(), sizeof(int) * (size_t)nwin, hipMemcpyHostToDevice));
+        AMG_HIP(hipMemcpy(wl_dev, wl.data(), sizeof(int) * (size_t)nwin, hipMemcpyHostToDevice));
+    }
     {
         std::vector<int> hp((size_t)nb + 1);
         AMG_HIP(hipMemcpy(hp.data(), M.Ap, sizeof(int) * ((size_t)nb + 1), hipMemcpyDeviceToHost));
@@ -458,7 +494,7 @@ int build_bsell_bs(DevBsr &M, long *acct)
     AMG_HIP(hipMalloc((void **)&brow, sizeof(int) * (size_t)nslices * NBR));
     AMG_HIP(hipMalloc((void **)&blen, sizeof(unsigned short) * (size_t)nslices * NBR));
     AMG_HIP(hipMalloc((void **)&w_dev, sizeof(int) * (size_t)nslices));
-    hipLaunchKernelGGL((bsell_sort_kernel<NBR>), dim3(nwin), dim3(1024), 0, nullptr, nb, M.Ap, brow, blen, w_dev);
+    hipLaunchKernelGGL((bsell_sort_kernel<NBR>), dim3(nwin), dim3(1024), 0, nullptr, nb, M.Ap, brow, blen, w_dev, (const int *)ws_dev, (const int *)wl_dev);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "bsell sort launch", __FILE__, __LINE__);
     std::vector<int> hw((size_t)nslices);
@@ -468,7 +504,8 @@ int build_bsell_bs(DevBsr &M, long *acct)
     off[0] = 0;
     for (int s = 0; s < nslices; ++s) off[(size_t)s + 1] = off[(size_t)s] + hw[(size_t)s];
     const long cols = off[(size_t)nslices];                          // block slot columns
-    if ((double)cols * NBR > 1.15 * (double)M.nblocks) { hipFree(brow); hipFree(blen); return 0; }
+    if (ws_dev) { hipFree(ws_dev); hipFree(wl_dev); }
+    if ((double)cols * NBR > (level_ptr ? 1.3 : 1.15) * (double)M.nblocks) { hipFree(brow); hipFree(blen); return 0; }
     long *off_dev = nullptr; int *col = nullptr; double *val = nullptr;
     AMG_HIP(hipMalloc((void **)&off_dev, sizeof(long) * ((size_t)nslices + 1)));
     AMG_HIP(hipMalloc((void **)&col, sizeof(int) * (size_t)std::max(cols * NBR, 1L)));
@@ -477,6 +514,10 @@ int build_bsell_bs(DevBsr &M, long *acct)
     hipLaunchKernelGGL((bsell_fill_kernel<BS>), dim3((nslices + 3) / 4), dim3(256), 0, nullptr, nslices, M.Ap, M.Aj, M.Ax, brow, blen, off_dev, col, val);
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "bsell fill launch", __FILE__, __LINE__);
+    if (rowmap_dev) {                                                // x / b / Dinv are indexed by the ORIGINAL block row
+        const int nslots = nslices * NBR;
+        hipLaunchKernelGGL(bsell_remap_kernel, dim3((nslots + 255) / 256), dim3(256), 0, nullptr, nslots, rowmap_dev, brow);
+    }
     AMG_HIP(hipDeviceSynchronize());
     M.bsl_brow = brow; M.bsl_len = blen; M.bsl_off = off_dev; M.bsl_col = col; M.bsl_val = val; M.bsl_nslices = nslices;
     if (acct) *acct += (long)(6L * nslices * NBR + 8L * (nslices + 1) + 4L * cols * NBR + 8L * cols * BS * NBR * BS);
@@ -506,6 +547,42 @@ int build_bsell(DevBsr &M, long *acct)
     return 0;
 }
 
+// the level-ordered copy of a block Gauss-Seidel schedule: slices cut at the level boundaries; level l is slices
+// level_slice[l] .. level_slice[l+1]
+int build_bsell_levels(DevBsr &M, const std::vector<int> &level_ptr, const int *rowmap_dev, std::vector<int> &level_slice, long *acct)
+{
+    const char *env = std::getenv("AMG_SELL");
+    level_slice.clear();
+    if (env && std::atoi(env) == 0) return 0;
+    if (M.nbrows < (1 << 15) || M.nblocks < 4L * M.nbrows || M.nblocks > 48L * M.nbrows || !M.Ap) return 0;
+    // only levels of thousands of block rows: a level of 2 500 block rows (C5 at 150^3) is a launch of 30 workgroups that
+    // the streamed kernel finishes in 4.8 us -- measured 20 % slower from slices; AMG_SELL_LEVELS=1 forces it (tests)
+    const char *force = std::getenv("AMG_SELL_LEVELS");
+    if (!(force && std::atoi(force) == 1) && (long)(level_ptr.size() - 1) * 8192L > (long)M.nbrows) return 0;
+    int rc = 0;
+    if (M.bs == 3) rc = build_bsell_bs<3>(M, acct, &level_ptr, rowmap_dev, &level_slice);
+    else if (M.bs == 2) rc = build_bsell_bs<2>(M, acct, &level_ptr, rowmap_dev, &level_slice);
+    if (!M.bsl_val) level_slice.clear();
+    return rc;
+}
+
+int launch_bsell_level(const DevBsr &M, BlockMode m, const BsrStreamArgs &a, int slice_lo, int slice_hi, hipStream_t st)
+{
+    if (slice_hi <= slice_lo) return 0;
+    BsellArgs S{M.bsl_brow, M.bsl_len, M.bsl_off, M.bsl_col, M.bsl_val, M.bsl_nslices};
+    const int n = slice_hi - slice_lo;
+    const int grid = (n + 3) / 4;
+    if (m != BM_BLOCK_GS) { set_error("launch_bsell_level: block Gauss-Seidel only"); return -1; }
+    if (M.bs == 3) hipLaunchKernelGGL((bsell_kernel<BM_BLOCK_GS, 3>), dim3(grid), dim3(256), 0, st, a, S, 0, slice_lo, n);
+    else if (M.bs == 2) hipLaunchKernelGGL((bsell_kernel<BM_BLOCK_GS, 2>), dim3(grid), dim3(256), 0, st, a, S, 0, slice_lo, n);
+    else { set_error("launch_bsell_level: block size not supported"); return -1; }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "bsell level launch", __FILE__, __LINE__);
+    return 0;
+}
+
+bool bsell_level_enabled() { return g_sell != 0; }
+
 bool bsell_applies(const DevBsr &M, BlockMode m, const BsrStreamArgs &a)
 {
     if (!M.bsl_val || !g_sell || a.rowmap || a.brow_lo != 0 || a.brow_hi != M.nbrows || a.Aj != M.Aj) return false;
@@ -519,10 +596,10 @@ int launch_bsell(const DevBsr &M, BlockMode m, const BsrStreamArgs &a, hipStream
     BsellArgs S{M.bsl_brow, M.bsl_len, M.bsl_off, M.bsl_col, M.bsl_val, M.bsl_nslices};
     const int grid = (M.bsl_nslices + 3) / 4;
     const int chunk = grid >= 4096 ? 32 : 0;
-    if (M.bs == 3 && m == BM_SPMV) hipLaunchKernelGGL((bsell_kernel<BM_SPMV, 3>), dim3(grid), dim3(256), 0, st, a, S, chunk);
-    else if (M.bs == 3) hipLaunchKernelGGL((bsell_kernel<BM_BLOCK_JACOBI, 3>), dim3(grid), dim3(256), 0, st, a, S, chunk);
-    else if (M.bs == 2 && m == BM_SPMV) hipLaunchKernelGGL((bsell_kernel<BM_SPMV, 2>), dim3(grid), dim3(256), 0, st, a, S, chunk);
-    else if (M.bs == 2) hipLaunchKernelGGL((bsell_kernel<BM_BLOCK_JACOBI, 2>), dim3(grid), dim3(256), 0, st, a, S, chunk);
+    if (M.bs == 3 && m == BM_SPMV) hipLaunchKernelGGL((bsell_kernel<BM_SPMV, 3>), dim3(grid), dim3(256), 0, st, a, S, chunk, 0, M.bsl_nslices);
+    else if (M.bs == 3) hipLaunchKernelGGL((bsell_kernel<BM_BLOCK_JACOBI, 3>), dim3(grid), dim3(256), 0, st, a, S, chunk, 0, M.bsl_nslices);
+    else if (M.bs == 2 && m == BM_SPMV) hipLaunchKernelGGL((bsell_kernel<BM_SPMV, 2>), dim3(grid), dim3(256), 0, st, a, S, chunk, 0, M.bsl_nslices);
+    else if (M.bs == 2) hipLaunchKernelGGL((bsell_kernel<BM_BLOCK_JACOBI, 2>), dim3(grid), dim3(256), 0, st, a, S, chunk, 0, M.bsl_nslices);
     else { set_error("launch_bsell: block size not supported"); return -1; }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "bsell launch", __FILE__, __LINE__);

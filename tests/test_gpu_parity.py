@@ -1477,22 +1477,25 @@ def test_sliced_form_same_bits_as_csr():
 
 
 @pytest.mark.gpu
-def test_sliced_block_form_same_bits_as_block_stream():
+def test_sliced_block_form_same_bits_as_block_stream(monkeypatch):
     """BSR(3,3) and BSR(2,2) level operators of 2^15 and more block rows run their whole passes -- r = b - A x from the
-    blocks, block Jacobi sweeps -- from the sliced block form (one lane per scalar row): same iterates and residual
+    blocks, block Jacobi sweeps, the dependency levels of block Gauss-Seidel sweeps -- from the sliced block form (one lane
+    per scalar row): same iterates and residual
     histories as bsr_stream_kernel, bit for bit, on the C5-shaped tet-mesh operator (irregular block rows) and a 2x2
     elasticity-like operator"""
     from pyamg_amd import _lib
     from pyamg_amd.aggregation import poisson as native, smoothed_aggregation_solver
     from pyamg_amd.gallery import tet_diffusion
     L = _lib.lib()
+    monkeypatch.setenv("AMG_SELL_LEVELS", "1")      # Gauss-Seidel levels from slices also at this size (default: >= 8192 block rows per level)
     rng = np.random.RandomState(4)
     A3 = tet_diffusion(51, blocksize=3)                                   # 44 217 block rows
     M2 = np.array([[2.0, -0.5], [-0.5, 1.5]])
     A2 = sps.kron(native((36, 35, 33)), M2).tobsr((2, 2)); A2.sort_indices()        # 41 580 block rows
     try:
-        for A, bs in ((A3, 3), (A2, 2)):
-            sm = ("block_jacobi", {"omega": 0.6, "blocksize": bs})
+        for A, bs, sm in ((A3, 3, ("block_jacobi", {"omega": 0.6, "blocksize": 3})), (A2, 2, ("block_jacobi", {"omega": 0.6, "blocksize": 2})),
+                          (A3, 3, ("block_gauss_seidel", {"sweep": "symmetric", "blocksize": 3})),
+                          (A2, 2, ("block_gauss_seidel", {"sweep": "forward", "blocksize": 2}))):
             np.random.seed(3)
             ml = smoothed_aggregation_solver(A, presmoother=sm, postsmoother=sm, max_levels=3)
             b = rng.rand(A.shape[0])
