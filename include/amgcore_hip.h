@@ -393,6 +393,9 @@ void amg_set_sell_form(int on);
  * two levels ahead; 1 operands gathered back from L2 after each barrier (also what index lists and partitioned
  * levels use); 0: one launch per level.  Same bits. */
 void amg_set_gs_chain(int on);
+/* levels too wide for a chain, one launch each: 1 (default) the launch's workgroups get their entry ranges in the kernel
+ * arguments (gs_level_kernel: two memory round trips per launch), 0 the general stream kernel (three) */
+void amg_set_gs_level_hint(int on);
 /* A of a BSR(bs,bs) level can be applied straight from its blocks (8 B per entry + 4 B per block) instead
  * of from the CSR expansion (12 B per entry); same summation order, same bits.  0: never, 1 (default):
  * for blocks of 3x3 and larger (where it is measured faster), 2: always */

@@ -208,6 +208,8 @@ def lib():
     L.amg_set_bsr_spmv.restype = None
     L.amg_set_gs_chain.argtypes = [I]
     L.amg_set_gs_chain.restype = None
+    L.amg_set_gs_level_hint.argtypes = [I]
+    L.amg_set_gs_level_hint.restype = None
     L.amg_set_stencil_form.argtypes = [I]
     L.amg_set_stencil_form.restype = None
     L.amg_set_stencil_pairs.argtypes = [I]

@@ -191,6 +191,16 @@ int launch_perm_scatter(const int *rowmap, const double *xp, double *x, int n, h
 int launch_gs_chain2(const int *lp, const double *val, const int *code, const int *off, double *dummy, int pf,
                      int l_first, int nlevels, int width, bool reverse, bool bsr1, double *x, const double *bd, int nzero, hipStream_t st);
 int gs_chain_max_rows();
+// runs of levels with few but long rows (SA coarse levels): entry-parallel products through LDS, one workgroup
+// of `width` (128 / 256 / 512) threads; a level holds at most `width` rows and width * gs_chainl_entries_per_lane() entries
+int launch_gs_chain_long(const DevCsr &G, const int *rowmap, const int *diagpos, const int *level_ptr_dev, int l_first,
+                         int nlevels, int width, bool reverse, bool bsr1, double *x, const double *b, hipStream_t st);
+// one dependency level by a launch of its own: with the level-ordered copy's row pointers on the host the entry
+// ranges travel in the kernel arguments (two memory round trips instead of three); falls back to launch_stream
+int launch_gs_level(const StreamArgs &a, bool bsr1, const int *gp_host, hipStream_t st);
+void set_gs_level_hint(int on);
+int gs_chainl_max_rows();
+int gs_chainl_entries_per_lane();
 bool gs_chain_enabled();
 int gs_chain_generation();
 void set_gs_chain(int on);

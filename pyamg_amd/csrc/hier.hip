@@ -484,6 +484,7 @@ int build_csr_schedule(const int *Ap, const int *Aj, const double *Ax, int n, co
         dpos[k] = d;
     }
     CHK(upload_csr(S.G, ntasks, n, gp.data(), gj.data(), gx.data(), nullptr));
+    S.gp_host = gp;
     CHK(dev_alloc(&S.rowmap, ntasks, (long *)nullptr));
     CHK(dev_alloc(&S.diagpos, ntasks, (long *)nullptr));
     AMG_HIP(hipMemcpy(S.rowmap, rowmap.data(), sizeof(int) * (size_t)ntasks, hipMemcpyHostToDevice));
@@ -542,13 +543,61 @@ int build_csr_schedule(const int *Ap, const int *Aj, const double *Ax, int n, co
         }
         l = e;
     }
+    // Operators with LONG rows (coarse levels of a smoothed-aggregation hierarchy: 30-60 entries per row, a dozen to a
+    // few hundred rows per dependency level, hundreds of levels): runs of levels that fit one workgroup entry-parallel
+    // (gs_chainl_kernel).  Pieces of one workgroup size each (128 / 256 / 512 threads by the widest level's rows and
+    // entries), pieces under 8 levels join a neighbour.
+    S.chain_long = false;
+    if (!short_rows && ntasks > 0 && gs_chain_max_rows() > 0) {
+        const int KE = gs_chainl_entries_per_lane(), WMAX = gs_chainl_max_rows();
+        auto need = [&](int q) {                                            // threads level q needs (> WMAX: not chained)
+            const int r = S.level_ptr[q + 1] - S.level_ptr[q];
+            const long e = (long)gp[(size_t)S.level_ptr[q + 1]] - gp[(size_t)S.level_ptr[q]];
+            const long w = std::max<long>(r, (e + KE - 1) / KE);
+            return w <= 128 ? 128 : (w <= 256 ? 256 : (w <= WMAX ? 512 : WMAX + 1));
+        };
+        for (int l = 0; l < nl;) {
+            if (need(l) > WMAX) { ++l; continue; }
+            int e = l;
+            while (e < nl && need(e) <= WMAX) ++e;
+            if (e - l >= 4) {
+                std::vector<std::array<int, 3>> pc;                          // first, last + 1, class
+                for (int q = l; q < e; ++q) {
+                    const int c = need(q);
+                    if (!pc.empty() && pc.back()[2] == c) pc.back()[1] = q + 1;
+                    else pc.push_back({q, q + 1, c});
+                }
+                for (bool merged = true; merged && pc.size() > 1;) {
+                    merged = false;
+                    for (size_t k = 0; k < pc.size(); ++k) {
+                        if (pc[k][1] - pc[k][0] >= 8) continue;
+                        const size_t j = (k == 0) ? 1 : ((k + 1 == pc.size()) ? k - 1 : (pc[k - 1][2] <= pc[k + 1][2] ? k - 1 : k + 1));
+                        const size_t a0 = std::min(j, k), a1 = std::max(j, k);
+                        pc[a0] = {pc[a0][0], pc[a1][1], std::max(pc[a0][2], pc[a1][2])};
+                        pc.erase(pc.begin() + (long)a1);
+                        merged = true;
+                        break;
+                    }
+                    for (size_t k = 0; k + 1 < pc.size();)
+                        if (pc[k][2] == pc[k + 1][2]) { pc[k][1] = pc[k + 1][1]; pc.erase(pc.begin() + (long)k + 1); merged = true; }
+                        else ++k;
+                }
+                for (const auto &q : pc) {
+                    S.chains.emplace_back(q[0], q[1]);
+                    S.chain_width.push_back(q[2]);
+                }
+                S.chain_long = true;
+            }
+            l = e;
+        }
+    }
     // ---- the chained sweep's padded copy (Schedule::c2_*, gs_chain2_kernel)
     S.chain2 = false;
     S.perm = false;
     // The second-generation chain runs in LEVEL-ORDER numbering (unknown k = the k-th row of the schedule), which
     // needs the schedule to be a permutation of the unknowns of a square operator: every row listed exactly once and
     // no column outside (a partitioned level's halo columns are).
-    bool permutation = !S.chains.empty() && max_rows <= CHAIN2_WG && ntasks == n;
+    bool permutation = !S.chains.empty() && !S.chain_long && max_rows <= CHAIN2_WG && ntasks == n;
     for (size_t q = 0; permutation && q < gj.size(); ++q) permutation = gj[q] >= 0 && gj[q] < n;
     if (permutation) {
         std::vector<int> lvl_of((size_t)n, -1), pos_of((size_t)n, -1), piece_of((size_t)nl, -1), inv((size_t)n, -1);
@@ -770,7 +819,7 @@ int gs_sweep_csr(const Schedule &S, bool bsr1, double *x, const double *b, const
                 const int l = reverse ? l1 - 1 - q : l0 + q;
                 a.row_lo = S.level_ptr[l];
                 a.row_hi = S.level_ptr[l + 1];
-                CHK(launch_stream(bsr1 ? SM_GS_BSR1 : SM_GS, a, st));
+                CHK(launch_gs_level(a, bsr1, S.gp_host.empty() ? nullptr : S.gp_host.data(), st));
             }
             return 0;
         };
@@ -786,6 +835,8 @@ int gs_sweep_csr(const Schedule &S, bool bsr1, double *x, const double *b, const
             if (perm)
                 CHK(launch_gs_chain2(S.level_ptr_dev, S.c2_val, reverse ? S.c2_code_b : S.c2_code_f, S.c2_off, S.c2_dummy, S.c2_pf,
                                      ch.first, ch.second - ch.first, width, reverse, bsr1, xs, S.bd, S.ntasks, st));
+            else if (S.chain_long)
+                CHK(launch_gs_chain_long(G, rowmap, S.diagpos, S.level_ptr_dev, ch.first, ch.second - ch.first, width, reverse, bsr1, xs, bs, st));
             else
                 CHK(launch_gs_chain(G, rowmap, S.diagpos, S.level_ptr_dev, ch.first, ch.second - ch.first, width, reverse, bsr1, xs, bs, st));
         }
@@ -2476,6 +2527,7 @@ void amg_set_stencil_form(int on) { amg::set_stencil_form(on); }
 void amg_set_stencil_pairs(int on) { amg::set_stencil_pairs(on); }
 void amg_set_sell_form(int on) { amg::set_sell_form(on); }
 void amg_set_gs_chain(int on) { amg::set_gs_chain(on); }
+void amg_set_gs_level_hint(int on) { amg::set_gs_level_hint(on); }
 void amg_set_bsr_spmv(int on) { amg::set_bsr_spmv(on); }
 void amg_set_index16(int on) { amg::set_index16(on); }
 void amg_set_tile_target(int t) { amg::set_tile_target(t); }

@@ -32,6 +32,8 @@ struct Schedule {
     // per row, and for every entry an operand CODE per sweep direction: >= 0 the operand's level-order position (it is
     // final in memory long before it is needed and is prefetched), < 0 a slot of the workgroup's LDS ring (the
     // operand was produced by one of the last CHAIN2_D levels of this very launch).
+    std::vector<int> gp_host;          // row pointers of G on the host: a level launch gets its workgroups' entry ranges as kernel arguments
+    bool chain_long = false;           // the chains are runs of levels with few but LONG rows: gs_chainl_kernel (entry-parallel, products through LDS)
     bool chain2 = false;
     int c2_pf = 0;                 // slots per row of the copy: 4, 8 or 12
     int *c2_code_f = nullptr, *c2_code_b = nullptr, *c2_off = nullptr;

@@ -993,6 +993,139 @@ int launch_gs_chain(const DevCsr &G, const int *rowmap, const int *diagpos, cons
 }
 
 // ---------------------------------------------------------------------------
+// Chained Gauss-Seidel sweep for runs of dependency levels with FEW BUT LONG rows (the coarse levels of a
+// smoothed-aggregation hierarchy: a dozen rows of 30-60 entries per level, hundreds of levels per sweep -- each
+// was a launch of ~5 us: three dependent memory round trips for a few hundred entries).  One workgroup, one launch;
+// a level is handled the way csr_stream_kernel does it -- entry-parallel products into LDS, then one lane per row
+// sums ITS products left to right (same order, same bits) -- but everything that does not depend on x (the level's
+// entries, row bounds, diagonal, right-hand side) was requested one or two levels earlier, so the critical path of a
+// level is gather x (L2) -> products -> barrier -> row sums from LDS -> store -> barrier.
+// A level takes at most WGS rows and WGS * CHAINL_KE entries.
+// ---------------------------------------------------------------------------
+constexpr int CHAINL_KE = 8;          // entries per lane and level
+constexpr int CHAINL_LMAX = 1024;     // levels per launch (row and entry offsets in LDS)
+constexpr int CHAINL_WG = 512;
+
+// Written like gs_chain2_kernel: every request unconditional (idle lanes and the steps past the last level re-read a
+// valid row / entry and drop it) and the stage buffers rotated by residue, never moved -- so that the compiler's wait
+// counts stay exact and a level waits for ITS gathers only, not for the requests of the levels ahead.
+template <bool BSR1, int WGS>
+__global__ __launch_bounds__(WGS) void gs_chainl_kernel(const int *Ap, const int *Aj, const double *Ax, const int *rowmap,
+                                                            const int *diagpos, double *x, const double *b,
+                                                            const int *lp, int l_first, int nl, int reverse)
+{
+    constexpr int KE = CHAINL_KE;
+    const int t = threadIdx.x;
+    __shared__ int slp[CHAINL_LMAX + 1];          // first row (position in the level-ordered copy) of each level
+    __shared__ int sep[CHAINL_LMAX + 1];          // its first entry
+    __shared__ double prod[WGS * KE];
+    for (int k = t; k <= nl; k += WGS) {
+        const int p = lp[l_first + k];
+        slp[k] = p;
+        sep[k] = Ap[p];
+    }
+    __syncthreads();
+    auto level_of = [&](int q) { q = min(q, nl - 1); return reverse ? nl - 1 - q : q; };
+
+    struct Ent { int c[KE]; double v[KE]; };
+    struct Row { int s, e, row, dp, base; bool live; double bb, d; };
+    auto entries = [&](int q, Ent &E) {            // the level's entries, lane-strided; lanes past the end re-read the last one
+        const int l = level_of(q);
+        const int e0 = sep[l], last = sep[l + 1] - e0 - 1;                 // >= 0: a chained level has entries
+#pragma unroll
+        for (int u = 0; u < KE; ++u) {
+            const int k = e0 + min(t + u * WGS, last);
+            E.c[u] = Aj[k];
+            E.v[u] = Ax[k];
+        }
+    };
+    auto row_a = [&](int q, Row &R) {              // row bounds, row number, diagonal position
+        const int l = level_of(q);
+        const int cnt = slp[l + 1] - slp[l];                                // >= 1
+        const int p = slp[l] + min(t, cnt - 1);
+        R.live = (q < nl) && (t < cnt);
+        R.base = sep[l];
+        R.s = Ap[p]; R.e = Ap[p + 1]; R.row = rowmap ? rowmap[p] : p; R.dp = diagpos[p];
+    };
+    auto row_b = [&](Row &R) {                     // right-hand side and diagonal (need row_a's answers)
+        R.bb = b[R.row];
+        const double d = Ax[max(R.dp, 0)];
+        R.d = (R.dp >= 0) ? d : 0.0;
+    };
+    auto step = [&](int q, const Ent &E, Ent &fillE, const Row &R, Row &nextR, Row &fillR) {
+        // 1. the operands of this level's entries first; 2. requests for the levels ahead (nothing below waits for them)
+        double xv[KE];
+#pragma unroll
+        for (int u = 0; u < KE; ++u) xv[u] = load_fresh(&x[E.c[u]]);
+        entries(q + 2, fillE);
+        row_b(nextR);
+        row_a(q + 2, fillR);
+        // 3. products, entry k of the level at prod[k] (lanes past the end write a slot nobody reads)
+#pragma unroll
+        for (int u = 0; u < KE; ++u) prod[t + u * WGS] = E.v[u] * xv[u];
+        __syncthreads();
+        // 4. one lane per row: the sum in stored order, diagonal skipped (reads batched: one wait per 8)
+        if (R.live) {
+            double acc = BSR1 ? R.bb : 0.0;
+            for (int k = R.s; k < R.e; k += 8) {
+                double pr[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pr[j] = (k + j < R.e) ? prod[k + j - R.base] : 0.0;
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (k + j < R.e && k + j != R.dp) acc = BSR1 ? (acc - pr[j]) : (acc + pr[j]);
+            }
+            if (R.d != 0.0) x[R.row] = BSR1 ? (acc / R.d) : ((R.bb - acc) / R.d);
+        }
+        // one workgroup = one CU: the store is ordered before the next level's gathers (they bypass L1: load_fresh) by the barrier
+        __syncthreads();
+    };
+
+    Ent eb[3];
+    Row rb[3];
+    entries(0, eb[0]);
+    entries(1, eb[1]);
+    row_a(0, rb[0]);
+    row_a(1, rb[1]);
+    row_b(rb[0]);
+    // (the compiler drains every outstanding request at the loop's back edge: four rotations per trip make that one
+    // drain per 12 levels; steps past the last level run on idle lanes only)
+    for (int q = 0; q < nl; q += 12) {
+#pragma unroll
+        for (int r = 0; r < 12; r += 3) {
+            step(q + r, eb[0], eb[2], rb[0], rb[1], rb[2]);
+            step(q + r + 1, eb[1], eb[0], rb[1], rb[2], rb[0]);
+            step(q + r + 2, eb[2], eb[1], rb[2], rb[0], rb[1]);
+        }
+    }
+}
+
+int gs_chainl_max_rows() { return CHAINL_WG; }
+int gs_chainl_entries_per_lane() { return CHAINL_KE; }
+
+int launch_gs_chain_long(const DevCsr &G, const int *rowmap, const int *diagpos, const int *level_ptr_dev, int l_first,
+                         int nlevels, int width, bool reverse, bool bsr1, double *x, const double *b, hipStream_t st)
+{
+    if (nlevels <= 0) return 0;
+    if (width != 128 && width != 256 && width != 512) { set_error("gs_chain_long: workgroup size not instantiated"); return -4; }
+    const int npiece = (nlevels + CHAINL_LMAX - 1) / CHAINL_LMAX;
+    for (int c = 0; c < npiece; ++c) {
+        const int piece = reverse ? npiece - 1 - c : c;
+        const int lf = l_first + piece * CHAINL_LMAX;
+        const int cnt = std::min(CHAINL_LMAX, nlevels - piece * CHAINL_LMAX);
+#define CL_LAUNCH(B, W) hipLaunchKernelGGL((gs_chainl_kernel<B, W>), dim3(1), dim3(W), 0, st, G.Ap, G.Aj, G.Ax, rowmap, diagpos, x, b, \
+                                           level_ptr_dev, lf, cnt, reverse ? 1 : 0)
+#define CL_WIDTH(B) do { if (width == 128) CL_LAUNCH(B, 128); else if (width == 256) CL_LAUNCH(B, 256); else CL_LAUNCH(B, 512); } while (0)
+        if (bsr1) CL_WIDTH(true); else CL_WIDTH(false);
+#undef CL_WIDTH
+#undef CL_LAUNCH
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "gs long-row chain launch", __FILE__, __LINE__);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
 // csr_pattern: the same operator application for matrices whose rows repeat a few column-offset
 // patterns (stencil operators: 27 patterns for a 7-point grid operator with boundaries).  Only the
 // values are streamed (8 B per entry, 16-byte loads through the same LDS tile); a row's columns
@@ -1847,6 +1980,117 @@ static int launch_stream_mode(const StreamArgs &a, hipStream_t st)
         hipLaunchKernelGGL((csr_stream_kernel<MODE, 0>), dim3(nb), dim3(WG), 0, st, b, g_xcd_chunk, rpb);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "csr_stream launch", __FILE__, __LINE__);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// One dependency level of a scheduled Gauss-Seidel sweep, at most GS_LEVEL_MAXWG workgroups: the launch-per-level
+// path of levels too wide for a chain.  Such a launch is pure latency (a few thousand rows, ~5 us in
+// csr_stream_kernel: row pointers -> entries -> gathered operands, three dependent round trips).  Here every
+// workgroup's first and last entry position arrive in the KERNEL ARGUMENTS (the host knows the level-ordered copy's row
+// pointers), so the entries are requested at once, beside the row pointers, row numbers and diagonal positions:
+// two round trips.  Same tile, same left-to-right row sums as csr_stream_kernel<SM_GS / SM_GS_BSR1>.
+// ---------------------------------------------------------------------------
+constexpr int GS_LEVEL_MAXWG = 64;
+struct LevelEntries { int e[GS_LEVEL_MAXWG + 1]; };
+
+template <bool BSR1>
+__global__ __launch_bounds__(WG) void gs_level_kernel(StreamArgs a, LevelEntries H, int rpb)
+{
+    __shared__ double sp[TILE];
+    const int t = threadIdx.x;
+    const int blk = blockIdx.x;
+    const int r0 = a.row_lo + blk * rpb;
+    const int nr = min(rpb, a.row_hi - r0);
+    const int kbeg = H.e[blk], kend = H.e[blk + 1];
+    constexpr int U = TILE / WG;
+    // first tile's entries, then the row's own data (neither depends on the other)
+    int c[U];
+    double v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int k = kbeg + u * WG + t;
+        const bool ok = k < kend;
+        c[u] = ok ? a.Aj[k] : 0;
+        v[u] = ok ? a.Ax[k] : 0.0;
+    }
+    int my_s = kend, my_e = kend, row = r0 + t, dpos = -1;
+    if (t < nr) {
+        my_s = a.Ap[r0 + t];
+        my_e = a.Ap[r0 + t + 1];
+        if (a.rowmap) row = a.rowmap[r0 + t];
+        dpos = a.diagpos[r0 + t];
+    }
+    double gs_d = 0.0, gs_b = 0.0;
+    double acc = 0.0;
+    for (int tile_lo = kbeg; tile_lo < kend; tile_lo += TILE) {
+        const int tile_hi = min(tile_lo + TILE, kend);
+        if (tile_lo != kbeg) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int k = tile_lo + u * WG + t;
+                const bool ok = k < tile_hi;
+                c[u] = ok ? a.Aj[k] : 0;
+                v[u] = ok ? a.Ax[k] : 0.0;
+            }
+        }
+        double xv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) xv[u] = a.xg[c[u]];
+        if (tile_lo == kbeg && t < nr) {              // second round trip, beside the gathers
+            gs_d = (dpos >= 0) ? a.Ax[dpos] : 0.0;
+            gs_b = a.b[row];
+            if (BSR1) acc = gs_b;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) sp[u * WG + t] = v[u] * xv[u];
+        __syncthreads();
+        {
+            const int s = max(my_s, tile_lo), e2 = min(my_e, tile_hi);
+            constexpr int RB = AMG_ROWSUM_BATCH;
+            for (int k = s; k < e2; k += RB) {
+                double p[RB];
+#pragma unroll
+                for (int u = 0; u < RB; ++u) p[u] = sp[min(k + u, e2 - 1) - tile_lo];
+#pragma unroll
+                for (int u = 0; u < RB; ++u) {
+                    const bool take = (k + u < e2) && (k + u != dpos);
+                    const double nxt = BSR1 ? (acc - p[u]) : (acc + p[u]);
+                    acc = take ? nxt : acc;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (t >= nr) return;
+    if (kbeg >= kend) {                                // a workgroup of empty rows never entered the loop
+        gs_d = (dpos >= 0) ? a.Ax[dpos] : 0.0;
+        gs_b = a.b[row];
+        if (BSR1) acc = gs_b;
+    }
+    if (gs_d != 0.0) a.out[row] = BSR1 ? (acc / gs_d) : ((gs_b - acc) / gs_d);
+}
+
+static int g_gs_level_hint = 1;
+void set_gs_level_hint(int on) { g_gs_level_hint = on; ++g_config_epoch; }
+
+// gp_host: the row pointers of the launch's operator on the host (Schedule::gp_host), or null
+int launch_gs_level(const StreamArgs &a, bool bsr1, const int *gp_host, hipStream_t st)
+{
+    const int rows = a.row_hi - a.row_lo;
+    if (rows <= 0) return 0;
+    int rpb = a.rows_per_wg;
+    if (rpb < 1 || rpb > WG) rpb = WG;
+    const int nb = (rows + rpb - 1) / rpb;
+    if (!gp_host || !g_gs_level_hint || nb > GS_LEVEL_MAXWG || a.Aj16 != nullptr || (a.gscale != 0.0 && a.gscale != 1.0))
+        return launch_stream(bsr1 ? SM_GS_BSR1 : SM_GS, a, st);
+    LevelEntries H;
+    for (int g = 0; g <= nb; ++g) H.e[g] = gp_host[std::min(a.row_lo + g * rpb, a.row_hi)];
+    for (int g = nb + 1; g <= GS_LEVEL_MAXWG; ++g) H.e[g] = H.e[nb];
+    if (bsr1) hipLaunchKernelGGL((gs_level_kernel<true>), dim3(nb), dim3(WG), 0, st, a, H, rpb);
+    else hipLaunchKernelGGL((gs_level_kernel<false>), dim3(nb), dim3(WG), 0, st, a, H, rpb);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "gs level launch", __FILE__, __LINE__);
     return 0;
 }
 

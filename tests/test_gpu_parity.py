@@ -1188,6 +1188,71 @@ def test_chained_gauss_seidel_on_irregular_hierarchy_levels():
     assert np.array_equal(out[0], out[2])
 
 
+def test_long_row_chain_on_sa_coarse_levels():
+    """Coarse levels of a smoothed-aggregation hierarchy (rows of 30-60 entries, a dozen to a few hundred rows per
+    dependency level) are swept by gs_chainl_kernel: one workgroup per run of levels, entry-parallel products through
+    LDS, one lane per row summing in stored order.  Same bits as one launch per level and as the sequential oracle,
+    CSR and BSR(1,1) rounding, every sweep direction; a row without a diagonal entry is left untouched; and a whole
+    solve with the reference's default smoother (symmetric Gauss-Seidel) is unchanged."""
+    import ctypes as C
+    from pyamg_amd import _lib
+    from pyamg_amd.aggregation import poisson as native, smoothed_aggregation_solver
+    rng = np.random.RandomState(5)
+    sm = ("gauss_seidel", {"sweep": "symmetric"})
+    ml = smoothed_aggregation_solver(native((36, 34, 32)), presmoother=sm, postsmoother=sm, max_coarse=20)
+    mats = [sps.csr_matrix(lvl.A) for lvl in ml.levels[1:-1]]
+    assert mats and max(M.nnz / M.shape[0] for M in mats) > 20
+    Z = mats[0].tolil(); Z[5, 5] = 0.0; Z = sps.csr_matrix(Z); Z.eliminate_zeros()
+    mats.append(Z)
+    for M0 in mats:
+        n = M0.shape[0]
+        b = rng.rand(n)
+        for M in (M0, sps.bsr_matrix(M0, blocksize=(1, 1))):
+            for sweep in ("forward", "backward", "symmetric"):
+                out = {}
+                for on in (2, 0):
+                    _lib.lib().amg_set_gs_chain(on)
+                    x = np.cos(np.arange(n, dtype=float))
+                    relaxation.gauss_seidel(M, x, b, iterations=2, sweep=sweep)
+                    out[on] = x
+                _lib.lib().amg_set_gs_chain(2)
+                assert np.array_equal(out[0], out[2]), (n, type(M).__name__, sweep)
+                xo = np.cos(np.arange(n, dtype=float))
+                keep = []
+                m = oracle_lib.make_mat(M, keep)
+                s = oracle_lib.make_smoother({"name": "gauss_seidel", "iterations": 2, "sweep": sweep}, M, keep)
+                oracle_lib.load().oracle_relax(C.byref(m), C.byref(s), oracle_lib.dp(xo), oracle_lib.dp(b))
+                assert np.array_equal(out[2], xo), (n, type(M).__name__, sweep)
+    # (levels too wide for a chain are one launch each, their workgroups' entry ranges in the kernel arguments --
+    # gs_level_kernel, amg_set_gs_level_hint -- against the general stream kernel)
+    b = rng.rand(ml.levels[0].A.shape[0])
+    got = {}
+    for on, hint in ((2, 1), (0, 1), (0, 0), (2, 0)):
+        _lib.lib().amg_set_gs_chain(on)
+        _lib.lib().amg_set_gs_level_hint(hint)
+        ml._invalidate_device()
+        res = []
+        got[(on, hint)] = (ml.solve(b, tol=0.0, maxiter=4, residuals=res), list(res))
+    _lib.lib().amg_set_gs_chain(2)
+    _lib.lib().amg_set_gs_level_hint(1)
+    ml._invalidate_device()
+    for key in ((0, 1), (0, 0), (2, 0)):
+        assert np.array_equal(got[key][0], got[(2, 1)][0]) and got[key][1] == got[(2, 1)][1], key
+    # a level of long rows spanning several tiles of one workgroup, and empty rows
+    W = sps.random(600, 600, density=0.4, random_state=7, format="csr") + sps.identity(600) * 50.0
+    W = sps.csr_matrix(W); W.sort_indices()
+    Wl = W.tolil(); Wl[17, :] = 0.0; W = sps.csr_matrix(Wl); W.eliminate_zeros()
+    bw = rng.rand(600)
+    outw = {}
+    for hint in (1, 0):
+        _lib.lib().amg_set_gs_level_hint(hint)
+        x = np.sin(np.arange(600.0))
+        relaxation.gauss_seidel(W, x, bw, iterations=1, sweep="symmetric")
+        outw[hint] = x
+    _lib.lib().amg_set_gs_level_hint(1)
+    assert np.array_equal(outw[0], outw[1])
+
+
 # ---------------------------------------------------------------------------
 # device-resident Krylov methods (pyamg_amd/krylov.py): acceleration, smoothers, coarse solvers
 # ---------------------------------------------------------------------------
