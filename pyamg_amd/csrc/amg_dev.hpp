@@ -194,7 +194,9 @@ int gs_chain_max_rows();
 // runs of levels with few but long rows (SA coarse levels): entry-parallel products through LDS, one workgroup
 // of `width` (128 / 256 / 512) threads; a level holds at most `width` rows and width * gs_chainl_entries_per_lane() entries
 int launch_gs_chain_long(const DevCsr &G, const int *rowmap, const int *diagpos, const int *level_ptr_dev, int l_first,
-                         int nlevels, int width, bool reverse, bool bsr1, double *x, const double *b, hipStream_t st);
+                         int nlevels, int width, bool reverse, bool bsr1, double *x, const double *b, hipStream_t st,
+                         const int *ring_code = nullptr);      // ring_code: per-entry codes of the LDS hand-off variant (Schedule::cl_code_*)
+int gs_chainl_max_levels();
 // one dependency level by a launch of its own: with the level-ordered copy's row pointers on the host the entry
 // ranges travel in the kernel arguments (two memory round trips instead of three); falls back to launch_stream
 int launch_gs_level(const StreamArgs &a, bool bsr1, const int *gp_host, hipStream_t st);

@@ -407,7 +407,8 @@ void Schedule::release()
     if (level_ptr_dev) hipFree(level_ptr_dev);
     free_bsr(Gb);
     rowmap = diagpos = rows = level_ptr_dev = nullptr;
-    for (int *p : {c2_code_f, c2_code_b, c2_off, perm_Aj}) if (p) hipFree(p);
+    for (int *p : {c2_code_f, c2_code_b, c2_off, perm_Aj, cl_code_f, cl_code_b}) if (p) hipFree(p);
+    cl_code_f = cl_code_b = nullptr;
     for (double *p : {c2_diag, c2_val, c2_dummy, xp, bp, bd}) if (p) hipFree(p);
     c2_code_f = c2_code_b = c2_off = perm_Aj = nullptr;
     c2_diag = c2_val = c2_dummy = xp = bp = bd = nullptr;
@@ -554,7 +555,8 @@ int build_csr_schedule(const int *Ap, const int *Aj, const double *Ax, int n, co
             const int r = S.level_ptr[q + 1] - S.level_ptr[q];
             const long e = (long)gp[(size_t)S.level_ptr[q + 1]] - gp[(size_t)S.level_ptr[q]];
             const long w = std::max<long>(r, (e + KE - 1) / KE);
-            return w <= 128 ? 128 : (w <= 256 ? 256 : (w <= WMAX ? 512 : WMAX + 1));
+            if (e < 4) return WMAX + 1;                                     // (the kernel requests whole quads of entries)
+            return w <= 64 ? 64 : (w <= 128 ? 128 : (w <= 256 ? 256 : (w <= WMAX ? 512 : WMAX + 1)));
         };
         for (int l = 0; l < nl;) {
             if (need(l) > WMAX) { ++l; continue; }
@@ -582,13 +584,56 @@ int build_csr_schedule(const int *Ap, const int *Aj, const double *Ax, int n, co
                         if (pc[k][2] == pc[k + 1][2]) { pc[k][1] = pc[k + 1][1]; pc.erase(pc.begin() + (long)k + 1); merged = true; }
                         else ++k;
                 }
-                for (const auto &q : pc) {
-                    S.chains.emplace_back(q[0], q[1]);
-                    S.chain_width.push_back(q[2]);
-                }
+                for (const auto &q : pc)
+                    for (int p = q[0]; p < q[1]; p += gs_chainl_max_levels()) {      // one launch each
+                        S.chains.emplace_back(p, std::min(q[1], p + gs_chainl_max_levels()));
+                        S.chain_width.push_back(q[2]);
+                    }
                 S.chain_long = true;
             }
             l = e;
+        }
+        // LDS hand-off variant (gs_chainl2_kernel): per-entry codes -- the column, or ~(ring slot) for an operand produced
+        // one or two levels earlier in the same launch.  Needs every unknown listed exactly once, columns inside, and no
+        // zero diagonal in a chained row; otherwise the memory hand-off kernel sweeps the pieces.
+        bool ring_ok = S.chain_long && ntasks == n && gs_chain_generation() == 2;
+        std::vector<int> lvl_of, pos_of, piece_of;
+        if (ring_ok) {
+            lvl_of.assign((size_t)n, -1); pos_of.assign((size_t)n, -1); piece_of.assign((size_t)nl, -1);
+            for (int l = 0; l < nl && ring_ok; ++l)
+                for (int k = S.level_ptr[l]; k < S.level_ptr[l + 1]; ++k) {
+                    const int i = rowmap[(size_t)k];
+                    if (i < 0 || i >= n || lvl_of[(size_t)i] >= 0) { ring_ok = false; break; }
+                    lvl_of[(size_t)i] = l; pos_of[(size_t)i] = k - S.level_ptr[l];
+                }
+            for (size_t c = 0; c < S.chains.size(); ++c)
+                for (int l = S.chains[c].first; l < S.chains[c].second; ++l) piece_of[(size_t)l] = (int)c;
+        }
+        if (ring_ok) {
+            std::vector<int> cf(gj), cb(gj);                                // default: the column (read from memory)
+            const int RW = gs_chainl_max_rows();
+            for (int l = 0; l < nl && ring_ok; ++l) {
+                if (piece_of[(size_t)l] < 0) continue;
+                for (int k = S.level_ptr[l]; k < S.level_ptr[l + 1] && ring_ok; ++k) {
+                    if (dpos[(size_t)k] < 0 || gx[(size_t)dpos[(size_t)k]] == 0.0) { ring_ok = false; break; }   // a row that keeps its value
+                    for (int q = gp[(size_t)k]; q < gp[(size_t)k + 1]; ++q) {
+                        const int c = gj[(size_t)q];
+                        if (c < 0 || c >= n) { ring_ok = false; break; }
+                        const int lc = lvl_of[(size_t)c];
+                        if (piece_of[(size_t)lc] != piece_of[(size_t)l]) continue;
+                        const int dl = l - lc;                              // > 0: produced earlier in a forward sweep
+                        const int slot = (lc % 3) * RW + pos_of[(size_t)c];
+                        if (dl >= 1 && dl <= 2) cf[(size_t)q] = ~slot;
+                        if (-dl >= 1 && -dl <= 2) cb[(size_t)q] = ~slot;
+                    }
+                }
+            }
+            if (ring_ok) {
+                CHK(dev_alloc(&S.cl_code_f, (long)cf.size(), (long *)nullptr));
+                CHK(dev_alloc(&S.cl_code_b, (long)cb.size(), (long *)nullptr));
+                AMG_HIP(hipMemcpy(S.cl_code_f, cf.data(), sizeof(int) * cf.size(), hipMemcpyHostToDevice));
+                AMG_HIP(hipMemcpy(S.cl_code_b, cb.data(), sizeof(int) * cb.size(), hipMemcpyHostToDevice));
+            }
         }
     }
     // ---- the chained sweep's padded copy (Schedule::c2_*, gs_chain2_kernel)
@@ -836,7 +881,8 @@ int gs_sweep_csr(const Schedule &S, bool bsr1, double *x, const double *b, const
                 CHK(launch_gs_chain2(S.level_ptr_dev, S.c2_val, reverse ? S.c2_code_b : S.c2_code_f, S.c2_off, S.c2_dummy, S.c2_pf,
                                      ch.first, ch.second - ch.first, width, reverse, bsr1, xs, S.bd, S.ntasks, st));
             else if (S.chain_long)
-                CHK(launch_gs_chain_long(G, rowmap, S.diagpos, S.level_ptr_dev, ch.first, ch.second - ch.first, width, reverse, bsr1, xs, bs, st));
+                CHK(launch_gs_chain_long(G, rowmap, S.diagpos, S.level_ptr_dev, ch.first, ch.second - ch.first, width, reverse, bsr1, xs, bs, st,
+                                         gs_chain_generation() == 2 ? (reverse ? S.cl_code_b : S.cl_code_f) : nullptr));
             else
                 CHK(launch_gs_chain(G, rowmap, S.diagpos, S.level_ptr_dev, ch.first, ch.second - ch.first, width, reverse, bsr1, xs, bs, st));
         }

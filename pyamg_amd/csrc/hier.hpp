@@ -33,6 +33,7 @@ struct Schedule {
     // final in memory long before it is needed and is prefetched), < 0 a slot of the workgroup's LDS ring (the
     // operand was produced by one of the last CHAIN2_D levels of this very launch).
     std::vector<int> gp_host;          // row pointers of G on the host: a level launch gets its workgroups' entry ranges as kernel arguments
+    int *cl_code_f = nullptr, *cl_code_b = nullptr;   // long-row chain with LDS hand-off: per entry of G the column, or ~(ring slot); forward / backward sweep
     bool chain_long = false;           // the chains are runs of levels with few but LONG rows: gs_chainl_kernel (entry-parallel, products through LDS)
     bool chain2 = false;
     int c2_pf = 0;                 // slots per row of the copy: 4, 8 or 12

@@ -1100,13 +1100,163 @@ __global__ __launch_bounds__(WGS) void gs_chainl_kernel(const int *Ap, const int
     }
 }
 
+// ---------------------------------------------------------------------------
+// The same sweep with the hand-off through LDS (what gs_chain2_kernel is to gs_chain_kernel).  Handing a level's new
+// values to the next level through memory costs ~2 us per level (store to L2, gather back from L2): 3.6 us per level
+// measured for gs_chainl_kernel on 14 rows x 59 entries.  Here a level's new values also go to an LDS ring (3 levels x
+// 512), every entry carries a CODE precomputed on the host -- its column, or ~(ring slot) when its operand is produced
+// one or two levels earlier in the same launch -- and an operand that is read from memory is final there at least
+// two levels before it is needed, so it is requested two levels ahead together with the entry's value (codes four
+// levels ahead): nothing on a level's critical path touches memory.
+//   step q : ring reads + products -> LDS -> barrier -> row sums (one lane per row, stored order) -> x, ring -> barrier
+// Needs every unknown listed once and no zero diagonal in a chained row (declined on the host otherwise).
+// ---------------------------------------------------------------------------
+// 16-byte requests at 4-byte alignment (a level's first entry sits anywhere in the copy)
+struct __attribute__((packed, aligned(4))) QuadI { int v[4]; };
+struct __attribute__((packed, aligned(4))) PairD { double v[2]; };
+
+template <bool BSR1, int WGS>
+__global__ __launch_bounds__(WGS) void gs_chainl2_kernel(const int *Ap, const int *code, const double *Ax, const int *rowmap,
+                                                             const int *diagpos, double *x, const double *b,
+                                                             const int *lp, int l_first, int nl, int reverse)
+{
+    constexpr int KE = CHAINL_KE, NQ = CHAINL_KE / 4;
+    constexpr int RING = 3 * CHAINL_WG;
+    const int t = threadIdx.x;
+    __shared__ int slp[CHAINL_LMAX + 1];
+    __shared__ int sep[CHAINL_LMAX + 1];
+    __shared__ double prod[WGS * KE];
+    __shared__ double ring[RING + 1];              // + 1: what an entry without a ring operand reads
+    for (int k = t; k <= nl; k += WGS) {
+        const int p = lp[l_first + k];
+        slp[k] = p;
+        sep[k] = Ap[p];
+    }
+    if (t == 0) ring[RING] = 0.0;
+    __syncthreads();
+    auto level_of = [&](int q) { q = min(q, nl - 1); return reverse ? nl - 1 - q : q; };
+
+    // A lane owns NQ quads of 4 consecutive entries (one 16-byte request for the codes, two for the values: a compute
+    // unit takes ~16 cycles per wave-level memory instruction whatever its width); quads past the level's end re-read
+    // its last four entries (same products to the same slots).
+    struct Codes { int c[KE]; int at[NQ]; int s, e, row, dp, base, lvl; bool live; };
+    struct Stage { int c[KE]; double v[KE], xv[KE]; int at[NQ]; int s, e, row, dp, base, lvl; bool live; double bb, d; };
+    auto stage_a = [&](int q) -> Codes {           // entry codes, row bounds, row number, diagonal position
+        Codes C;
+        const int l = level_of(q);
+        const int e0 = sep[l], lastq = sep[l + 1] - e0 - 4;                 // >= 0: a chained level has at least 4 entries
+#pragma unroll
+        for (int h = 0; h < NQ; ++h) {
+            C.at[h] = min(4 * (t + h * WGS), lastq);
+            const QuadI cc = *reinterpret_cast<const QuadI *>(code + e0 + C.at[h]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) C.c[4 * h + j] = cc.v[j];
+        }
+        const int cnt = slp[l + 1] - slp[l];                                // >= 1
+        const int p = slp[l] + min(t, cnt - 1);
+        C.live = (q < nl) && (t < cnt);
+        C.base = e0;
+        C.lvl = l_first + l;
+        C.s = Ap[p]; C.e = Ap[p + 1]; C.row = rowmap ? rowmap[p] : p; C.dp = diagpos[p];
+        return C;
+    };
+    auto stage_b = [&](const Codes &C) -> Stage {  // values, operands that are final in memory, right-hand side, diagonal
+        Stage S;
+        S.s = C.s; S.e = C.e; S.row = C.row; S.dp = C.dp; S.base = C.base; S.lvl = C.lvl; S.live = C.live;
+#pragma unroll
+        for (int h = 0; h < NQ; ++h) {
+            S.at[h] = C.at[h];
+            const PairD v0 = *reinterpret_cast<const PairD *>(Ax + C.base + C.at[h]);
+            const PairD v1 = *reinterpret_cast<const PairD *>(Ax + C.base + C.at[h] + 2);
+            S.v[4 * h] = v0.v[0]; S.v[4 * h + 1] = v0.v[1]; S.v[4 * h + 2] = v1.v[0]; S.v[4 * h + 3] = v1.v[1];
+        }
+#pragma unroll
+        for (int u = 0; u < KE; ++u) {
+            S.c[u] = C.c[u];
+            S.xv[u] = load_fresh(&x[max(C.c[u], 0)]);
+        }
+        S.bb = b[C.row];
+        S.d = Ax[max(C.dp, 0)];
+        return S;
+    };
+    auto step = [&](Stage &cur, Stage &fill, const Codes &use, Codes &refill, int q) {
+        fill = stage_b(use);
+        refill = stage_a(q + 4);
+        // operands produced by the last two levels come from the ring (every lane reads: an entry without one reads the
+        // spare word and drops it)
+        double lv[KE];
+#pragma unroll
+        for (int u = 0; u < KE; ++u) lv[u] = ring[min((unsigned)~cur.c[u], (unsigned)RING)];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < KE; ++u) prod[cur.at[u / 4] + (u & 3)] = cur.v[u] * ((cur.c[u] < 0) ? lv[u] : cur.xv[u]);
+        __syncthreads();
+        if (cur.live) {
+            double acc = BSR1 ? cur.bb : 0.0;
+            constexpr int RB = 16;
+            for (int k = cur.s; k < cur.e; k += RB) {
+                double pr[RB];
+#pragma unroll
+                for (int j = 0; j < RB; ++j) pr[j] = prod[min(k + j, cur.e - 1) - cur.base];
+#pragma unroll
+                for (int j = 0; j < RB; ++j) {
+                    const bool take = (k + j < cur.e) && (k + j != cur.dp);
+                    const double nxt = BSR1 ? (acc - pr[j]) : (acc + pr[j]);
+                    acc = take ? nxt : acc;
+                }
+            }
+            const double xn = BSR1 ? (acc / cur.d) : ((cur.bb - acc) / cur.d);      // no zero diagonals in a chained row (declined at build)
+            x[cur.row] = xn;
+            ring[(cur.lvl % 3) * CHAINL_WG + t] = xn;
+        }
+        __syncthreads();
+    };
+
+    Stage sb[3];
+    Codes cq[3];
+    cq[0] = stage_a(0);
+    cq[1] = stage_a(1);
+    sb[0] = stage_b(cq[0]);
+    sb[1] = stage_b(cq[1]);
+    cq[2] = stage_a(2);
+    cq[0] = stage_a(3);
+    // (the compiler drains every outstanding request at the loop's back edge: four rotations per trip make that one
+    // drain per 12 levels; steps past the last level run on idle lanes only)
+    for (int q = 0; q < nl; q += 12) {
+#pragma unroll
+        for (int r = 0; r < 12; r += 3) {
+            step(sb[0], sb[2], cq[2], cq[1], q + r);
+            step(sb[1], sb[0], cq[0], cq[2], q + r + 1);
+            step(sb[2], sb[1], cq[1], cq[0], q + r + 2);
+        }
+    }
+}
+
 int gs_chainl_max_rows() { return CHAINL_WG; }
 int gs_chainl_entries_per_lane() { return CHAINL_KE; }
+int gs_chainl_max_levels() { return CHAINL_LMAX; }
 
 int launch_gs_chain_long(const DevCsr &G, const int *rowmap, const int *diagpos, const int *level_ptr_dev, int l_first,
-                         int nlevels, int width, bool reverse, bool bsr1, double *x, const double *b, hipStream_t st)
+                         int nlevels, int width, bool reverse, bool bsr1, double *x, const double *b, hipStream_t st,
+                         const int *ring_code)
 {
+    if (ring_code) {
+        // LDS hand-off: one launch holds the whole piece (the host cut the pieces accordingly)
+        if (nlevels <= 0) return 0;
+        if (nlevels > CHAINL_LMAX) { set_error("gs_chain_long: run longer than one launch holds"); return -4; }
+        if (width != 64 && width != 128 && width != 256 && width != 512) { set_error("gs_chain_long: workgroup size not instantiated"); return -4; }
+#define CL2_LAUNCH(B, W) hipLaunchKernelGGL((gs_chainl2_kernel<B, W>), dim3(1), dim3(W), 0, st, G.Ap, ring_code, G.Ax, rowmap, diagpos, x, b, \
+                                            level_ptr_dev, l_first, nlevels, reverse ? 1 : 0)
+#define CL2_WIDTH(B) do { if (width == 64) CL2_LAUNCH(B, 64); else if (width == 128) CL2_LAUNCH(B, 128); else if (width == 256) CL2_LAUNCH(B, 256); else CL2_LAUNCH(B, 512); } while (0)
+        if (bsr1) CL2_WIDTH(true); else CL2_WIDTH(false);
+#undef CL2_WIDTH
+#undef CL2_LAUNCH
+        hipError_t e2 = hipGetLastError();
+        if (e2 != hipSuccess) return hip_fail(e2, "gs long-row chain (LDS hand-off) launch", __FILE__, __LINE__);
+        return 0;
+    }
     if (nlevels <= 0) return 0;
+    if (width == 64) width = 128;
     if (width != 128 && width != 256 && width != 512) { set_error("gs_chain_long: workgroup size not instantiated"); return -4; }
     const int npiece = (nlevels + CHAINL_LMAX - 1) / CHAINL_LMAX;
     for (int c = 0; c < npiece; ++c) {
