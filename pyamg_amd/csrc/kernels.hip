@@ -1192,19 +1192,33 @@ __global__ __launch_bounds__(WGS) void gs_chainl2_kernel(const int *Ap, const in
         for (int u = 0; u < KE; ++u) prod[cur.at[u / 4] + (u & 3)] = cur.v[u] * ((cur.c[u] < 0) ? lv[u] : cur.xv[u]);
         __syncthreads();
         if (cur.live) {
+            // The whole wave runs this for its few live lanes, so the phase is bound by its INSTRUCTION count (SQ counters:
+            // ~1000 vector-ALU instructions per level, 17 % of the cycles waiting): the row is summed as two runs, left
+            // and right of the diagonal, whole batches of 8 without any per-entry test, then one tested batch.
             double acc = BSR1 ? cur.bb : 0.0;
-            constexpr int RB = 16;
-            for (int k = cur.s; k < cur.e; k += RB) {
-                double pr[RB];
+            auto run = [&](int lo, int hi) {                                // prod[lo .. hi), left to right
+                const double *pp = prod + lo;
+                int left = hi - lo;
+                for (; left >= 8; left -= 8, pp += 8) {
+                    double pr[8];
 #pragma unroll
-                for (int j = 0; j < RB; ++j) pr[j] = prod[min(k + j, cur.e - 1) - cur.base];
+                    for (int j = 0; j < 8; ++j) pr[j] = pp[j];
 #pragma unroll
-                for (int j = 0; j < RB; ++j) {
-                    const bool take = (k + j < cur.e) && (k + j != cur.dp);
-                    const double nxt = BSR1 ? (acc - pr[j]) : (acc + pr[j]);
-                    acc = take ? nxt : acc;
+                    for (int j = 0; j < 8; ++j) acc = BSR1 ? (acc - pr[j]) : (acc + pr[j]);
                 }
-            }
+                if (left > 0) {
+                    double pr[7];
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) pr[j] = pp[min(j, left - 1)];
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) {
+                        const double nxt = BSR1 ? (acc - pr[j]) : (acc + pr[j]);
+                        acc = (j < left) ? nxt : acc;
+                    }
+                }
+            };
+            run(cur.s - cur.base, cur.dp - cur.base);                        // (a chained row has its diagonal: dp >= s)
+            run(cur.dp + 1 - cur.base, cur.e - cur.base);
             const double xn = BSR1 ? (acc / cur.d) : ((cur.bb - acc) / cur.d);      // no zero diagonals in a chained row (declined at build)
             x[cur.row] = xn;
             ring[(cur.lvl % 3) * CHAINL_WG + t] = xn;
