@@ -596,7 +596,7 @@ int build_csr_schedule(const int *Ap, const int *Aj, const double *Ax, int n, co
         // LDS hand-off variant (gs_chainl2_kernel): per-entry codes -- the column, or ~(ring slot) for an operand produced
         // one or two levels earlier in the same launch.  Needs every unknown listed exactly once, columns inside, and no
         // zero diagonal in a chained row; otherwise the memory hand-off kernel sweeps the pieces.
-        bool ring_ok = S.chain_long && ntasks == n && gs_chain_generation() == 2;
+        bool ring_ok = S.chain_long && ntasks == n;
         std::vector<int> lvl_of, pos_of, piece_of;
         if (ring_ok) {
             lvl_of.assign((size_t)n, -1); pos_of.assign((size_t)n, -1); piece_of.assign((size_t)nl, -1);

@@ -1210,13 +1210,14 @@ def test_long_row_chain_on_sa_coarse_levels():
         for M in (M0, sps.bsr_matrix(M0, blocksize=(1, 1))):
             for sweep in ("forward", "backward", "symmetric"):
                 out = {}
-                for on in (2, 0):
+                for on in (2, 1, 0):          # LDS hand-off (gs_chainl2_kernel) / hand-off through memory (gs_chainl_kernel) / a launch per level
                     _lib.lib().amg_set_gs_chain(on)
                     x = np.cos(np.arange(n, dtype=float))
                     relaxation.gauss_seidel(M, x, b, iterations=2, sweep=sweep)
                     out[on] = x
                 _lib.lib().amg_set_gs_chain(2)
                 assert np.array_equal(out[0], out[2]), (n, type(M).__name__, sweep)
+                assert np.array_equal(out[0], out[1]), (n, type(M).__name__, sweep)
                 xo = np.cos(np.arange(n, dtype=float))
                 keep = []
                 m = oracle_lib.make_mat(M, keep)
