@@ -69,7 +69,7 @@ def run(name, ml, A, sweeps_per_application, steps, check_oracle):
            "cycle_algorithmic_GBs": round(dev.cycle_bytes("V") / (ms_step * 1e-3) / 1e9, 1),
            "hbm_resident_GB": round(dev.device_bytes() / 1e9, 2),
            "residuals_first_last": [float(res[0]), float(res[-1])]}
-    out["roofline"] = {"bound": "hbm", "kernel": "bsr_stream_kernel (level-0 smoother)", "achieved": out["level0_smoother_GBs"],
+    out["roofline"] = {"bound": "hbm", "kernel": "bsell_kernel (level-0 smoother from the sliced block form; bsr_stream_kernel where a level has no slices)", "achieved": out["level0_smoother_GBs"],
                        "peak": 8000.0, "unit": "GB/s", "frac": round(out["level0_smoother_GBs"] / 8000.0, 4)}
     if check_oracle:
         x1 = np.zeros(n)
