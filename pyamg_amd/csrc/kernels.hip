@@ -2155,7 +2155,7 @@ static int launch_stream_mode(const StreamArgs &a, hipStream_t st)
 // pointers), so the entries are requested at once, beside the row pointers, row numbers and diagonal positions:
 // two round trips.  Same tile, same left-to-right row sums as csr_stream_kernel<SM_GS / SM_GS_BSR1>.
 // ---------------------------------------------------------------------------
-constexpr int GS_LEVEL_MAXWG = 64;
+constexpr int GS_LEVEL_MAXWG = 224;
 struct LevelEntries { int e[GS_LEVEL_MAXWG + 1]; };
 
 template <bool BSR1>
