@@ -68,7 +68,9 @@ def run(name, ml, A, sweeps_per_application, steps, check_oracle):
            "level0_residual_GBs": round((smoother_bytes(A, 1) - 8.0 * n * 3) / (ms_spmv * 1e-3) / 1e9, 1),
            "cycle_algorithmic_GBs": round(dev.cycle_bytes("V") / (ms_step * 1e-3) / 1e9, 1),
            "hbm_resident_GB": round(dev.device_bytes() / 1e9, 2),
-           "residuals_first_last": [float(res[0]), float(res[-1])]}
+           "residuals_first_last": [float(res[0]), float(res[-1])],
+           # one application of the presmoother on every coarser level that has one (ms): what the cycle spends below level 0
+           "coarse_smoother_ms": [round(dev.time_relax(l, 0, reps=3), 3) for l in range(1, len(ml.levels) - 1)]}
     out["roofline"] = {"bound": "hbm", "kernel": "bsell_kernel (level-0 smoother from the sliced block form; bsr_stream_kernel where a level has no slices)", "achieved": out["level0_smoother_GBs"],
                        "peak": 8000.0, "unit": "GB/s", "frac": round(out["level0_smoother_GBs"] / 8000.0, 4)}
     if check_oracle:
