@@ -291,6 +291,9 @@ int amg_mat_apply_rows(amg_mat *m, int mode, int row_lo, int row_hi, const doubl
 int amg_mat_build_gs(amg_mat *m, const int *order, int norder);
 int amg_mat_gs_levels(amg_mat *m);
 int amg_mat_gs_sweep(amg_mat *m, double *x, const double *b, int reverse, int bsr1, void *stream);
+/* a whole sequence of directional sweeps (seq[k] != 0: backward) as the in-cycle smoothers issue them: the
+ * dataflow form runs up to four of them per launch */
+int amg_mat_gs_sweeps(amg_mat *m, double *x, const double *b, const unsigned char *seq, int nseq, int bsr1, void *stream);
 int amg_dev_scale(double *out, const double *in, double c, long n, void *stream);
 int amg_dev_axpy(double *x, const double *h, long n, void *stream);
 int amg_dev_axpy_scaled(double *x, const double *r, double c, long n, void *stream);   /* x += c*r */
@@ -396,6 +399,18 @@ void amg_set_gs_chain(int on);
 /* levels too wide for a chain, one launch each: 1 (default) the launch's workgroups get their entry ranges in the kernel
  * arguments (gs_level_kernel: two memory round trips per launch), 0 the general stream kernel (three) */
 void amg_set_gs_level_hint(int on);
+/* Gauss-Seidel sweeps (pyamg/amg_core/relaxation.h:34-62, :90-173 with 1x1 blocks) as ONE persistent launch per
+ * smoother application ("dataflow" form, csrc/gsflow.hip): rows wait for their own operands instead of for a
+ * dependency level.  1 (default): schedules whose levels would otherwise be launches of their own or long-row chains
+ * (3-D operators, coarse levels of smoothed-aggregation hierarchies); 2: every schedule the form exists for; 0: never
+ * (level launches and chained sweeps).  Read when a schedule is built and when it is swept.  Same bits. */
+void amg_set_gs_flow(int mode);
+/* look-ahead of the dataflow sweep in dependency levels (resident waves = look-ahead x average chunks per level);
+ * 0: the default (4) */
+void amg_set_gs_flow_lookahead(int levels);
+/* host-synchronous: nonzero when a wave of a dataflow sweep gave up waiting (4 s budget) since the last call -- the
+ * iterates of that sweep are then unusable.  amg_hier_solve checks it before it returns. */
+int amg_gs_flow_status(void);
 /* A of a BSR(bs,bs) level can be applied straight from its blocks (8 B per entry + 4 B per block) instead
  * of from the CSR expansion (12 B per entry); same summation order, same bits.  0: never, 1 (default):
  * for blocks of 3x3 and larger (where it is measured faster), 2: always */

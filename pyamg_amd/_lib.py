@@ -101,6 +101,7 @@ def lib():
         "amg_dev_axpy_scaled": [V, V, D, C.c_long, V],
         "amg_mat_build_gs": [V, c_int_p, I],
         "amg_mat_gs_sweep": [V, V, V, I, I, V],
+        "amg_mat_gs_sweeps": [V, V, V, V, I, I, V],
         "amg_dev_scale": [V, V, D, C.c_long, V],
         "amg_dev_axpy": [V, V, C.c_long, V],
         "amg_dev_norm2": [V, C.c_long, V, V, V],
@@ -210,6 +211,12 @@ def lib():
     L.amg_set_gs_chain.restype = None
     L.amg_set_gs_level_hint.argtypes = [I]
     L.amg_set_gs_level_hint.restype = None
+    L.amg_set_gs_flow.argtypes = [I]
+    L.amg_set_gs_flow.restype = None
+    L.amg_set_gs_flow_lookahead.argtypes = [I]
+    L.amg_set_gs_flow_lookahead.restype = None
+    L.amg_gs_flow_status.argtypes = []
+    L.amg_gs_flow_status.restype = I
     L.amg_set_stencil_form.argtypes = [I]
     L.amg_set_stencil_form.restype = None
     L.amg_set_stencil_pairs.argtypes = [I]

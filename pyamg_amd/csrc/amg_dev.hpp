@@ -285,4 +285,37 @@ int build_bsell_levels(DevBsr &M, const std::vector<int> &level_ptr, const int *
 int launch_bsell_level(const DevBsr &M, BlockMode m, const BsrStreamArgs &a, int slice_lo, int slice_hi, hipStream_t st);
 bool bsell_level_enabled();
 
+// ---------------------------------------------------------------- dataflow Gauss-Seidel (gsflow.hip)
+// A whole sequence of directional sweeps as ONE persistent launch: the unknowns in level-order numbering, every
+// dependency level cut into chunks of 64 rows (one wave, one lane per row, the off-diagonal entries slot-major), chunks
+// dealt to the resident waves in sweep order.  A sweep reads the previous sweep's values from one buffer and publishes
+// its own into another that starts out filled with a signalling-NaN sentinel; an operand is ready when it no longer
+// reads as the sentinel, so a row starts the moment ITS operands exist -- no barrier, no launch per level.
+constexpr int FLOW_MAXSEQ = 4;          // directional sweeps per launch (buffers: FLOW_MAXSEQ + 1)
+struct FlowChunk { int row0, nrows, nslots, lvl_lo, lvl_hi, off, pad0, pad1; };   // nslots: slots per LANE; off: first slot row of the chunk (x 64 entries)
+struct FlowForm {
+    bool ready = false;
+    int n = 0, nchunks = 0, nlevels = 0, lpr = 1;    // lpr: lanes sharing a row (1 .. 64, by the longest row: 8 slots per lane)
+    long slot_rows = 0;                 // rows of 64 (value, column) pairs stored
+    int *rowmap = nullptr;              // [n] original row of level-order position k (rows of a level sorted by length)
+    FlowChunk *meta = nullptr;          // [nchunks]
+    int *col = nullptr;                 // [slot_rows * 64] operand position (n: the permanent 0.0 of padded slots)
+    double *val = nullptr;              // [slot_rows * 64]
+    double *diag = nullptr;             // [n]
+    int *gate_f = nullptr, *gate_b = nullptr;   // [n] forward / backward sweep: the row's latest operand produced at least two levels earlier (n: none)
+    double *bp = nullptr;               // [n] right-hand side in level-order numbering (gathered per application)
+    double *X = nullptr;                // [(FLOW_MAXSEQ + 1) * xstride] iterate buffers, entry n of each = 0.0
+    long xstride = 0;
+    long bytes = 0;
+    void release();
+};
+// from the level-ordered copy of a schedule (host arrays): leaves F.ready false when the form does not apply
+int build_flow_form(FlowForm &F, int n, int ntasks, const std::vector<int> &level_ptr, const std::vector<int> &rowmap,
+                    const std::vector<int> &gp, const std::vector<int> &gj, const std::vector<double> &gx);
+int gs_flow_sweep(const FlowForm &F, bool bsr1, double *x, const double *b, const unsigned char *seq, int nseq, hipStream_t st);
+int gs_flow_mode();                     // 0 off, 1 where it measured faster (default), 2 wherever the form exists
+void set_gs_flow(int mode);
+void set_gs_flow_lookahead(int levels);
+int gs_flow_status();                   // host-synchronous: nonzero when a wave of a dataflow sweep ran out of its time budget (resets the flag)
+
 }  // namespace amg

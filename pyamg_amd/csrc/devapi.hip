@@ -9,6 +9,7 @@
 namespace amg {
 int upload_csr(DevCsr &M, int nrows, int ncols, const int *Ap, const int *Aj, const double *Ax, long *acct);
 int gs_sweep_csr(const Schedule &S, bool bsr1, double *x, const double *b, bool reverse, hipStream_t st);
+int gs_sweep_csr(const Schedule &S, bool bsr1, double *x, const double *b, const unsigned char *seq, int nseq, hipStream_t st);
 int try_patterns(DevCsr &M, const int *Ap, const int *Aj, long *acct);
 int apply_operator(const DevCsr &M, StreamMode mode, const StreamArgs &a, hipStream_t st);
 void free_csr(DevCsr &M);
@@ -103,6 +104,14 @@ int amg_mat_gs_sweep(amg_mat *m, double *x, const double *b, int reverse, int bs
     if (!m || !m->sched) { set_error("amg_mat_build_gs was not called"); return AMG_ESTATE; }
     AMG_HIP(hipSetDevice(m->device));
     return gs_sweep_csr(*m->sched, bsr1 != 0, x, b, reverse != 0, (hipStream_t)stream);
+}
+
+int amg_mat_gs_sweeps(amg_mat *m, double *x, const double *b, const unsigned char *seq, int nseq, int bsr1, void *stream)
+{
+    if (!m || !m->sched) { set_error("amg_mat_build_gs was not called"); return AMG_ESTATE; }
+    if (nseq < 0 || (nseq > 0 && !seq)) { set_error("bad sweep sequence"); return AMG_EINVAL; }
+    AMG_HIP(hipSetDevice(m->device));
+    return gs_sweep_csr(*m->sched, bsr1 != 0, x, b, seq, nseq, (hipStream_t)stream);
 }
 
 long amg_mat_nnz(amg_mat *m) { return m ? m->M.nnz : 0; }

@@ -1,0 +1,465 @@
+// Dataflow Gauss-Seidel: the exact sequential sweep of pyamg/amg_core/relaxation.h:34-62 (gauss_seidel) and :90-173
+// (bsr_gauss_seidel with 1x1 blocks) as ONE persistent launch per sequence of directional sweeps.
+//
+// Dependency-level scheduling (hier.hip build_levels) reproduces the sequential sweep bit for bit, but every wide
+// level used to be a launch of its own: ~4.5-5.4 us start to start for a few microseconds' worth of bytes, so the
+// reference's default 3-D setup (smoothed aggregation + symmetric Gauss-Seidel) was launch-bound (DESIGN.md
+// section 4).  Here nothing waits for a LEVEL any more:
+//   * unknowns are renumbered in level order (rows of a level sorted by length), every level is cut into chunks of
+//     64 rows -- one wave, one lane per row, the row's off-diagonal entries slot-major as in the sliced form
+//     (sell.hip), padded slots = value 0 times a permanent 0.0;
+//   * chunks are dealt to the resident waves round-robin IN SWEEP ORDER (static: task Q runs on wave Q mod NW); a wave
+//     loads its chunk's entries, diagonal and right-hand side (none of which depend on the sweep), then gathers
+//     its operands;
+//   * a directional sweep reads the values of the previous sweep from buffer X[s] and publishes its own into
+//     X[s+1], which the gather kernel has filled with a signalling-NaN SENTINEL: an operand is ready when it no longer
+//     reads as the sentinel.  Every value is written exactly once per launch by ONE relaxed agent-scope 8-byte
+//     atomic store and read by relaxed agent-scope atomic loads: the datum is its own flag, so no ordering between
+//     different addresses is needed, and there are no write-after-read hazards because no buffer is overwritten;
+//     results of IEEE divisions are never signalling NaNs, so a finished value cannot be mistaken for the sentinel
+//     (the gather quiets a user-supplied x entry that happens to carry the sentinel's bits: every arithmetic use of
+//     it would have quieted it the same way);
+//   * forward and backward sweeps (and further iterations) follow each other inside the launch without any
+//     barrier: the first chunks of the backward sweep simply wait for the forward values they read.
+// Each lane adds ITS row's products in stored order with separately rounded multiply and add and divides once:
+// bit-identical to the level-scheduled kernels, the chained sweeps and the oracle.
+//
+// Progress: every wave handles its tasks in increasing order and a task only waits for tasks that precede it in
+// that order, so the earliest unfinished task can always run -- provided all waves are resident, which the launch
+// guarantees by sizing the grid from the occupancy query with a margin (MI355X_MICROARCH.md, residency).  Every
+// spin is bounded by a wall-clock budget measured from the wave's start; a wave that runs out of it raises the
+// status flag and leaves, and so does everybody who waits for it (gs_flow_status()).
+#include "hier.hpp"
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+namespace amg {
+
+namespace {
+
+constexpr unsigned long long FLOW_SENT = 0x7FF4A5A55A5A0001ULL;    // a signalling NaN no arithmetic result can equal
+constexpr unsigned long long FLOW_QUIET = 0x0008000000000000ULL;
+#ifndef AMG_FLOW_SEG
+#define AMG_FLOW_SEG 8
+#endif
+#ifndef AMG_FLOW_SLEEP
+#define AMG_FLOW_SLEEP 1
+#endif
+constexpr int FLOW_SEG = AMG_FLOW_SEG;          // slots a lane owns at most: a row of up to FLOW_SEG * LPR off-diagonal entries is shared by LPR lanes
+
+#define FCHK(call)                 \
+    do {                           \
+        int rc__ = (call);         \
+        if (rc__ != 0) return rc__; \
+    } while (0)
+
+template <class T> int falloc(T **p, long count, long *acct)
+{
+    *p = nullptr;
+    if (count <= 0) count = 1;
+    hipError_t e = hipMalloc((void **)p, sizeof(T) * (size_t)count);
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc (dataflow Gauss-Seidel form)", __FILE__, __LINE__);
+    if (acct) *acct += (long)(sizeof(T) * (size_t)count);
+    return 0;
+}
+
+struct FlowArgs {
+    unsigned long long *X;      // (nseq + 1) buffers of xstride entries
+    double *x_out;              // the caller's x (original numbering): written by the last sweep
+    int *status;
+    long xstride;
+    long long budget;
+    int nchunks, nseq, n;
+    unsigned dirmask;           // bit s: sweep s runs backward
+};
+
+__device__ __forceinline__ unsigned long long ald(const unsigned long long *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// the workgroup IS one wave: LDS operations of a wave execute in order, so all that is needed between the lanes'
+// product writes and the leaders' reads is that the compiler keeps them in order
+__device__ __forceinline__ void flow_wave_sync()
+{
+#ifdef AMG_FLOW_SYNCTHREADS
+    __syncthreads();
+#else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+}
+
+// x (original numbering) -> X[0] (level order), b -> bp; X[1..nseq] = sentinel; entry n of every buffer = 0.0
+__global__ __launch_bounds__(256) void flow_gather_kernel(const int *rowmap, const double *x, const double *b, unsigned long long *X,
+                                                           double *bp, long xstride, int n, int nseq)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k > n) return;
+    if (k == n) {
+        for (int s = 0; s <= nseq; ++s) X[(long)s * xstride + n] = 0ULL;
+        return;
+    }
+    const int i = rowmap[k];
+    unsigned long long xb = (unsigned long long)__double_as_longlong(x[i]);
+    if (xb == FLOW_SENT) xb |= FLOW_QUIET;
+    X[k] = xb;
+    bp[k] = b[i];
+    for (int s = 1; s <= nseq; ++s) X[(long)s * xstride + k] = FLOW_SENT;
+}
+
+// The static arrays travel as __restrict__ parameters of their own: the chunk descriptor is then read through the
+// scalar cache (one s_load per task) and nothing static is re-read after the stores.
+// LPR lanes share a row (64 / LPR rows per wave): lane g of a row's group owns the row's slots [g * seg, (g + 1) * seg)
+// -- its entries, its operand gathers, its products -- and the group's first lane adds the products of all groups in
+// stored order (through LDS when LPR > 1).  A long row then costs SEG wave-level gathers instead of its length, and
+// a level of few long rows spreads over more compute units.
+template <int SEG, int LPR, bool BSR1>
+__global__ __launch_bounds__(64) void gs_flow_kernel(const FlowChunk *__restrict__ meta, const int *__restrict__ col,
+                                                      const double *__restrict__ val, const double *__restrict__ diag,
+                                                      const double *__restrict__ bp, const int *__restrict__ rowmap,
+                                                      const int *__restrict__ gate_f, const int *__restrict__ gate_b, FlowArgs a)
+{
+    __shared__ double prod[LPR > 1 ? SEG * 64 : 1];
+    const int lane = threadIdx.x;
+    const int t = lane / LPR;
+    const int NW = (int)gridDim.x;
+    const long long t0 = wall_clock64();
+    int s = 0, q = (int)blockIdx.x;
+    while (q >= a.nchunks) { q -= a.nchunks; ++s; }
+    while (s < a.nseq) {
+        const bool rev = ((a.dirmask >> s) & 1u) != 0;
+        const int c = rev ? a.nchunks - 1 - q : q;
+        const FlowChunk m = meta[c];
+        const int seg = m.nslots;                       // slots per lane in this chunk (<= SEG)
+        const bool leader = (lane % LPR) == 0 && t < m.nrows;
+        const int k = m.row0 + (t < m.nrows ? t : 0);
+        // what does not depend on the sweep: entries, right-hand side, diagonal.  Straight-line code: always SEG slots per
+        // lane; a slot past the chunk's own `seg` re-reads the last real slot (same cache lines) and is turned into the
+        // padding pair (0.0, the permanent zero) -- uniform branches per slot cost more than the redundant requests
+        int idx[SEG];
+        double v[SEG];
+        const long e0 = (long)m.off * 64 + lane;
+        const int smax = seg > 0 ? seg - 1 : 0;
+#pragma unroll
+        for (int u = 0; u < SEG; ++u) {
+            const long e = e0 + (long)min(u, smax) * 64;
+            idx[u] = col[e];
+            v[u] = val[e];
+        }
+        double bb = 0.0, dd = 1.0;
+        int orow = 0, gate = a.n;
+        const bool last = s == a.nseq - 1;
+        if (leader) {
+            bb = bp[k]; dd = diag[k];
+            gate = rev ? gate_b[k] : gate_f[k];
+            if (last) orow = rowmap[k];
+        }
+        const unsigned long long *Xo = a.X + (long)s * a.xstride;
+        unsigned long long *Xn = a.X + (long)(s + 1) * a.xstride;
+        // Gate: the row's latest operand of this sweep that is produced at least TWO levels earlier.  Until it exists the
+        // wave is far ahead of the sweep and polls this one word per row instead of all its operands.
+        {
+            unsigned long long gv = ald(Xn + gate);
+            for (unsigned spin = 0; __any(gv == FLOW_SENT); ++spin) {
+                __builtin_amdgcn_s_sleep(4);
+                if ((spin & 31u) == 31u && wall_clock64() - t0 > a.budget) {
+                    if (lane == 0) __hip_atomic_store(a.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    return;
+                }
+                if (gv == FLOW_SENT) gv = ald(Xn + gate);
+            }
+        }
+        // operands: produced by THIS sweep (earlier levels in sweep order) -> new buffer, everything else -> old one
+        const int xs = (int)a.xstride;
+        unsigned long long xb[SEG];
+#pragma unroll
+        for (int u = 0; u < SEG; ++u) {
+            const bool real = u < seg && (seg > 0);
+            v[u] = real ? v[u] : 0.0;
+            idx[u] = real ? idx[u] : a.n;
+            const bool fresh = rev ? (idx[u] >= m.lvl_hi) : (idx[u] < m.lvl_lo);
+            idx[u] += fresh ? xs : 0;
+            xb[u] = ald(Xo + idx[u]);
+        }
+        for (unsigned spin = 0;; ++spin) {
+            bool bad = false;
+#pragma unroll
+            for (int u = 0; u < SEG; ++u) bad |= (xb[u] == FLOW_SENT);
+            if (!__any(bad)) break;
+            if (AMG_FLOW_SLEEP > 0) __builtin_amdgcn_s_sleep(AMG_FLOW_SLEEP);
+            if ((spin & 31u) == 31u && wall_clock64() - t0 > a.budget) {
+                if (lane == 0) __hip_atomic_store(a.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+#pragma unroll
+            for (int u = 0; u < SEG; ++u)
+                if (xb[u] == FLOW_SENT) xb[u] = ald(Xo + idx[u]);
+        }
+        double acc = BSR1 ? bb : 0.0;
+        if constexpr (LPR == 1) {
+#pragma unroll
+            for (int u = 0; u < SEG; ++u) {
+                const double pr = v[u] * __longlong_as_double((long long)xb[u]);
+                acc = BSR1 ? (acc - pr) : (acc + pr);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < SEG; ++u) prod[u * 64 + lane] = v[u] * __longlong_as_double((long long)xb[u]);
+            flow_wave_sync();
+            if (leader) {
+                // the products of the row's LPR lanes in stored order: lane g's slots 0 .. SEG-1 (padding = +0.0, which
+                // leaves the running sum's bits alone), GB lanes' worth of LDS reads in flight at a time
+                constexpr int GB = LPR < 4 ? LPR : 4;
+#pragma unroll 1
+                for (int g0 = 0; g0 < LPR; g0 += GB) {
+                    double p[GB * SEG];
+#pragma unroll
+                    for (int g = 0; g < GB; ++g)
+#pragma unroll
+                        for (int u = 0; u < SEG; ++u) p[g * SEG + u] = prod[u * 64 + lane + g0 + g];
+#pragma unroll
+                    for (int w = 0; w < GB * SEG; ++w) acc = BSR1 ? (acc - p[w]) : (acc + p[w]);
+                }
+            }
+            flow_wave_sync();
+        }
+        if (leader) {
+            const double xn = BSR1 ? (acc / dd) : ((bb - acc) / dd);
+            __hip_atomic_store(Xn + k, (unsigned long long)__double_as_longlong(xn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (last) a.x_out[orow] = xn;
+        }
+        q += NW;
+        while (q >= a.nchunks) { q -= a.nchunks; ++s; }
+    }
+}
+
+int g_flow_mode = 1;
+int g_flow_la = 0;              // look-ahead in levels; 0: default
+int *g_status = nullptr;        // device word, one per process and device (first use)
+int g_status_dev = -1;
+
+int flow_status_word(int **out)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return hip_fail(e, "hipGetDevice", __FILE__, __LINE__);
+    if (!g_status || g_status_dev != dev) {
+        e = hipMalloc((void **)&g_status, 64);
+        if (e != hipSuccess) return hip_fail(e, "hipMalloc (dataflow status word)", __FILE__, __LINE__);
+        e = hipMemset(g_status, 0, 64);
+        if (e != hipSuccess) return hip_fail(e, "hipMemset", __FILE__, __LINE__);
+        g_status_dev = dev;
+    }
+    *out = g_status;
+    return 0;
+}
+
+template <int LPR>
+int flow_waves_cap(bool bsr1)
+{
+    // resident waves the launch may count on: occupancy query, at most 8 per compute unit, 3/4 of that as a margin
+    static int cap[2] = {0, 0};
+    int &c = cap[bsr1 ? 1 : 0];
+    if (c == 0) {
+        int nb = 0, dev = 0, ncu = 0;
+        hipError_t e = bsr1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gs_flow_kernel<FLOW_SEG, LPR, true>, 64, 0)
+                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gs_flow_kernel<FLOW_SEG, LPR, false>, 64, 0);
+        if (e != hipSuccess || nb < 1) nb = 1;
+        hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount;
+        if (ncu < 1) ncu = 64;
+        c = std::max(16, ncu * std::min(nb, 8) * 3 / 4);
+    }
+    return c;
+}
+
+template <int LPR>
+int launch_flow(const FlowForm &F, bool bsr1, const FlowArgs &a, hipStream_t st)
+{
+    const int la = g_flow_la > 0 ? g_flow_la : 4;
+    long nw = (long)la * ((F.nchunks + std::max(1, F.nlevels) - 1) / std::max(1, F.nlevels));
+    static const int minw = std::getenv("AMG_FLOW_MINW") ? std::atoi(std::getenv("AMG_FLOW_MINW")) : 32;
+    nw = std::max<long>(nw, minw);
+    nw = std::min<long>(nw, flow_waves_cap<LPR>(bsr1));
+    nw = std::min<long>(nw, (long)a.nseq * F.nchunks);
+    if (bsr1) hipLaunchKernelGGL((gs_flow_kernel<FLOW_SEG, LPR, true>), dim3((unsigned)nw), dim3(64), 0, st, F.meta, F.col, F.val, F.diag, F.bp, F.rowmap, F.gate_f, F.gate_b, a);
+    else hipLaunchKernelGGL((gs_flow_kernel<FLOW_SEG, LPR, false>), dim3((unsigned)nw), dim3(64), 0, st, F.meta, F.col, F.val, F.diag, F.bp, F.rowmap, F.gate_f, F.gate_b, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "dataflow Gauss-Seidel launch", __FILE__, __LINE__);
+    return 0;
+}
+
+}  // namespace
+
+void FlowForm::release()
+{
+    for (void *p : {(void *)rowmap, (void *)meta, (void *)col, (void *)val, (void *)diag, (void *)bp, (void *)X, (void *)gate_f, (void *)gate_b})
+        if (p) hipFree(p);
+    gate_f = gate_b = nullptr;
+    rowmap = nullptr; meta = nullptr; col = nullptr; val = nullptr; diag = nullptr; bp = nullptr; X = nullptr;
+    ready = false;
+    bytes = 0;
+}
+
+int gs_flow_mode() { return g_flow_mode; }
+void set_gs_flow(int mode) { g_flow_mode = mode; bump_config_epoch(); }
+void set_gs_flow_lookahead(int levels) { g_flow_la = levels; bump_config_epoch(); }
+
+int gs_flow_status()
+{
+    if (!g_status) return 0;
+    int v = 0;
+    if (hipMemcpy(&v, g_status, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (v != 0) hipMemset(g_status, 0, sizeof(int));
+    return v;
+}
+
+// rowmap / gp / gj / gx: the schedule's level-ordered copy (row k of it = original row rowmap[k], ORIGINAL columns)
+int build_flow_form(FlowForm &F, int n, int ntasks, const std::vector<int> &level_ptr, const std::vector<int> &rowmap,
+                    const std::vector<int> &gp, const std::vector<int> &gj, const std::vector<double> &gx)
+{
+    F.release();
+    const int nl = (int)level_ptr.size() - 1;
+    if (n <= 0 || ntasks != n || nl <= 0) return 0;
+    if ((double)n * (FLOW_MAXSEQ + 1) >= 2.0e9) return 0;                      // operand positions are 32-bit offsets across the buffers
+    // every unknown listed exactly once, all columns inside, a nonzero diagonal in every row (relaxation.h:58-60
+    // leaves a row with a zero diagonal untouched: such operators keep the level-scheduled kernels)
+    std::vector<int> cnt((size_t)n), seen((size_t)n, 0);
+    std::vector<double> dg((size_t)n, 0.0);
+    int longest = 0;
+    for (int k = 0; k < n; ++k) {
+        const int i = rowmap[(size_t)k];
+        if (i < 0 || i >= n || seen[(size_t)i]) return 0;
+        seen[(size_t)i] = 1;
+        int c = 0;
+        bool has_d = false;
+        double d = 0.0;
+        for (int q = gp[(size_t)k]; q < gp[(size_t)k + 1]; ++q) {
+            const int j = gj[(size_t)q];
+            if (j < 0 || j >= n) return 0;
+            if (j == i) { d = gx[(size_t)q]; has_d = true; }                   // the last diagonal entry wins (relaxation.h:51-52)
+            else ++c;
+        }
+        if (!has_d || d == 0.0) return 0;
+        cnt[(size_t)k] = c;
+        dg[(size_t)k] = d;
+        longest = std::max(longest, c);
+    }
+    if (longest > FLOW_SEG * 64) return 0;
+    int lpr = 1;
+    while (lpr * FLOW_SEG < longest) lpr *= 2;
+    F.lpr = lpr;
+    const int R = 64 / lpr;                                                    // rows per chunk
+    // rows of a level sorted by length (longest first, ties in schedule order): chunks are nearly rectangular
+    std::vector<int> ord((size_t)n), pos_of((size_t)n);
+    for (int l = 0; l < nl; ++l) {
+        const int lo = level_ptr[(size_t)l], hi = level_ptr[(size_t)l + 1];
+        for (int k = lo; k < hi; ++k) ord[(size_t)k] = k;
+        std::stable_sort(ord.begin() + lo, ord.begin() + hi, [&](int p, int q) { return cnt[(size_t)p] > cnt[(size_t)q]; });
+    }
+    for (int k = 0; k < n; ++k) pos_of[(size_t)rowmap[(size_t)ord[(size_t)k]]] = k;
+    std::vector<FlowChunk> meta;
+    long slot_rows = 0;
+    for (int l = 0; l < nl; ++l) {
+        const int lo = level_ptr[(size_t)l], hi = level_ptr[(size_t)l + 1];
+        for (int r0 = lo; r0 < hi; r0 += R) {
+            FlowChunk m;
+            std::memset(&m, 0, sizeof(m));
+            m.row0 = r0; m.nrows = std::min(R, hi - r0);
+            m.nslots = (cnt[(size_t)ord[(size_t)r0]] + lpr - 1) / lpr;          // per lane; the chunk's first row is its longest
+            m.lvl_lo = lo; m.lvl_hi = hi;
+            if (slot_rows > 2000000000L / 64) return 0;
+            m.off = (int)slot_rows;
+            slot_rows += m.nslots;
+            meta.push_back(m);
+        }
+    }
+    std::vector<int> col((size_t)slot_rows * 64, n), rmap((size_t)n), lev((size_t)n), gf((size_t)n, n), gb((size_t)n, n);
+    std::vector<double> val((size_t)slot_rows * 64, 0.0), dgs((size_t)n);
+    for (int l = 0; l < nl; ++l)
+        for (int k = level_ptr[(size_t)l]; k < level_ptr[(size_t)l + 1]; ++k) lev[(size_t)k] = l;
+    for (const FlowChunk &m : meta)
+        for (int t = 0; t < m.nrows; ++t) {
+            const int kk = m.row0 + t;                                          // position in the form's numbering
+            const int k = ord[(size_t)kk], i = rowmap[(size_t)k];
+            rmap[(size_t)kk] = i;
+            dgs[(size_t)kk] = dg[(size_t)k];
+            const int lk = lev[(size_t)kk];
+            int j = 0, gfl = -1, gbl = nl;                                      // off-diagonal entries in stored order
+            for (int q = gp[(size_t)k]; q < gp[(size_t)k + 1]; ++q) {
+                const int cj = gj[(size_t)q];
+                if (cj == i) continue;
+                const int g = j / m.nslots, u = j % m.nslots;                   // lane g of the row's group, its slot u
+                const size_t at = ((size_t)m.off + (size_t)u) * 64 + (size_t)t * lpr + (size_t)g;
+                const int pc = pos_of[(size_t)cj], lc = lev[(size_t)pc];
+                col[at] = pc;
+                val[at] = gx[(size_t)q];
+                if (lc <= lk - 2 && lc > gfl) { gfl = lc; gf[(size_t)kk] = pc; }  // forward gate: the latest level at least two back
+                if (lc >= lk + 2 && lc < gbl) { gbl = lc; gb[(size_t)kk] = pc; }  // backward gate
+                ++j;
+            }
+        }
+    F.n = n; F.nchunks = (int)meta.size(); F.nlevels = nl; F.slot_rows = slot_rows;
+    F.xstride = ((long)n + 1 + 15) / 16 * 16;
+    long acct = 0;
+    FCHK(falloc(&F.rowmap, n, &acct));
+    FCHK(falloc(&F.meta, (long)meta.size(), &acct));
+    FCHK(falloc(&F.col, slot_rows * 64, &acct));
+    FCHK(falloc(&F.val, slot_rows * 64, &acct));
+    FCHK(falloc(&F.diag, n, &acct));
+    FCHK(falloc(&F.bp, n, &acct));
+    FCHK(falloc(&F.gate_f, n, &acct));
+    FCHK(falloc(&F.gate_b, n, &acct));
+    FCHK(falloc(&F.X, (FLOW_MAXSEQ + 1) * F.xstride, &acct));
+    AMG_HIP(hipMemcpy(F.rowmap, rmap.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
+    AMG_HIP(hipMemcpy(F.meta, meta.data(), sizeof(FlowChunk) * meta.size(), hipMemcpyHostToDevice));
+    if (slot_rows > 0) {
+        AMG_HIP(hipMemcpy(F.col, col.data(), sizeof(int) * col.size(), hipMemcpyHostToDevice));
+        AMG_HIP(hipMemcpy(F.val, val.data(), sizeof(double) * val.size(), hipMemcpyHostToDevice));
+    }
+    AMG_HIP(hipMemcpy(F.diag, dgs.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+    AMG_HIP(hipMemcpy(F.gate_f, gf.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
+    AMG_HIP(hipMemcpy(F.gate_b, gb.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
+    F.bytes = acct;
+    F.ready = true;
+    return 0;
+}
+
+// all directional sweeps of one smoother application (seq[k] != 0: backward), FLOW_MAXSEQ per launch
+int gs_flow_sweep(const FlowForm &F, bool bsr1, double *x, const double *b, const unsigned char *seq, int nseq, hipStream_t st)
+{
+    if (!F.ready) { set_error("dataflow Gauss-Seidel form was not built"); return -3; }
+    int *status = nullptr;
+    FCHK(flow_status_word(&status));
+    for (int s0 = 0; s0 < nseq; s0 += FLOW_MAXSEQ) {
+        const int ns = std::min(FLOW_MAXSEQ, nseq - s0);
+        hipLaunchKernelGGL(flow_gather_kernel, dim3((unsigned)((F.n + 1 + 255) / 256)), dim3(256), 0, st, F.rowmap, x, b,
+                           (unsigned long long *)F.X, F.bp, F.xstride, F.n, ns);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return hip_fail(e, "dataflow gather launch", __FILE__, __LINE__);
+        FlowArgs a;
+        std::memset(&a, 0, sizeof(a));
+        a.X = (unsigned long long *)F.X; a.x_out = x; a.status = status;
+        a.xstride = F.xstride; a.budget = 100000000LL * 4;                   // 4 s of the 100 MHz wall clock
+        a.nchunks = F.nchunks; a.nseq = ns; a.n = F.n;
+        a.dirmask = 0;
+        for (int k = 0; k < ns; ++k) a.dirmask |= (seq[s0 + k] != 0 ? 1u : 0u) << k;
+        switch (F.lpr) {
+        case 1: FCHK(launch_flow<1>(F, bsr1, a, st)); break;
+        case 2: FCHK(launch_flow<2>(F, bsr1, a, st)); break;
+        case 4: FCHK(launch_flow<4>(F, bsr1, a, st)); break;
+        case 8: FCHK(launch_flow<8>(F, bsr1, a, st)); break;
+        case 16: FCHK(launch_flow<16>(F, bsr1, a, st)); break;
+        case 32: FCHK(launch_flow<32>(F, bsr1, a, st)); break;
+        default: FCHK(launch_flow<64>(F, bsr1, a, st)); break;
+        }
+    }
+    return 0;
+}
+
+}  // namespace amg

@@ -406,6 +406,7 @@ void Schedule::release()
     if (rows) hipFree(rows);
     if (level_ptr_dev) hipFree(level_ptr_dev);
     free_bsr(Gb);
+    flow.release();
     rowmap = diagpos = rows = level_ptr_dev = nullptr;
     for (int *p : {c2_code_f, c2_code_b, c2_off, perm_Aj, cl_code_f, cl_code_b}) if (p) hipFree(p);
     cl_code_f = cl_code_b = nullptr;
@@ -731,6 +732,19 @@ int build_csr_schedule(const int *Ap, const int *Aj, const double *Ax, int n, co
             S.perm = true;
         }
     }
+    // ---- dataflow form (gsflow.hip): one persistent launch per smoother application
+    S.flow_auto = false;
+    if (gs_flow_mode() != 0 && ntasks == n) {
+        // by default only where levels would otherwise be launches of their own or long-row chains: the sweeps of
+        // narrow short-row levels (2-D operators) hand their values on through LDS faster than any memory hand-off
+        int chained = 0;
+        for (const auto &c : S.chains) chained += c.second - c.first;
+        const bool wanted = S.chain_long || chained * 10 < nl * 9;
+        if (wanted || gs_flow_mode() == 2) {
+            CHK(build_flow_form(S.flow, n, ntasks, S.level_ptr, rowmap, gp, gj, gx));
+            S.flow_auto = wanted && S.flow.ready;
+        }
+    }
     return 0;
 }
 
@@ -844,6 +858,8 @@ int gs_sweep_csr(const Schedule &S, bool bsr1, double *x, const double *b, const
                  hipStream_t st)
 {
     if (nseq <= 0) return 0;
+    if (S.flow.ready && (gs_flow_mode() == 2 || (gs_flow_mode() == 1 && S.flow_auto)))
+        return gs_flow_sweep(S.flow, bsr1, x, b, seq, nseq, st);
     const bool perm = S.perm && gs_chain_enabled() && gs_chain_generation() == 2;
     DevCsr G = S.G;
     G.owned = false;
@@ -2574,6 +2590,9 @@ void amg_set_stencil_pairs(int on) { amg::set_stencil_pairs(on); }
 void amg_set_sell_form(int on) { amg::set_sell_form(on); }
 void amg_set_gs_chain(int on) { amg::set_gs_chain(on); }
 void amg_set_gs_level_hint(int on) { amg::set_gs_level_hint(on); }
+void amg_set_gs_flow(int mode) { amg::set_gs_flow(mode); }
+void amg_set_gs_flow_lookahead(int levels) { amg::set_gs_flow_lookahead(levels); }
+int amg_gs_flow_status(void) { return amg::gs_flow_status(); }
 void amg_set_bsr_spmv(int on) { amg::set_bsr_spmv(on); }
 void amg_set_index16(int on) { amg::set_index16(on); }
 void amg_set_tile_target(int t) { amg::set_tile_target(t); }

@@ -48,6 +48,9 @@ struct Schedule {
     int *rows = nullptr;          // device
     DevBsr Gb;                    // BSR flavour with values: block rows copied in level order (streamed)
     std::vector<int> gb_level_slice;   // sliced block form of Gb (sell.hip): first slice of every level (empty: not built)
+    // dataflow form (gsflow.hip): the whole sequence of directional sweeps as one persistent launch
+    FlowForm flow;
+    bool flow_auto = false;            // the default picks it for this schedule (wide or long-row levels that would be launches)
     int nlevels() const { return (int)level_ptr.size() - 1; }
     void release();
 };

@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """Randomised cross-check of the Gauss-Seidel sweep paths: chained sweeps (LDS hand-off / memory hand-off), long-row
-chains, level launches with and without entry ranges in the kernel arguments -- against one plain launch per level,
+chains, level launches with and without entry ranges in the kernel arguments, the dataflow sweep (one persistent launch,
+three look-ahead settings) -- against one plain launch per level,
 bit for bit, and against the sequential reference loop (scipy-free restatement below) on the small cases.
 Matrices: banded, random sparse, 2-D / 3-D grid operators with random coefficients, Galerkin-like products (long rows),
 rows without a diagonal entry, zero diagonals, empty rows.  usage: stress_gs.py [seed=0] [cases=60]"""
-import sys, os, numpy as np, scipy.sparse as sp
+import sys, os, ctypes, numpy as np, scipy.sparse as sp, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pyamg_amd import _lib, relaxation
 from pyamg_amd.aggregation import poisson
@@ -56,6 +57,27 @@ def make(rng, kind):
     return A
 
 
+def fused_sequences(A, b, rng, bsr1):
+    """a whole sequence of directional sweeps in one call (what the in-cycle smoothers issue): dataflow launches of up
+    to four sweeps against the level-scheduled paths, on device vectors"""
+    n = A.shape[0]
+    Ap, Aj, Ax = A.indptr.astype(np.int32), A.indices.astype(np.int32), np.ascontiguousarray(A.data)
+    seq = rng.randint(0, 2, size=int(rng.randint(1, 7))).astype(np.uint8)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    outs = []
+    for flow, la in ((0, 0), (2, 0), (2, 2), (2, 200)):
+        L.amg_set_gs_flow(flow); L.amg_set_gs_flow_lookahead(la)
+        m = L.amg_mat_create(0, n, n, _lib.ip(Ap), _lib.ip(Aj), _lib.dp(Ax))
+        _lib.check(L.amg_mat_build_gs(m, None, 0))
+        x = torch.from_numpy(np.cos(np.arange(n, dtype=float))).cuda(); bd = torch.from_numpy(b).cuda()
+        _lib.check(L.amg_mat_gs_sweeps(m, ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(bd.data_ptr()), seq.ctypes.data_as(ctypes.c_void_p), len(seq), int(bsr1), st))
+        torch.cuda.synchronize()
+        outs.append(x.cpu().numpy())
+        L.amg_mat_destroy(m)
+    L.amg_set_gs_flow(1); L.amg_set_gs_flow_lookahead(0)
+    return all(np.array_equal(outs[0], v) for v in outs[1:]) and L.amg_gs_flow_status() == 0, len(seq)
+
+
 def main():
     seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     ncase = int(sys.argv[2]) if len(sys.argv) > 2 else 60
@@ -69,22 +91,27 @@ def main():
         sweep = ("forward", "backward", "symmetric")[int(rng.randint(0, 3))]
         M = A if rng.rand() < 0.6 else sp.bsr_matrix(A, blocksize=(1, 1))
         out = {}
-        for chain, hint in ((0, 0), (2, 1), (1, 1), (0, 1), (2, 0)):
-            L.amg_set_gs_chain(chain); L.amg_set_gs_level_hint(hint)
+        its = int(rng.randint(1, 4))
+        for chain, hint, flow, la in ((0, 0, 0, 0), (2, 1, 0, 0), (1, 1, 0, 0), (0, 1, 0, 0), (2, 0, 0, 0), (2, 1, 2, 0), (2, 1, 2, 1), (2, 1, 2, 64)):
+            L.amg_set_gs_chain(chain); L.amg_set_gs_level_hint(hint); L.amg_set_gs_flow(flow); L.amg_set_gs_flow_lookahead(la)
             x = np.cos(np.arange(n, dtype=float))
-            relaxation.gauss_seidel(M, x, b, iterations=2, sweep=sweep)
-            out[(chain, hint)] = x
-        L.amg_set_gs_chain(2); L.amg_set_gs_level_hint(1)
-        ok = all(np.array_equal(out[(0, 0)], v) for v in out.values())
+            relaxation.gauss_seidel(M, x, b, iterations=its, sweep=sweep)
+            out[(chain, hint, flow, la)] = x
+        L.amg_set_gs_chain(2); L.amg_set_gs_level_hint(1); L.amg_set_gs_flow(1); L.amg_set_gs_flow_lookahead(0)
+        if L.amg_gs_flow_status() != 0:
+            print("case %d: a dataflow sweep ran out of its time budget" % case); bad += 1
+        ok = all(np.array_equal(out[(0, 0, 0, 0)], v) for v in out.values())
         ref = ""
         if n <= 1500 and not sp.isspmatrix_bsr(M):
-            xs = sequential(A, np.cos(np.arange(n, dtype=float)), b, sweep)
-            xs = sequential(A, xs, b, sweep)
-            same = np.array_equal(xs, out[(0, 0)])
+            xs = np.cos(np.arange(n, dtype=float))
+            for _ in range(its): xs = sequential(A, xs, b, sweep)
+            same = np.array_equal(xs, out[(0, 0, 0, 0)])
             ok = ok and same
             ref = " sequential loop equal: %s" % same
+        fused, nseq = fused_sequences(A, b, rng, sp.isspmatrix_bsr(M))
+        ok = ok and fused
         bad += 0 if ok else 1
-        print("case %3d kind %d n %6d nnz/row %5.1f %-9s %-4s all paths equal: %s%s" % (case, kind, n, A.nnz / max(n, 1), sweep, "bsr1" if sp.isspmatrix_bsr(M) else "csr", ok, ref), flush=True)
+        print("case %3d kind %d n %6d nnz/row %5.1f %-9s x%d %-4s all paths equal: %s%s  fused sequence of %d sweeps equal: %s" % (case, kind, n, A.nnz / max(n, 1), sweep, its, "bsr1" if sp.isspmatrix_bsr(M) else "csr", ok, ref, nseq, fused), flush=True)
     print("FAILED: %d" % bad if bad else "all %d cases equal" % ncase)
     return 1 if bad else 0
 
