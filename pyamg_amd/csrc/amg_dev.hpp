@@ -313,6 +313,26 @@ struct FlowForm {
 int build_flow_form(FlowForm &F, int n, int ntasks, const std::vector<int> &level_ptr, const std::vector<int> &rowmap,
                     const std::vector<int> &gp, const std::vector<int> &gj, const std::vector<double> &gx);
 int gs_flow_sweep(const FlowForm &F, bool bsr1, double *x, const double *b, const unsigned char *seq, int nseq, hipStream_t st);
+// block Gauss-Seidel (relaxation.h:756-810) the same way: a lane per SCALAR row, LPR lanes per scalar row, FLOW_SEG
+// blocks per lane; positions count block rows, the iterate buffers hold bs scalars per block row
+struct BlockFlowForm {
+    bool ready = false;
+    int nb = 0, bs = 0, nchunks = 0, nlevels = 0, lpr = 1;
+    long slot_rows = 0;
+    int *rows = nullptr;                // [nb] original block row of position k
+    FlowChunk *meta = nullptr;
+    int *col = nullptr;                 // [slot_rows * (64 / bs)] block position of the slot's operand (nb: the permanent zero block)
+    double *val = nullptr;              // [slot_rows * bs * 64]: slot, column inside the block, lane
+    int *gate_f = nullptr, *gate_b = nullptr;   // [nb]
+    double *bp = nullptr;               // [nb * bs]
+    double *X = nullptr;                // [(FLOW_MAXSEQ + 1) * xstride]
+    long xstride = 0;
+    long bytes = 0;
+    void release();
+};
+int build_block_flow_form(BlockFlowForm &F, int nb, int bs, int ntasks, const std::vector<int> &level_ptr, const std::vector<int> &rows,
+                          const std::vector<int> &gp, const std::vector<int> &gj, const std::vector<double> &gx);
+int block_flow_sweep(const BlockFlowForm &F, const double *Dinv, double *x, const double *b, const unsigned char *seq, int nseq, hipStream_t st);
 int gs_flow_mode();                     // 0 off, 1 where it measured faster (default), 2 wherever the form exists
 void set_gs_flow(int mode);
 void set_gs_flow_lookahead(int levels);

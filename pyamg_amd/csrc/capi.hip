@@ -17,7 +17,7 @@ void expand_bsr(int nbrows, int R, int C, const int *Ap, const int *Aj, const do
                 std::vector<int> &cp, std::vector<int> &cj, std::vector<double> &cx);
 }
 namespace amg {
-int gs_sweep_csr(const Schedule &S, bool bsr1, double *x, const double *b, bool reverse, hipStream_t st);
+int gs_sweep_csr(const Schedule &S, bool bsr1, double *x, const double *b, bool reverse, hipStream_t st, bool allow_flow = true);
 }
 using namespace amg;
 
@@ -336,7 +336,8 @@ int amgcore_block_gauss_seidel_f64(const int Ap[], int Ap_size, const int Aj[], 
     CHK(dx.from_host(x, sizeof(double) * (size_t)x_size));
     CHK(db.from_host(b, sizeof(double) * (size_t)b_size));
     CHK(dd.from_host(Tx, sizeof(double) * (size_t)Tx_size));
-    CHK(sweep_block_schedule(sh.S, BM_BLOCK_GS, dd.d(), dx.d(), dx.d(), db.d(), 1.0, false, nullptr));
+    const unsigned char fwd = 0;
+    CHK(block_gs_sweeps(sh.S, dd.d(), dx.d(), db.d(), &fwd, 1, nullptr));
     AMG_HIP(hipDeviceSynchronize());
     return dx.to_host(x, sizeof(double) * (size_t)x_size);
 }

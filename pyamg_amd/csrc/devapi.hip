@@ -8,8 +8,8 @@
 
 namespace amg {
 int upload_csr(DevCsr &M, int nrows, int ncols, const int *Ap, const int *Aj, const double *Ax, long *acct);
-int gs_sweep_csr(const Schedule &S, bool bsr1, double *x, const double *b, bool reverse, hipStream_t st);
-int gs_sweep_csr(const Schedule &S, bool bsr1, double *x, const double *b, const unsigned char *seq, int nseq, hipStream_t st);
+int gs_sweep_csr(const Schedule &S, bool bsr1, double *x, const double *b, bool reverse, hipStream_t st, bool allow_flow = true);
+int gs_sweep_csr(const Schedule &S, bool bsr1, double *x, const double *b, const unsigned char *seq, int nseq, hipStream_t st, bool allow_flow = true);
 int try_patterns(DevCsr &M, const int *Ap, const int *Aj, long *acct);
 int apply_operator(const DevCsr &M, StreamMode mode, const StreamArgs &a, hipStream_t st);
 void free_csr(DevCsr &M);

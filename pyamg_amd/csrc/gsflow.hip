@@ -238,7 +238,182 @@ __global__ __launch_bounds__(64) void gs_flow_kernel(const FlowChunk *__restrict
     }
 }
 
-int g_flow_mode = 1;
+// ---------------------------------------------------------------------------------------------------------------
+// Block Gauss-Seidel (relaxation.h:756-810): x_i = Dinv_i (b_i - sum_{j != i} A_ij x_j), block rows in sequence.  A lane
+// per SCALAR row r of a block row, LPR lanes per scalar row: lane (block row, g, r) owns blocks [g * seg, (g + 1) * seg) of
+// its block row -- row r of each -- and forms v = sum_c a[r][c] x_j[c] from 0 for them (linalg.h gemm); the g = 0 lane adds
+// the v's of all groups in stored order, the BS leaders of a block row exchange b - rsum by shuffles and apply Dinv.
+// Same arithmetic as bsr_stream_kernel / bsell_kernel<BM_BLOCK_GS>.
+struct BlockFlowArgs {
+    unsigned long long *X;
+    double *x_out;
+    const double *Dinv;
+    int *status;
+    long xstride;
+    long long budget;
+    int nchunks, nseq, nb;
+    unsigned dirmask;
+};
+
+template <int BS>
+__global__ __launch_bounds__(256) void bflow_gather_kernel(const int *rows, const double *x, const double *b, unsigned long long *X,
+                                                            double *bp, long xstride, int nb, int nseq)
+{
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    const long n = (long)nb * BS;
+    if (p >= n + BS) return;
+    if (p >= n) {
+        for (int s = 0; s <= nseq; ++s) X[(long)s * xstride + p] = 0ULL;
+        return;
+    }
+    const long kb = p / BS;
+    const int r = (int)(p - kb * BS);
+    const long i = (long)rows[kb] * BS + r;
+    unsigned long long xb = (unsigned long long)__double_as_longlong(x[i]);
+    if (xb == FLOW_SENT) xb |= FLOW_QUIET;
+    X[p] = xb;
+    bp[p] = b[i];
+    for (int s = 1; s <= nseq; ++s) X[(long)s * xstride + p] = FLOW_SENT;
+}
+
+template <int BS, int LPR>
+__global__ __launch_bounds__(64) void bgs_flow_kernel(const FlowChunk *__restrict__ meta, const int *__restrict__ col,
+                                                       const double *__restrict__ val, const double *__restrict__ bp,
+                                                       const int *__restrict__ rows, const int *__restrict__ gate_f,
+                                                       const int *__restrict__ gate_b, BlockFlowArgs a)
+{
+    constexpr int SEG = FLOW_SEG, NG = 64 / BS, LW = BS * LPR, NBR = 64 / LW;
+    __shared__ double prod[LPR > 1 ? SEG * 64 : 1];
+    const int lane = threadIdx.x;
+    const int br = lane / LW, grp = lane / BS, r = lane - grp * BS;
+    const int NW = (int)gridDim.x;
+    const long long t0 = wall_clock64();
+    int s = 0, q = (int)blockIdx.x;
+    while (q >= a.nchunks) { q -= a.nchunks; ++s; }
+    while (s < a.nseq) {
+        const bool rev = ((a.dirmask >> s) & 1u) != 0;
+        const int c = rev ? a.nchunks - 1 - q : q;
+        const FlowChunk m = meta[c];
+        const int seg = m.nslots;
+        const bool rowok = br < m.nrows && br < NBR;
+        const bool leader = rowok && (lane - br * LW) < BS;                  // g == 0: lanes (block row, 0, r)
+        const int kb = m.row0 + (rowok ? br : 0);
+        int bc[SEG];
+        double v[SEG][BS];
+        const int smax = seg > 0 ? seg - 1 : 0;
+        const int gcl = min(grp, NG - 1);
+#pragma unroll
+        for (int u = 0; u < SEG; ++u) {
+            const long su = (long)m.off + min(u, smax);
+            bc[u] = col[su * NG + gcl];
+#pragma unroll
+            for (int cc = 0; cc < BS; ++cc) v[u][cc] = val[(su * BS + cc) * 64 + lane];
+        }
+        double bb = 0.0;
+        int orow = 0, gate = a.nb;
+        const bool last = s == a.nseq - 1;
+        if (leader) {
+            bb = bp[(long)kb * BS + r];
+            gate = rev ? gate_b[kb] : gate_f[kb];
+            orow = rows[kb];
+        }
+        const unsigned long long *Xo = a.X + (long)s * a.xstride;
+        unsigned long long *Xn = a.X + (long)(s + 1) * a.xstride;
+        {
+            const unsigned long long *gp_ = Xn + (long)gate * BS + r;
+            unsigned long long gv = ald(gp_);
+            for (unsigned spin = 0; __any(gv == FLOW_SENT); ++spin) {
+                __builtin_amdgcn_s_sleep(4);
+                if ((spin & 31u) == 31u && wall_clock64() - t0 > a.budget) {
+                    if (lane == 0) __hip_atomic_store(a.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    return;
+                }
+                if (gv == FLOW_SENT) gv = ald(gp_);
+            }
+        }
+        const int xs = (int)a.xstride;
+        int idx[SEG];
+        unsigned long long xb[SEG][BS];
+#pragma unroll
+        for (int u = 0; u < SEG; ++u) {
+            const bool real = u < seg && seg > 0 && lane < NG * BS;
+            const int cb = real ? bc[u] : a.nb;
+#pragma unroll
+            for (int cc = 0; cc < BS; ++cc) v[u][cc] = real ? v[u][cc] : 0.0;
+            const bool fresh = rev ? (cb >= m.lvl_hi) : (cb < m.lvl_lo);
+            idx[u] = cb * BS + (fresh ? xs : 0);
+#pragma unroll
+            for (int cc = 0; cc < BS; ++cc) xb[u][cc] = ald(Xo + idx[u] + cc);
+        }
+        for (unsigned spin = 0;; ++spin) {
+            bool bad = false;
+#pragma unroll
+            for (int u = 0; u < SEG; ++u)
+#pragma unroll
+                for (int cc = 0; cc < BS; ++cc) bad |= (xb[u][cc] == FLOW_SENT);
+            if (!__any(bad)) break;
+            if (AMG_FLOW_SLEEP > 0) __builtin_amdgcn_s_sleep(AMG_FLOW_SLEEP);
+            if ((spin & 31u) == 31u && wall_clock64() - t0 > a.budget) {
+                if (lane == 0) __hip_atomic_store(a.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+#pragma unroll
+            for (int u = 0; u < SEG; ++u)
+#pragma unroll
+                for (int cc = 0; cc < BS; ++cc)
+                    if (xb[u][cc] == FLOW_SENT) xb[u][cc] = ald(Xo + idx[u] + cc);
+        }
+        double vb[SEG];
+#pragma unroll
+        for (int u = 0; u < SEG; ++u) {
+            double w = 0.0;
+#pragma unroll
+            for (int cc = 0; cc < BS; ++cc) w = w + v[u][cc] * __longlong_as_double((long long)xb[u][cc]);
+            vb[u] = w;
+        }
+        double rsum = 0.0;
+        if constexpr (LPR == 1) {
+#pragma unroll
+            for (int u = 0; u < SEG; ++u) rsum = rsum + vb[u];
+        } else {
+#pragma unroll
+            for (int u = 0; u < SEG; ++u) prod[u * 64 + lane] = vb[u];
+            flow_wave_sync();
+            if (leader) {
+                constexpr int GB = LPR < 4 ? LPR : 4;
+#pragma unroll 1
+                for (int g0 = 0; g0 < LPR; g0 += GB) {
+                    double p[GB * SEG];
+#pragma unroll
+                    for (int g = 0; g < GB; ++g)
+#pragma unroll
+                        for (int u = 0; u < SEG; ++u) p[g * SEG + u] = prod[u * 64 + lane + (g0 + g) * BS];
+#pragma unroll
+                    for (int w = 0; w < GB * SEG; ++w) rsum = rsum + p[w];
+                }
+            }
+            flow_wave_sync();
+        }
+        // x_i = Dinv_i (b_i - rsum): the BS leaders of the block row exchange their entries of b - rsum
+        const double t = bb - rsum;
+        double vD = 0.0;
+        const int base = br * LW;
+#pragma unroll
+        for (int cc = 0; cc < BS; ++cc) {
+            const double tc = __shfl(t, base + cc, 64);
+            const double d = leader ? a.Dinv[(long)orow * (BS * BS) + r * BS + cc] : 0.0;
+            vD = vD + d * tc;
+        }
+        if (leader) {
+            __hip_atomic_store(Xn + (long)kb * BS + r, (unsigned long long)__double_as_longlong(vD), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (last) a.x_out[(long)orow * BS + r] = vD;
+        }
+        q += NW;
+        while (q >= a.nchunks) { q -= a.nchunks; ++s; }
+    }
+}
+
+int g_flow_mode = std::getenv("AMG_GS_FLOW") ? std::atoi(std::getenv("AMG_GS_FLOW")) : 1;   // A/B runs of tools without a knob of their own
 int g_flow_la = 0;              // look-ahead in levels; 0: default
 int *g_status = nullptr;        // device word, one per process and device (first use)
 int g_status_dev = -1;
@@ -259,6 +434,13 @@ int flow_status_word(int **out)
     return 0;
 }
 
+// one-wave workgroups a compute unit is asked to hold at most (the occupancy query is the other bound)
+int flow_wpc()
+{
+    static const int w = std::getenv("AMG_FLOW_WPC") ? std::atoi(std::getenv("AMG_FLOW_WPC")) : 8;
+    return std::max(1, w);
+}
+
 template <int LPR>
 int flow_waves_cap(bool bsr1)
 {
@@ -273,7 +455,7 @@ int flow_waves_cap(bool bsr1)
         hipDeviceProp_t pr;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount;
         if (ncu < 1) ncu = 64;
-        c = std::max(16, ncu * std::min(nb, 8) * 3 / 4);
+        c = std::max(16, ncu * std::min(nb, flow_wpc()) * 3 / 4);
     }
     return c;
 }
@@ -294,6 +476,180 @@ int launch_flow(const FlowForm &F, bool bsr1, const FlowArgs &a, hipStream_t st)
     return 0;
 }
 
+template <int BS, int LPR>
+int launch_bflow(const BlockFlowForm &F, const BlockFlowArgs &a, hipStream_t st)
+{
+    static int cap = 0;
+    if (cap == 0) {
+        int nb = 0, dev = 0, ncu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, bgs_flow_kernel<BS, LPR>, 64, 0) != hipSuccess || nb < 1) nb = 1;
+        hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount;
+        if (ncu < 1) ncu = 64;
+        cap = std::max(16, ncu * std::min(nb, flow_wpc()) * 3 / 4);
+    }
+    const int la = g_flow_la > 0 ? g_flow_la : 4;
+    long nw = (long)la * ((F.nchunks + std::max(1, F.nlevels) - 1) / std::max(1, F.nlevels));
+    static const int minw = std::getenv("AMG_FLOW_MINW") ? std::atoi(std::getenv("AMG_FLOW_MINW")) : 32;
+    nw = std::max<long>(nw, minw);
+    nw = std::min<long>(nw, cap);
+    nw = std::min<long>(nw, (long)a.nseq * F.nchunks);
+    hipLaunchKernelGGL((bgs_flow_kernel<BS, LPR>), dim3((unsigned)nw), dim3(64), 0, st, F.meta, F.col, F.val, F.bp, F.rows, F.gate_f, F.gate_b, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "dataflow block Gauss-Seidel launch", __FILE__, __LINE__);
+    return 0;
+}
+
+template <int BS>
+int launch_bflow_bs(const BlockFlowForm &F, const BlockFlowArgs &a, hipStream_t st)
+{
+    switch (F.lpr) {
+    case 1: return launch_bflow<BS, 1>(F, a, st);
+    case 2: return launch_bflow<BS, 2>(F, a, st);
+    case 4: return launch_bflow<BS, 4>(F, a, st);
+    case 8: return launch_bflow<BS, 8>(F, a, st);
+    default: return launch_bflow<BS, 16>(F, a, st);
+    }
+}
+
+}  // namespace
+
+void BlockFlowForm::release()
+{
+    for (void *p : {(void *)rows, (void *)meta, (void *)col, (void *)val, (void *)bp, (void *)X, (void *)gate_f, (void *)gate_b})
+        if (p) hipFree(p);
+    rows = nullptr; meta = nullptr; col = nullptr; val = nullptr; bp = nullptr; X = nullptr; gate_f = gate_b = nullptr;
+    ready = false;
+    bytes = 0;
+}
+
+// rows / gp / gj / gx: the block schedule's level-ordered copy (block row k of it = original block row rows[k], ORIGINAL
+// block columns, blocks row-major)
+int build_block_flow_form(BlockFlowForm &F, int nb, int bs, int ntasks, const std::vector<int> &level_ptr, const std::vector<int> &rows,
+                          const std::vector<int> &gp, const std::vector<int> &gj, const std::vector<double> &gx)
+{
+    F.release();
+    const int nl = (int)level_ptr.size() - 1;
+    if (nb <= 0 || ntasks != nb || nl <= 0 || (bs != 2 && bs != 3)) return 0;
+    if ((double)nb * bs * (FLOW_MAXSEQ + 1) >= 2.0e9) return 0;
+    const long B2 = (long)bs * bs;
+    std::vector<int> cnt((size_t)nb), seen((size_t)nb, 0);
+    int longest = 0;
+    for (int k = 0; k < nb; ++k) {
+        const int i = rows[(size_t)k];
+        if (i < 0 || i >= nb || seen[(size_t)i]) return 0;
+        seen[(size_t)i] = 1;
+        int c = 0;
+        for (int q = gp[(size_t)k]; q < gp[(size_t)k + 1]; ++q) {
+            const int j = gj[(size_t)q];
+            if (j < 0 || j >= nb) return 0;
+            if (j != i) ++c;                                                    // diagonal blocks are not part of the sum (relaxation.h:785)
+        }
+        cnt[(size_t)k] = c;
+        longest = std::max(longest, c);
+    }
+    if (longest > FLOW_SEG * 16) return 0;
+    int lpr = 1;
+    while (lpr * FLOW_SEG < longest) lpr *= 2;
+    F.lpr = lpr; F.bs = bs;
+    const int NG = 64 / bs, R = 64 / (bs * lpr);                                // groups per wave, block rows per chunk
+    if (R < 1) return 0;
+    std::vector<int> ord((size_t)nb), pos_of((size_t)nb);
+    for (int l = 0; l < nl; ++l) {
+        const int lo = level_ptr[(size_t)l], hi = level_ptr[(size_t)l + 1];
+        for (int k = lo; k < hi; ++k) ord[(size_t)k] = k;
+        std::stable_sort(ord.begin() + lo, ord.begin() + hi, [&](int p, int q) { return cnt[(size_t)p] > cnt[(size_t)q]; });
+    }
+    for (int k = 0; k < nb; ++k) pos_of[(size_t)rows[(size_t)ord[(size_t)k]]] = k;
+    std::vector<FlowChunk> meta;
+    long slot_rows = 0;
+    for (int l = 0; l < nl; ++l) {
+        const int lo = level_ptr[(size_t)l], hi = level_ptr[(size_t)l + 1];
+        for (int r0 = lo; r0 < hi; r0 += R) {
+            FlowChunk m;
+            std::memset(&m, 0, sizeof(m));
+            m.row0 = r0; m.nrows = std::min(R, hi - r0);
+            m.nslots = (cnt[(size_t)ord[(size_t)r0]] + lpr - 1) / lpr;
+            m.lvl_lo = lo; m.lvl_hi = hi;
+            if (slot_rows > 2000000000L / (64L * bs)) return 0;
+            m.off = (int)slot_rows;
+            slot_rows += m.nslots;
+            meta.push_back(m);
+        }
+    }
+    std::vector<int> col((size_t)std::max(slot_rows, 1L) * NG, nb), rmap((size_t)nb), lev((size_t)nb), gf((size_t)nb, nb), gb((size_t)nb, nb);
+    std::vector<double> val((size_t)std::max(slot_rows, 1L) * bs * 64, 0.0);
+    for (int l = 0; l < nl; ++l)
+        for (int k = level_ptr[(size_t)l]; k < level_ptr[(size_t)l + 1]; ++k) lev[(size_t)k] = l;
+    for (const FlowChunk &m : meta)
+        for (int t = 0; t < m.nrows; ++t) {
+            const int kk = m.row0 + t;
+            const int k = ord[(size_t)kk], i = rows[(size_t)k];
+            rmap[(size_t)kk] = i;
+            const int lk = lev[(size_t)kk];
+            int j = 0, gfl = -1, gbl = nl;
+            for (int q = gp[(size_t)k]; q < gp[(size_t)k + 1]; ++q) {
+                const int cj = gj[(size_t)q];
+                if (cj == i) continue;
+                const int g = j / m.nslots, u = j % m.nslots;
+                const int pc = pos_of[(size_t)cj], lc = lev[(size_t)pc];
+                const int grp = t * lpr + g;                                    // lanes grp * bs .. grp * bs + bs - 1
+                col[((size_t)m.off + (size_t)u) * NG + (size_t)grp] = pc;
+                for (int r = 0; r < bs; ++r)
+                    for (int c = 0; c < bs; ++c)
+                        val[(((size_t)m.off + (size_t)u) * bs + (size_t)c) * 64 + (size_t)grp * bs + (size_t)r] = gx[(size_t)q * B2 + (size_t)r * bs + (size_t)c];
+                if (lc <= lk - 2 && lc > gfl) { gfl = lc; gf[(size_t)kk] = pc; }
+                if (lc >= lk + 2 && lc < gbl) { gbl = lc; gb[(size_t)kk] = pc; }
+                ++j;
+            }
+        }
+    F.nb = nb; F.nchunks = (int)meta.size(); F.nlevels = nl; F.slot_rows = slot_rows;
+    F.xstride = ((long)(nb + 1) * bs + 15) / 16 * 16;
+    long acct = 0;
+    FCHK(falloc(&F.rows, nb, &acct));
+    FCHK(falloc(&F.meta, (long)meta.size(), &acct));
+    FCHK(falloc(&F.col, (long)col.size(), &acct));
+    FCHK(falloc(&F.val, (long)val.size(), &acct));
+    FCHK(falloc(&F.bp, (long)nb * bs, &acct));
+    FCHK(falloc(&F.gate_f, nb, &acct));
+    FCHK(falloc(&F.gate_b, nb, &acct));
+    FCHK(falloc(&F.X, (FLOW_MAXSEQ + 1) * F.xstride, &acct));
+    AMG_HIP(hipMemcpy(F.rows, rmap.data(), sizeof(int) * (size_t)nb, hipMemcpyHostToDevice));
+    AMG_HIP(hipMemcpy(F.meta, meta.data(), sizeof(FlowChunk) * meta.size(), hipMemcpyHostToDevice));
+    AMG_HIP(hipMemcpy(F.col, col.data(), sizeof(int) * col.size(), hipMemcpyHostToDevice));
+    AMG_HIP(hipMemcpy(F.val, val.data(), sizeof(double) * val.size(), hipMemcpyHostToDevice));
+    AMG_HIP(hipMemcpy(F.gate_f, gf.data(), sizeof(int) * (size_t)nb, hipMemcpyHostToDevice));
+    AMG_HIP(hipMemcpy(F.gate_b, gb.data(), sizeof(int) * (size_t)nb, hipMemcpyHostToDevice));
+    F.bytes = acct;
+    F.ready = true;
+    return 0;
+}
+
+int block_flow_sweep(const BlockFlowForm &F, const double *Dinv, double *x, const double *b, const unsigned char *seq, int nseq, hipStream_t st)
+{
+    if (!F.ready) { set_error("dataflow block Gauss-Seidel form was not built"); return -3; }
+    int *status = nullptr;
+    FCHK(flow_status_word(&status));
+    for (int s0 = 0; s0 < nseq; s0 += FLOW_MAXSEQ) {
+        const int ns = std::min(FLOW_MAXSEQ, nseq - s0);
+        const long np = (long)(F.nb + 1) * F.bs;
+        if (F.bs == 3) hipLaunchKernelGGL((bflow_gather_kernel<3>), dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, F.rows, x, b, (unsigned long long *)F.X, F.bp, F.xstride, F.nb, ns);
+        else hipLaunchKernelGGL((bflow_gather_kernel<2>), dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, F.rows, x, b, (unsigned long long *)F.X, F.bp, F.xstride, F.nb, ns);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return hip_fail(e, "dataflow block gather launch", __FILE__, __LINE__);
+        BlockFlowArgs a;
+        std::memset(&a, 0, sizeof(a));
+        a.X = (unsigned long long *)F.X; a.x_out = x; a.Dinv = Dinv; a.status = status;
+        a.xstride = F.xstride; a.budget = 100000000LL * 4;
+        a.nchunks = F.nchunks; a.nseq = ns; a.nb = F.nb;
+        for (int k = 0; k < ns; ++k) a.dirmask |= (seq[s0 + k] != 0 ? 1u : 0u) << k;
+        if (F.bs == 3) FCHK(launch_bflow_bs<3>(F, a, st));
+        else FCHK(launch_bflow_bs<2>(F, a, st));
+    }
+    return 0;
+}
+
+namespace {
 }  // namespace
 
 void FlowForm::release()

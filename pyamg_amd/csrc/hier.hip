@@ -407,6 +407,7 @@ void Schedule::release()
     if (level_ptr_dev) hipFree(level_ptr_dev);
     free_bsr(Gb);
     flow.release();
+    bflow.release();
     rowmap = diagpos = rows = level_ptr_dev = nullptr;
     for (int *p : {c2_code_f, c2_code_b, c2_off, perm_Aj, cl_code_f, cl_code_b}) if (p) hipFree(p);
     cl_code_f = cl_code_b = nullptr;
@@ -785,8 +786,11 @@ int build_block_schedule(const int *Ap, const int *Aj, int nb, const int *tasks,
             std::memcpy(gx.data() + (long)gp[k] * B2, Ax + (long)Ap[i] * B2, sizeof(double) * (size_t)(len * B2));
         }
         CHK(upload_bsr(S.Gb, ntasks, bs, gp.data(), gj.data(), gx.data(), nullptr));
-        // block Gauss-Seidel levels of a large operator: one launch per level from the sliced block form
-        if (!independent) CHK(build_bsell_levels(S.Gb, S.level_ptr, S.rows, S.gb_level_slice, nullptr));
+        // block Gauss-Seidel: the dataflow form (one persistent launch per smoother application), else for the levels of
+        // a large operator one launch per level from the sliced block form
+        if (!independent && gs_flow_mode() != 0 && (bs == 2 || bs == 3))
+            CHK(build_block_flow_form(S.bflow, nb, bs, ntasks, S.level_ptr, rows, gp, gj, gx));
+        if (!independent && !S.bflow.ready) CHK(build_bsell_levels(S.Gb, S.level_ptr, S.rows, S.gb_level_slice, nullptr));
     }
     return 0;
 }
@@ -855,10 +859,10 @@ int spmv(const DevCsr &M, StreamMode mode, const double *xg, const double *b, co
 // second-generation chain the sweeps run in LEVEL-ORDER numbering on gathered copies of x and b (one gather before,
 // one scatter after the whole sequence): every access of a level is then contiguous over the lanes.
 int gs_sweep_csr(const Schedule &S, bool bsr1, double *x, const double *b, const unsigned char *seq, int nseq,
-                 hipStream_t st)
+                 hipStream_t st, bool allow_flow)
 {
     if (nseq <= 0) return 0;
-    if (S.flow.ready && (gs_flow_mode() == 2 || (gs_flow_mode() == 1 && S.flow_auto)))
+    if (allow_flow && S.flow.ready && (gs_flow_mode() == 2 || (gs_flow_mode() == 1 && S.flow_auto)))
         return gs_flow_sweep(S.flow, bsr1, x, b, seq, nseq, st);
     const bool perm = S.perm && gs_chain_enabled() && gs_chain_generation() == 2;
     DevCsr G = S.G;
@@ -909,10 +913,10 @@ int gs_sweep_csr(const Schedule &S, bool bsr1, double *x, const double *b, const
     return 0;
 }
 
-int gs_sweep_csr(const Schedule &S, bool bsr1, double *x, const double *b, bool reverse, hipStream_t st)
+int gs_sweep_csr(const Schedule &S, bool bsr1, double *x, const double *b, bool reverse, hipStream_t st, bool allow_flow)
 {
     const unsigned char r = reverse ? 1 : 0;
-    return gs_sweep_csr(S, bsr1, x, b, &r, 1, st);
+    return gs_sweep_csr(S, bsr1, x, b, &r, 1, st, allow_flow);
 }
 
 // one directional pass over the block rows of a schedule built WITH values (Schedule::Gb: the rows copied in level
@@ -944,6 +948,14 @@ static int gs_sweep_block(const Schedule &S, const DevBsr &Ab, BlockMode mode, c
 {
     (void)Ab;
     return sweep_block_schedule(S, mode, Dinv, x, x, b, 1.0, reverse, st);
+}
+
+int block_gs_sweeps(const Schedule &S, const double *Dinv, double *x, const double *b, const unsigned char *seq, int nseq, hipStream_t st,
+                    bool allow_flow)
+{
+    if (allow_flow && S.bflow.ready && gs_flow_mode() != 0) return block_flow_sweep(S.bflow, Dinv, x, b, seq, nseq, st);
+    for (int k = 0; k < nseq; ++k) CHK(sweep_block_schedule(S, BM_BLOCK_GS, Dinv, x, x, b, 1.0, seq[k] != 0, st));
+    return 0;
 }
 
 static int bsr_stream_all(const DevBsr &Ab, BlockMode mode, const double *Dinv, const double *xin, double *xout,
@@ -1046,7 +1058,9 @@ static int relax(amg_hier *h, Level &L, Smoother &s, double *&x, double *&xalt, 
             CHK(exchange(h, L, x));
             if (point_block)
                 return gs_sweep_block(*s.sched, L.Ab, BM_BSR_GS, nullptr, x, b, reverse, st);
-            return gs_sweep_csr(*s.sched, bsr && s.kind != AMG_SM_GAUSS_SEIDEL_INDEXED, x, b, reverse, st);
+            // (several ranks may share one device: persistent dataflow launches of different processes could keep each
+            //  other's waves from becoming resident, so a partitioned hierarchy stays with the level-scheduled sweeps)
+            return gs_sweep_csr(*s.sched, bsr && s.kind != AMG_SM_GAUSS_SEIDEL_INDEXED, x, b, reverse, st, !h->comm);
         };
         auto gs = [&](int iterations, int sweep) -> int {
             if (!point_block && !h->comm) {
@@ -1057,7 +1071,7 @@ static int relax(amg_hier *h, Level &L, Smoother &s, double *&x, double *&xalt, 
                     else if (sweep == AMG_SWEEP_BACKWARD) seq.push_back(1);
                     else { seq.push_back(0); seq.push_back(1); }
                 }
-                return gs_sweep_csr(*s.sched, bsr && s.kind != AMG_SM_GAUSS_SEIDEL_INDEXED, x, b, seq.data(), (int)seq.size(), st);
+                return gs_sweep_csr(*s.sched, bsr && s.kind != AMG_SM_GAUSS_SEIDEL_INDEXED, x, b, seq.data(), (int)seq.size(), st, true);
             }
             for (int it = 0; it < iterations; ++it) {
                 if (sweep == AMG_SWEEP_FORWARD) CHK(sweep_once(false));
@@ -1198,14 +1212,12 @@ static int relax(amg_hier *h, Level &L, Smoother &s, double *&x, double *&xalt, 
     }
     case AMG_SM_BLOCK_GAUSS_SEIDEL: {
         // relaxation.py:509-590
-        const DevBsr &Ab = s.Ablk_owned ? s.Ablk : L.Ab;
+        std::vector<unsigned char> seq;
         for (int it = 0; it < s.iterations; ++it) {
-            if (s.sweep == AMG_SWEEP_FORWARD || s.sweep == AMG_SWEEP_SYMMETRIC)
-                CHK(gs_sweep_block(*s.sched, Ab, BM_BLOCK_GS, s.Dinv, x, b, false, st));
-            if (s.sweep == AMG_SWEEP_BACKWARD || s.sweep == AMG_SWEEP_SYMMETRIC)
-                CHK(gs_sweep_block(*s.sched, Ab, BM_BLOCK_GS, s.Dinv, x, b, true, st));
+            if (s.sweep == AMG_SWEEP_FORWARD || s.sweep == AMG_SWEEP_SYMMETRIC) seq.push_back(0);
+            if (s.sweep == AMG_SWEEP_BACKWARD || s.sweep == AMG_SWEEP_SYMMETRIC) seq.push_back(1);
         }
-        return 0;
+        return block_gs_sweeps(*s.sched, s.Dinv, x, b, seq.data(), (int)seq.size(), st, !h->comm);
     }
     }
     set_error("unknown smoother kind");
@@ -1774,6 +1786,7 @@ static int need_schedule(amg_hier *h, Level &L, Smoother &s)
                 L.sched_blk = std::make_shared<Schedule>();
                 CHK(build_block_schedule(bp.data(), bj.data(), L.Ab.nbrows, nullptr, L.Ab.nbrows, *L.sched_blk, h->stream,
                                          bx.data(), L.Ab.bs));
+                h->dev_bytes += L.sched_blk->bflow.bytes;
             }
             s.sched = L.sched_blk;
         } else {
@@ -1787,7 +1800,7 @@ static int need_schedule(amg_hier *h, Level &L, Smoother &s)
                 }
                 L.sched_csr = std::make_shared<Schedule>();
                 CHK(build_csr_schedule(ap.data(), aj.data(), ax.data(), n, nullptr, n, *L.sched_csr, h->stream));
-                h->dev_bytes += 12L * L.A.nnz + 12L * n;
+                h->dev_bytes += 12L * L.A.nnz + 12L * n + L.sched_csr->flow.bytes;
             }
             s.sched = L.sched_csr;
         }
@@ -2098,6 +2111,8 @@ static int store_x(amg_hier *h, double *x, int flags)
     hipMemcpyKind kind = (flags & AMG_SOLVE_DEVICE_VECTORS) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
     if (x != L0.x) AMG_HIP(hipMemcpyAsync(x, L0.x, bytes, kind, h->stream));
     AMG_HIP(hipStreamSynchronize(h->stream));
+    // a dataflow Gauss-Seidel sweep whose waves gave up waiting left unusable iterates behind: say so
+    if (gs_flow_status() != 0) { set_error("a dataflow Gauss-Seidel sweep ran out of its time budget (amg_set_gs_flow(0) selects the level-scheduled sweeps)"); return AMG_ESTATE; }
     return 0;
 }
 

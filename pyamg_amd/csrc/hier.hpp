@@ -50,6 +50,7 @@ struct Schedule {
     std::vector<int> gb_level_slice;   // sliced block form of Gb (sell.hip): first slice of every level (empty: not built)
     // dataflow form (gsflow.hip): the whole sequence of directional sweeps as one persistent launch
     FlowForm flow;
+    BlockFlowForm bflow;               // the same for block Gauss-Seidel over Gb
     bool flow_auto = false;            // the default picks it for this schedule (wide or long-row levels that would be launches)
     int nlevels() const { return (int)level_ptr.size() - 1; }
     void release();
@@ -63,6 +64,9 @@ int build_block_schedule(const int *Ap, const int *Aj, int nb, const int *tasks,
                          Schedule &S, hipStream_t st, const double *Ax = nullptr, int bs = 0, bool independent = false);
 int sweep_block_schedule(const Schedule &S, BlockMode mode, const double *Dinv, const double *xin, double *x, const double *b,
                          double omega, bool reverse, hipStream_t st);
+// block Gauss-Seidel: all directional sweeps of a smoother application (seq[k] != 0: backward); the dataflow form where built
+int block_gs_sweeps(const Schedule &S, const double *Dinv, double *x, const double *b, const unsigned char *seq, int nseq, hipStream_t st,
+                    bool allow_flow = true);
 
 struct Smoother {
     // AMG_SM_CALLBACK: the relaxation is driven from outside (the device-resident Krylov smoothers of

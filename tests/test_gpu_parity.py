@@ -840,7 +840,16 @@ def test_schwarz_definition_on_small_systems():
             assert np.allclose(x, want, rtol=1e-7, atol=1e-9), (n, sweep)
 
 
-def test_chained_gauss_seidel_equals_per_level_launches():
+@pytest.fixture
+def no_gs_flow():
+    """level-scheduled Gauss-Seidel paths only (chains, level launches): the dataflow sweep is switched off for the test"""
+    from pyamg_amd import _lib
+    _lib.lib().amg_set_gs_flow(0)
+    yield
+    _lib.lib().amg_set_gs_flow(1)
+
+
+def test_chained_gauss_seidel_equals_per_level_launches(no_gs_flow):
     """Runs of narrow dependency levels are swept by one workgroup in one launch (gs_chain2_kernel: new values handed
     on through LDS, everything else prefetched two levels ahead; gs_chain_kernel: the first generation).  Same
     bits as one launch per level and as the sequential oracle: 2-D 5-point operator (every level narrow),
@@ -1149,7 +1158,7 @@ def test_saved_hierarchy_reloads_to_bit_identical_iterates(case, tmp_path):
     assert np.array_equal(x, x2) and np.array_equal(res, res2)
 
 
-def test_chained_gauss_seidel_on_irregular_hierarchy_levels():
+def test_chained_gauss_seidel_on_irregular_hierarchy_levels(no_gs_flow):
     """The LDS hand-off chain on what it is built for and on what could break it: the README hierarchy's coarse
     levels (Ruge-Stuben: rows of 5..13 entries, operands one AND two dependency levels back, zero-free diagonals),
     a level with a zero diagonal entry (row left untouched, relaxation.h:58-60), and an index list in which a row
@@ -1188,7 +1197,7 @@ def test_chained_gauss_seidel_on_irregular_hierarchy_levels():
     assert np.array_equal(out[0], out[2])
 
 
-def test_long_row_chain_on_sa_coarse_levels():
+def test_long_row_chain_on_sa_coarse_levels(no_gs_flow):
     """Coarse levels of a smoothed-aggregation hierarchy (rows of 30-60 entries, a dozen to a few hundred rows per
     dependency level) are swept by gs_chainl_kernel: one workgroup per run of levels, entry-parallel products through
     LDS, one lane per row summing in stored order.  Same bits as one launch per level and as the sequential oracle,
@@ -1252,6 +1261,138 @@ def test_long_row_chain_on_sa_coarse_levels():
         outw[hint] = x
     _lib.lib().amg_set_gs_level_hint(1)
     assert np.array_equal(outw[0], outw[1])
+
+
+def test_dataflow_gauss_seidel_same_bits_as_level_launches_and_oracle():
+    """csrc/gsflow.hip: a whole sequence of directional sweeps as ONE persistent launch -- rows wait for their own operands
+    (sentinel-tagged values), no launch per dependency level.  Same bits as a launch per level and as the sequential
+    oracle (relaxation.h:34-62, :90-173 with 1x1 blocks): 3-D 7-point operator (one lane per row), the coarse levels
+    of a smoothed-aggregation hierarchy (rows of 30-60 entries: 4-8 lanes per row, products summed in stored order
+    through LDS), rows of more than 64 entries (16 lanes per row), an operator with a zero diagonal (the form declines:
+    such a row keeps its value), sequences of up to six sweeps fused into launches of four, several look-ahead settings;
+    and whole solves with the reference's default smoother."""
+    import ctypes as C
+    import torch
+    from pyamg_amd import _lib
+    from pyamg_amd.aggregation import poisson as native, smoothed_aggregation_solver
+    L = _lib.lib()
+    rng = np.random.RandomState(11)
+    sm = ("gauss_seidel", {"sweep": "symmetric"})
+    ml = smoothed_aggregation_solver(native((36, 34, 32)), presmoother=sm, postsmoother=sm, max_coarse=20)
+    mats = [sps.csr_matrix(native((23, 27, 31)))] + [sps.csr_matrix(lvl.A) for lvl in ml.levels[1:-1]]
+    W = sps.random(700, 700, density=0.18, random_state=3, format="csr") + sps.identity(700) * 40.0      # ~126 entries per row
+    mats.append(sps.csr_matrix(W))
+    Z = mats[1].tolil(); Z[5, 5] = 0.0; Z = sps.csr_matrix(Z); Z.eliminate_zeros()
+    mats.append(Z)
+    try:
+        for M0 in mats:
+            M0.sort_indices()
+            n = M0.shape[0]
+            b = rng.rand(n)
+            for M in (M0, sps.bsr_matrix(M0, blocksize=(1, 1))):
+                for sweep in ("forward", "backward", "symmetric"):
+                    out = {}
+                    for flow, la in ((0, 0), (2, 0), (2, 1), (2, 50)):
+                        L.amg_set_gs_flow(flow); L.amg_set_gs_flow_lookahead(la)
+                        x = np.cos(np.arange(n, dtype=float))
+                        relaxation.gauss_seidel(M, x, b, iterations=2, sweep=sweep)
+                        out[(flow, la)] = x
+                    for key in out:
+                        assert np.array_equal(out[(0, 0)], out[key]), (n, type(M).__name__, sweep, key)
+                    xo = np.cos(np.arange(n, dtype=float))
+                    keep = []
+                    m = oracle_lib.make_mat(M, keep)
+                    s = oracle_lib.make_smoother({"name": "gauss_seidel", "iterations": 2, "sweep": sweep}, M, keep)
+                    oracle_lib.load().oracle_relax(C.byref(m), C.byref(s), oracle_lib.dp(xo), oracle_lib.dp(b))
+                    assert np.array_equal(out[(2, 0)], xo), (n, type(M).__name__, sweep)
+            # sequences of sweeps in one call, as the in-cycle smoothers issue them (device vectors)
+            Ap, Aj, Ax = M0.indptr.astype(np.intc), M0.indices.astype(np.intc), np.ascontiguousarray(M0.data)
+            st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            for seq in ([0, 1], [1, 1, 0], [0, 1, 0, 1, 0, 0]):
+                sq = np.array(seq, dtype=np.uint8)
+                outs = []
+                for flow in (0, 2):
+                    L.amg_set_gs_flow(flow); L.amg_set_gs_flow_lookahead(0)
+                    mat = L.amg_mat_create(0, n, n, _lib.ip(Ap), _lib.ip(Aj), _lib.dp(Ax))
+                    _lib.check(L.amg_mat_build_gs(mat, None, 0))
+                    xd = torch.from_numpy(np.sin(np.arange(n, dtype=float))).cuda(); bd = torch.from_numpy(b).cuda()
+                    _lib.check(L.amg_mat_gs_sweeps(mat, C.c_void_p(xd.data_ptr()), C.c_void_p(bd.data_ptr()), sq.ctypes.data_as(C.c_void_p), len(seq), 0, st))
+                    torch.cuda.synchronize()
+                    outs.append(xd.cpu().numpy())
+                    L.amg_mat_destroy(mat)
+                assert np.array_equal(outs[0], outs[1]), (n, seq)
+        assert L.amg_gs_flow_status() == 0
+        # whole solves: the default picks the dataflow sweep on this 3-D hierarchy; identical to the level-scheduled paths
+        b = rng.rand(ml.levels[0].A.shape[0])
+        got = {}
+        for flow in (1, 0, 2):
+            L.amg_set_gs_flow(flow); L.amg_set_gs_flow_lookahead(0)
+            ml._invalidate_device()
+            res = []
+            got[flow] = (ml.solve(b, tol=0.0, maxiter=4, residuals=res), list(res))
+        assert np.array_equal(got[0][0], got[1][0]) and got[0][1] == got[1][1]
+        assert np.array_equal(got[0][0], got[2][0]) and got[0][1] == got[2][1]
+        levels, Mc = _oracle_levels(ml)
+        xo, reso = oracle_lib.Hierarchy(levels, Mc).solve(b, tol=0.0, maxiter=4)
+        assert np.array_equal(got[1][0], xo)
+    finally:
+        L.amg_set_gs_flow(1); L.amg_set_gs_flow_lookahead(0)
+        ml._invalidate_device()
+    assert L.amg_gs_flow_status() == 0
+
+
+@pytest.mark.parametrize("bs", [3, 2])
+def test_dataflow_block_gauss_seidel_same_bits(bs, oracle):
+    """block Gauss-Seidel (relaxation.h:756-810) as one persistent launch per smoother application (gsflow.hip
+    bgs_flow_kernel: a lane per scalar row, 1-8 lanes sharing a scalar row's blocks): same bits as the level-scheduled
+    sweep and the oracle on the tet-mesh operator (irregular block rows) and its Galerkin coarse level (block rows of
+    40+ blocks), flat entry point in both directions and whole solves."""
+    from pyamg_amd import _lib
+    from pyamg_amd.gallery import tet_diffusion
+    from pyamg_amd.aggregation import smoothed_aggregation_solver
+    from pyamg_amd.util import get_block_diag
+    L = _lib.lib()
+    rng = np.random.RandomState(17)
+    A3 = tet_diffusion(24 if bs == 3 else 22, blocksize=bs)
+    smoother = ("block_gauss_seidel", {"sweep": "symmetric", "blocksize": bs, "iterations": 2})
+    np.random.seed(0)
+    ml = smoothed_aggregation_solver(A3, presmoother=smoother, postsmoother=smoother, max_coarse=40)
+    assert len(ml.levels) >= 3
+    try:
+        for A in [lvl.A for lvl in ml.levels[:-1]]:
+            A = sps.bsr_matrix(A, blocksize=(bs, bs))
+            n, nb = A.shape[0], A.shape[0] // bs
+            b = rng.rand(n)
+            Dinv = get_block_diag(A, bs, inv_flag=True)
+            Ap, Aj, Ax = A.indptr.astype(np.intc), A.indices.astype(np.intc), np.ravel(A.data).copy()
+            for (rs, re, rt) in ((0, nb, 1), (nb - 1, -1, -1)):
+                out = {}
+                for flow, la in ((0, 0), (2, 0), (2, 1), (2, 40)):
+                    L.amg_set_gs_flow(flow); L.amg_set_gs_flow_lookahead(la)
+                    x = np.cos(np.arange(n, dtype=float))
+                    amg_core.block_gauss_seidel(Ap, Aj, Ax, x, b, np.ravel(Dinv), rs, re, rt, bs)
+                    out[(flow, la)] = x
+                for key in out:
+                    assert np.array_equal(out[(0, 0)], out[key]), (n, rs, key)
+                xo = np.cos(np.arange(n, dtype=float))
+                oracle.oracle_block_gauss_seidel(oracle_lib.ip(Ap), oracle_lib.ip(Aj), oracle_lib.dp(Ax), oracle_lib.dp(xo),
+                                                 oracle_lib.dp(b), oracle_lib.dp(np.ravel(Dinv).copy()), rs, re, rt, bs)
+                assert np.array_equal(out[(2, 0)], xo), (n, rs)
+        b = rng.rand(A3.shape[0])
+        got = {}
+        for flow in (1, 0):
+            L.amg_set_gs_flow(flow); L.amg_set_gs_flow_lookahead(0)
+            ml._invalidate_device()
+            res = []
+            got[flow] = (ml.solve(b, tol=0.0, maxiter=3, residuals=res), list(res))
+        assert np.array_equal(got[0][0], got[1][0]) and got[0][1] == got[1][1]
+        levels, Mc = _oracle_levels(ml)
+        xo, reso = oracle_lib.Hierarchy(levels, Mc).solve(b, tol=0.0, maxiter=3)
+        assert np.array_equal(got[1][0], xo)
+    finally:
+        L.amg_set_gs_flow(1); L.amg_set_gs_flow_lookahead(0)
+        ml._invalidate_device()
+    assert L.amg_gs_flow_status() == 0
 
 
 # ---------------------------------------------------------------------------
