@@ -88,6 +88,8 @@ def host_lib():
         L.amgsetup_kuhn_p1_diffusion.restype = C.c_int64
         L.amgsetup_greedy_coloring.argtypes = [C.c_int, ip, ip, ip]
         L.amgsetup_greedy_coloring.restype = C.c_int
+        L.amgsetup_pattern_symmetric.argtypes = [C.c_int, ip, ip]
+        L.amgsetup_pattern_symmetric.restype = C.c_int
         L.amgsetup_extract_subblocks.argtypes = [ip, ip, dp, dp, ip, ip, ip, C.c_int, C.c_int]
         L.amgsetup_extract_subblocks.restype = None
         L.amgsetup_num_threads.restype = C.c_int
@@ -123,12 +125,17 @@ def greedy_colouring(A):
     M = A if (isspmatrix_csr(A) or isspmatrix_bsr(A)) else csr_matrix(A)
     if isspmatrix_bsr(M) and M.blocksize != (1, 1):
         M = M.tocsr()
-    S = csr_matrix((np.ones(len(M.indices), dtype=np.int8), M.indices, M.indptr), shape=M.shape)
-    S = (S + S.T).tocsr()                     # a colouring must respect both a_ij and a_ji
-    Ap = np.ascontiguousarray(S.indptr, dtype=np.intc)
-    Aj = np.ascontiguousarray(S.indices, dtype=np.intc)
-    colour = np.empty(S.shape[0], dtype=np.intc)
-    ncol = host_lib().amgsetup_greedy_coloring(S.shape[0], _ip(Ap), _ip(Aj), _ip(colour))
+    Ap = np.ascontiguousarray(M.indptr, dtype=np.intc)
+    Aj = np.ascontiguousarray(M.indices, dtype=np.intc)
+    if not host_lib().amgsetup_pattern_symmetric(M.shape[0], _ip(Ap), _ip(Aj)):
+        # a colouring must respect both a_ij and a_ji (a structurally symmetric pattern -- the usual case -- needs no
+        # symmetrised copy: first-fit only looks at neighbour SETS)
+        S = csr_matrix((np.ones(len(M.indices), dtype=np.int8), M.indices, M.indptr), shape=M.shape)
+        S = (S + S.T).tocsr()
+        Ap = np.ascontiguousarray(S.indptr, dtype=np.intc)
+        Aj = np.ascontiguousarray(S.indices, dtype=np.intc)
+    colour = np.empty(M.shape[0], dtype=np.intc)
+    ncol = host_lib().amgsetup_greedy_coloring(M.shape[0], _ip(Ap), _ip(Aj), _ip(colour))
     return colour, ncol
 
 

@@ -253,6 +253,7 @@ struct BlockFlowArgs {
     long long budget;
     int nchunks, nseq, nb;
     unsigned dirmask;
+    int prefetch;               // request the next task's matrix data before waiting for the current task's operands
 };
 
 template <int BS>
@@ -276,140 +277,187 @@ __global__ __launch_bounds__(256) void bflow_gather_kernel(const int *rows, cons
     for (int s = 1; s <= nseq; ++s) X[(long)s * xstride + p] = FLOW_SENT;
 }
 
+// what a block task needs that does not depend on the sweep's values: chunk descriptor, block columns, values, and the
+// block row's own right-hand side / gate / row number.  Two of these live in registers: the NEXT task's is requested
+// before the current task starts waiting for its operands, so that on wide levels (more chunks per level than resident
+// waves: no look-ahead left between tasks) the matrix stream does not wait for the dependency chain.
+template <int BS>
+struct BlockTask {
+    FlowChunk m;
+    int bc[FLOW_SEG];
+    double v[FLOW_SEG][BS];
+    double bb;
+    int gate, orow, s;
+    bool valid;
+};
+
+template <int BS, int LPR>
+__device__ __forceinline__ void bflow_load(BlockTask<BS> &T, int s, int q, const FlowChunk *__restrict__ meta, const int *__restrict__ col,
+                                            const double *__restrict__ val, const double *__restrict__ bp, const int *__restrict__ rows,
+                                            const int *__restrict__ gate_f, const int *__restrict__ gate_b, const BlockFlowArgs &a)
+{
+    constexpr int SEG = FLOW_SEG, NG = 64 / BS, LW = BS * LPR, NBR = 64 / LW;
+    T.valid = s < a.nseq;
+    T.s = s;
+    if (!T.valid) return;
+    const int lane = threadIdx.x;
+    const int br = lane / LW, grp = lane / BS, r = lane - grp * BS;
+    const bool rev = ((a.dirmask >> s) & 1u) != 0;
+    const int c = rev ? a.nchunks - 1 - q : q;
+    T.m = meta[c];
+    const int seg = T.m.nslots;
+    const int smax = seg > 0 ? seg - 1 : 0;
+    const int gcl = min(grp, NG - 1);
+#pragma unroll
+    for (int u = 0; u < SEG; ++u) {
+        const long su = (long)T.m.off + min(u, smax);
+        T.bc[u] = col[su * NG + gcl];
+#pragma unroll
+        for (int cc = 0; cc < BS; ++cc) T.v[u][cc] = val[(su * BS + cc) * 64 + lane];
+    }
+    const bool rowok = br < T.m.nrows && br < NBR;
+    const bool leader = rowok && (lane - br * LW) < BS;
+    const int kb = T.m.row0 + (rowok ? br : 0);
+    T.bb = 0.0; T.orow = 0; T.gate = a.nb;
+    if (leader) {
+        T.bb = bp[(long)kb * BS + r];
+        T.gate = rev ? gate_b[kb] : gate_f[kb];
+        T.orow = rows[kb];
+    }
+}
+
+// returns false when the wave ran out of its time budget
+template <int BS, int LPR>
+__device__ __forceinline__ bool bflow_run(BlockTask<BS> &T, double *prod, long long t0, const BlockFlowArgs &a)
+{
+    constexpr int SEG = FLOW_SEG, NG = 64 / BS, LW = BS * LPR, NBR = 64 / LW;
+    const int lane = threadIdx.x;
+    const int br = lane / LW, grp = lane / BS, r = lane - grp * BS;
+    const FlowChunk &m = T.m;
+    const int s = T.s, seg = m.nslots;
+    const bool rev = ((a.dirmask >> s) & 1u) != 0;
+    const bool last = s == a.nseq - 1;
+    const bool rowok = br < m.nrows && br < NBR;
+    const bool leader = rowok && (lane - br * LW) < BS;                  // g == 0: lanes (block row, 0, r)
+    const int kb = m.row0 + (rowok ? br : 0);
+    const unsigned long long *Xo = a.X + (long)s * a.xstride;
+    unsigned long long *Xn = a.X + (long)(s + 1) * a.xstride;
+    {
+        const unsigned long long *gp_ = Xn + (long)T.gate * BS + r;
+        unsigned long long gv = ald(gp_);
+        for (unsigned spin = 0; __any(gv == FLOW_SENT); ++spin) {
+            __builtin_amdgcn_s_sleep(4);
+            if ((spin & 31u) == 31u && wall_clock64() - t0 > a.budget) {
+                if (lane == 0) __hip_atomic_store(a.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+            }
+            if (gv == FLOW_SENT) gv = ald(gp_);
+        }
+    }
+    const int xs = (int)a.xstride;
+    int idx[SEG];
+    unsigned long long xb[SEG][BS];
+#pragma unroll
+    for (int u = 0; u < SEG; ++u) {
+        const bool real = u < seg && seg > 0 && lane < NG * BS;
+        const int cb = real ? T.bc[u] : a.nb;
+#pragma unroll
+        for (int cc = 0; cc < BS; ++cc) T.v[u][cc] = real ? T.v[u][cc] : 0.0;
+        const bool fresh = rev ? (cb >= m.lvl_hi) : (cb < m.lvl_lo);
+        idx[u] = cb * BS + (fresh ? xs : 0);
+#pragma unroll
+        for (int cc = 0; cc < BS; ++cc) xb[u][cc] = ald(Xo + idx[u] + cc);
+    }
+    for (unsigned spin = 0;; ++spin) {
+        bool bad = false;
+#pragma unroll
+        for (int u = 0; u < SEG; ++u)
+#pragma unroll
+            for (int cc = 0; cc < BS; ++cc) bad |= (xb[u][cc] == FLOW_SENT);
+        if (!__any(bad)) break;
+        if (AMG_FLOW_SLEEP > 0) __builtin_amdgcn_s_sleep(AMG_FLOW_SLEEP);
+        if ((spin & 31u) == 31u && wall_clock64() - t0 > a.budget) {
+            if (lane == 0) __hip_atomic_store(a.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+#pragma unroll
+        for (int u = 0; u < SEG; ++u)
+#pragma unroll
+            for (int cc = 0; cc < BS; ++cc)
+                if (xb[u][cc] == FLOW_SENT) xb[u][cc] = ald(Xo + idx[u] + cc);
+    }
+    double vb[SEG];
+#pragma unroll
+    for (int u = 0; u < SEG; ++u) {
+        double w = 0.0;
+#pragma unroll
+        for (int cc = 0; cc < BS; ++cc) w = w + T.v[u][cc] * __longlong_as_double((long long)xb[u][cc]);
+        vb[u] = w;
+    }
+    double rsum = 0.0;
+    if constexpr (LPR == 1) {
+#pragma unroll
+        for (int u = 0; u < SEG; ++u) rsum = rsum + vb[u];
+    } else {
+#pragma unroll
+        for (int u = 0; u < SEG; ++u) prod[u * 64 + lane] = vb[u];
+        flow_wave_sync();
+        if (leader) {
+            constexpr int GB = LPR < 4 ? LPR : 4;
+#pragma unroll 1
+            for (int g0 = 0; g0 < LPR; g0 += GB) {
+                double p[GB * SEG];
+#pragma unroll
+                for (int g = 0; g < GB; ++g)
+#pragma unroll
+                    for (int u = 0; u < SEG; ++u) p[g * SEG + u] = prod[u * 64 + lane + (g0 + g) * BS];
+#pragma unroll
+                for (int w = 0; w < GB * SEG; ++w) rsum = rsum + p[w];
+            }
+        }
+        flow_wave_sync();
+    }
+    // x_i = Dinv_i (b_i - rsum): the BS leaders of the block row exchange their entries of b - rsum
+    const double t = T.bb - rsum;
+    double vD = 0.0;
+    const int base = br * LW;
+#pragma unroll
+    for (int cc = 0; cc < BS; ++cc) {
+        const double tc = __shfl(t, base + cc, 64);
+        const double d = leader ? a.Dinv[(long)T.orow * (BS * BS) + r * BS + cc] : 0.0;
+        vD = vD + d * tc;
+    }
+    if (leader) {
+        __hip_atomic_store(Xn + (long)kb * BS + r, (unsigned long long)__double_as_longlong(vD), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (last) a.x_out[(long)T.orow * BS + r] = vD;
+    }
+    return true;
+}
+
 template <int BS, int LPR>
 __global__ __launch_bounds__(64) void bgs_flow_kernel(const FlowChunk *__restrict__ meta, const int *__restrict__ col,
                                                        const double *__restrict__ val, const double *__restrict__ bp,
                                                        const int *__restrict__ rows, const int *__restrict__ gate_f,
                                                        const int *__restrict__ gate_b, BlockFlowArgs a)
 {
-    constexpr int SEG = FLOW_SEG, NG = 64 / BS, LW = BS * LPR, NBR = 64 / LW;
-    __shared__ double prod[LPR > 1 ? SEG * 64 : 1];
-    const int lane = threadIdx.x;
-    const int br = lane / LW, grp = lane / BS, r = lane - grp * BS;
+    __shared__ double prod[LPR > 1 ? FLOW_SEG * 64 : 1];
     const int NW = (int)gridDim.x;
     const long long t0 = wall_clock64();
     int s = 0, q = (int)blockIdx.x;
     while (q >= a.nchunks) { q -= a.nchunks; ++s; }
-    while (s < a.nseq) {
-        const bool rev = ((a.dirmask >> s) & 1u) != 0;
-        const int c = rev ? a.nchunks - 1 - q : q;
-        const FlowChunk m = meta[c];
-        const int seg = m.nslots;
-        const bool rowok = br < m.nrows && br < NBR;
-        const bool leader = rowok && (lane - br * LW) < BS;                  // g == 0: lanes (block row, 0, r)
-        const int kb = m.row0 + (rowok ? br : 0);
-        int bc[SEG];
-        double v[SEG][BS];
-        const int smax = seg > 0 ? seg - 1 : 0;
-        const int gcl = min(grp, NG - 1);
-#pragma unroll
-        for (int u = 0; u < SEG; ++u) {
-            const long su = (long)m.off + min(u, smax);
-            bc[u] = col[su * NG + gcl];
-#pragma unroll
-            for (int cc = 0; cc < BS; ++cc) v[u][cc] = val[(su * BS + cc) * 64 + lane];
-        }
-        double bb = 0.0;
-        int orow = 0, gate = a.nb;
-        const bool last = s == a.nseq - 1;
-        if (leader) {
-            bb = bp[(long)kb * BS + r];
-            gate = rev ? gate_b[kb] : gate_f[kb];
-            orow = rows[kb];
-        }
-        const unsigned long long *Xo = a.X + (long)s * a.xstride;
-        unsigned long long *Xn = a.X + (long)(s + 1) * a.xstride;
-        {
-            const unsigned long long *gp_ = Xn + (long)gate * BS + r;
-            unsigned long long gv = ald(gp_);
-            for (unsigned spin = 0; __any(gv == FLOW_SENT); ++spin) {
-                __builtin_amdgcn_s_sleep(4);
-                if ((spin & 31u) == 31u && wall_clock64() - t0 > a.budget) {
-                    if (lane == 0) __hip_atomic_store(a.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    return;
-                }
-                if (gv == FLOW_SENT) gv = ald(gp_);
-            }
-        }
-        const int xs = (int)a.xstride;
-        int idx[SEG];
-        unsigned long long xb[SEG][BS];
-#pragma unroll
-        for (int u = 0; u < SEG; ++u) {
-            const bool real = u < seg && seg > 0 && lane < NG * BS;
-            const int cb = real ? bc[u] : a.nb;
-#pragma unroll
-            for (int cc = 0; cc < BS; ++cc) v[u][cc] = real ? v[u][cc] : 0.0;
-            const bool fresh = rev ? (cb >= m.lvl_hi) : (cb < m.lvl_lo);
-            idx[u] = cb * BS + (fresh ? xs : 0);
-#pragma unroll
-            for (int cc = 0; cc < BS; ++cc) xb[u][cc] = ald(Xo + idx[u] + cc);
-        }
-        for (unsigned spin = 0;; ++spin) {
-            bool bad = false;
-#pragma unroll
-            for (int u = 0; u < SEG; ++u)
-#pragma unroll
-                for (int cc = 0; cc < BS; ++cc) bad |= (xb[u][cc] == FLOW_SENT);
-            if (!__any(bad)) break;
-            if (AMG_FLOW_SLEEP > 0) __builtin_amdgcn_s_sleep(AMG_FLOW_SLEEP);
-            if ((spin & 31u) == 31u && wall_clock64() - t0 > a.budget) {
-                if (lane == 0) __hip_atomic_store(a.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                return;
-            }
-#pragma unroll
-            for (int u = 0; u < SEG; ++u)
-#pragma unroll
-                for (int cc = 0; cc < BS; ++cc)
-                    if (xb[u][cc] == FLOW_SENT) xb[u][cc] = ald(Xo + idx[u] + cc);
-        }
-        double vb[SEG];
-#pragma unroll
-        for (int u = 0; u < SEG; ++u) {
-            double w = 0.0;
-#pragma unroll
-            for (int cc = 0; cc < BS; ++cc) w = w + v[u][cc] * __longlong_as_double((long long)xb[u][cc]);
-            vb[u] = w;
-        }
-        double rsum = 0.0;
-        if constexpr (LPR == 1) {
-#pragma unroll
-            for (int u = 0; u < SEG; ++u) rsum = rsum + vb[u];
-        } else {
-#pragma unroll
-            for (int u = 0; u < SEG; ++u) prod[u * 64 + lane] = vb[u];
-            flow_wave_sync();
-            if (leader) {
-                constexpr int GB = LPR < 4 ? LPR : 4;
-#pragma unroll 1
-                for (int g0 = 0; g0 < LPR; g0 += GB) {
-                    double p[GB * SEG];
-#pragma unroll
-                    for (int g = 0; g < GB; ++g)
-#pragma unroll
-                        for (int u = 0; u < SEG; ++u) p[g * SEG + u] = prod[u * 64 + lane + (g0 + g) * BS];
-#pragma unroll
-                    for (int w = 0; w < GB * SEG; ++w) rsum = rsum + p[w];
-                }
-            }
-            flow_wave_sync();
-        }
-        // x_i = Dinv_i (b_i - rsum): the BS leaders of the block row exchange their entries of b - rsum
-        const double t = bb - rsum;
-        double vD = 0.0;
-        const int base = br * LW;
-#pragma unroll
-        for (int cc = 0; cc < BS; ++cc) {
-            const double tc = __shfl(t, base + cc, 64);
-            const double d = leader ? a.Dinv[(long)orow * (BS * BS) + r * BS + cc] : 0.0;
-            vD = vD + d * tc;
-        }
-        if (leader) {
-            __hip_atomic_store(Xn + (long)kb * BS + r, (unsigned long long)__double_as_longlong(vD), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (last) a.x_out[(long)orow * BS + r] = vD;
-        }
-        q += NW;
-        while (q >= a.nchunks) { q -= a.nchunks; ++s; }
+    auto advance = [&]() { q += NW; while (q >= a.nchunks) { q -= a.nchunks; ++s; } };
+    BlockTask<BS> A, B;
+    bflow_load<BS, LPR>(A, s, q, meta, col, val, bp, rows, gate_f, gate_b, a);
+    while (A.valid) {
+        advance();
+        if (a.prefetch) bflow_load<BS, LPR>(B, s, q, meta, col, val, bp, rows, gate_f, gate_b, a);
+        if (!bflow_run<BS, LPR>(A, prod, t0, a)) return;
+        if (!a.prefetch) bflow_load<BS, LPR>(B, s, q, meta, col, val, bp, rows, gate_f, gate_b, a);
+        if (!B.valid) break;
+        advance();
+        if (a.prefetch) bflow_load<BS, LPR>(A, s, q, meta, col, val, bp, rows, gate_f, gate_b, a);
+        if (!bflow_run<BS, LPR>(B, prod, t0, a)) return;
+        if (!a.prefetch) bflow_load<BS, LPR>(A, s, q, meta, col, val, bp, rows, gate_f, gate_b, a);
     }
 }
 
@@ -642,6 +690,8 @@ int block_flow_sweep(const BlockFlowForm &F, const double *Dinv, double *x, cons
         a.X = (unsigned long long *)F.X; a.x_out = x; a.Dinv = Dinv; a.status = status;
         a.xstride = F.xstride; a.budget = 100000000LL * 4;
         a.nchunks = F.nchunks; a.nseq = ns; a.nb = F.nb;
+        static const int pf = std::getenv("AMG_FLOW_PREFETCH") ? std::atoi(std::getenv("AMG_FLOW_PREFETCH")) : 1;
+        a.prefetch = pf;
         for (int k = 0; k < ns; ++k) a.dirmask |= (seq[s0 + k] != 0 ? 1u : 0u) << k;
         if (F.bs == 3) FCHK(launch_bflow_bs<3>(F, a, st));
         else FCHK(launch_bflow_bs<2>(F, a, st));

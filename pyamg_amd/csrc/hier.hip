@@ -740,7 +740,9 @@ int build_csr_schedule(const int *Ap, const int *Aj, const double *Ax, int n, co
         // narrow short-row levels (2-D operators) hand their values on through LDS faster than any memory hand-off
         int chained = 0;
         for (const auto &c : S.chains) chained += c.second - c.first;
-        const bool wanted = S.chain_long || chained * 10 < nl * 9;
+        // ... and not where a level holds hundreds of thousands of rows (multicolour orderings, the 500^3 level): a launch
+        // per level then runs at streaming speed and the second copy of the operator would only cost memory
+        const bool wanted = (S.chain_long || chained * 10 < nl * 9) && (long)ntasks < (long)nl * 200000L;
         if (wanted || gs_flow_mode() == 2) {
             CHK(build_flow_form(S.flow, n, ntasks, S.level_ptr, rowmap, gp, gj, gx));
             S.flow_auto = wanted && S.flow.ready;

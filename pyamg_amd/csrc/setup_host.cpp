@@ -1139,6 +1139,9 @@ int amgsetup_greedy_coloring(int n, const int *Ap, const int *Aj, int *colour)
     return ncol;
 }
 
+// 1 when every stored entry (i, j) has its mirror (j, i) stored too (checked on all host threads)
+int amgsetup_pattern_symmetric(int n, const int *Ap, const int *Aj) { return pattern_symmetric(Ap, Aj, n) ? 1 : 0; }
+
 void amgsetup_set_num_threads(int n)
 {
 #ifdef _OPENMP

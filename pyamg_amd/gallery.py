@@ -111,6 +111,12 @@ def tet_diffusion(n, eps=(1.0, 0.1, 0.01), theta=np.pi / 6, phi=np.pi / 5, jitte
     if blocksize:
         if A.shape[0] % blocksize:
             raise ValueError("n^3 must be divisible by the blocksize")
+        # ~15 blocks per block row: above 2^31 stored values the int32 addressing of the BSR data array ends -- the
+        # reference's kernels index Ax[jj * blocksize * blocksize] with int (relaxation.h:90-173, :756-810) and scipy's
+        # csr_tobsr crashes; 360^3 = 46.7 M unknowns is the largest cube divisible by 3 below that (369^3 = 50.2 M is not)
+        if (A.shape[0] // blocksize) * 15.0 * blocksize * blocksize >= 2.0 ** 31:      # this mesh: <= 15 blocks per block row
+            raise ValueError("BSR(%d,%d) form of %d unknowns needs more than 2^31 stored values (int32 addressing of the "
+                             "block data array, as in the reference's amg_core): use n <= 360" % (blocksize, blocksize, A.shape[0]))
         A = _tobsr_sorted(A, blocksize) if native else A.tobsr((blocksize, blocksize))
     return A
 

@@ -222,7 +222,8 @@ def setup_multicolor_gauss_seidel(lvl, iterations=1, sweep="forward"):
     dependency levels per sweep as colours (2 for a 7-point stencil), so it runs at SpMV speed."""
     from .aggregation import greedy_colouring
     colour, ncol = greedy_colouring(lvl.A)
-    indices = np.argsort(colour, kind="stable").astype(np.intc)
+    key = colour.astype(np.int16) if ncol < 32768 else colour     # 16-bit keys: numpy's stable sort is a radix sort there
+    indices = np.argsort(key, kind="stable").astype(np.intc)
     sm = setup_gauss_seidel_indexed(lvl, indices=indices, iterations=iterations, sweep=sweep)
     sm.ncolours = ncol
     return sm

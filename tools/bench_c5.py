@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """BASELINE configuration C5 at (near) full size: anisotropic diffusion, P1 on a jittered Kuhn tetrahedral mesh,
-C5_GRID^3 unknowns (default 345^3 = 41.1 M; 369^3 = 50.2 M) as BSR with 3x3 blocks, our own block-SA setup,
+C5_GRID^3 unknowns (default 345^3 = 41.1 M; 360^3 = 46.7 M is the largest whose block data array stays below 2^31
+values, the int32 addressing of the reference's kernels and of scipy's csr_tobsr) as BSR with 3x3 blocks, our own block-SA setup,
 symmetric block Gauss-Seidel (relaxation.py:509-590) and block Jacobi (:430-506) smoothers on one MI355X.
 Prints one JSON line per smoother: V-cycle rate, the level-0 smoother's achieved HBM GB/s at the ALGORITHMIC
 bytes of SURVEY 8(d) (BSR: 8 nnz + 4 nnz / bs^2 + 4 (rows / bs + 1); + 8 n bs for Dinv; x, b, out: 8 n each),
