@@ -20,6 +20,7 @@ struct PeerPtrs {
     double *data[COMM_MAX_RANKS];           // push: (me -> p) staging in p's arena; unpack: (p -> me) staging in mine
     unsigned long long *flag[COMM_MAX_RANKS];   // signal: my flag in p's arena; wait: p's flag in mine
     int start[COMM_MAX_RANKS + 1];          // prefix of the per-peer counts
+    unsigned partner;                       // bit p: data travels between this rank and p in EITHER direction on this channel
 };
 
 __global__ __launch_bounds__(256) void comm_push_kernel(PeerPtrs P, const double *v, const int *send_idx,
@@ -40,7 +41,10 @@ __global__ void comm_signal_kernel(PeerPtrs P, unsigned long long *seq_send)
 {
     const unsigned long long s = *seq_send + 1;
     const int p = threadIdx.x;
-    if (p < P.n && P.start[p + 1] > P.start[p])
+    // every PARTNER is signalled, also one that only sends to this rank: its next push into the staging slot of the same
+    // parity must not start before this rank has unpacked the previous one, and the only thing that holds it back is
+    // its own wait for this flag (one-directional couplings: ADVICE r2)
+    if (p < P.n && ((P.partner >> p) & 1u))
         __hip_atomic_store(P.flag[p], s, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     __syncthreads();
     if (p == 0) *seq_send = s;
@@ -50,7 +54,7 @@ __global__ void comm_wait_kernel(PeerPtrs P, unsigned long long *seq_recv, int *
 {
     const unsigned long long s = *seq_recv + 1;
     const int p = threadIdx.x;
-    if (p < P.n && P.start[p + 1] > P.start[p]) {
+    if (p < P.n && ((P.partner >> p) & 1u)) {
         const long long t0 = wall_clock64();
         while (__hip_atomic_load(P.flag[p], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < s) {
             __builtin_amdgcn_s_sleep(4);
@@ -132,6 +136,14 @@ static int launch_ok(const char *what)
     return 0;
 }
 
+static unsigned partner_mask(const amg_comm *c, const Channel &C)
+{
+    unsigned m = 0;
+    for (int p = 0; p < c->world; ++p)
+        if (C.send_start[p + 1] > C.send_start[p] || C.recv_start[p + 1] > C.recv_start[p]) m |= 1u << p;
+    return m;
+}
+
 static PeerPtrs producer_ptrs(amg_comm *c, int chn)
 {
     const Channel &C = c->ch[(size_t)chn];
@@ -144,6 +156,7 @@ static PeerPtrs producer_ptrs(amg_comm *c, int chn)
         P.start[p] = C.send_start[p];
     }
     P.start[c->world] = C.send_start[c->world];
+    P.partner = partner_mask(c, C);
     return P;
 }
 
@@ -159,6 +172,7 @@ static PeerPtrs consumer_ptrs(amg_comm *c, int chn)
         P.start[p] = C.recv_start[p];
     }
     P.start[c->world] = C.recv_start[c->world];
+    P.partner = partner_mask(c, C);
     return P;
 }
 

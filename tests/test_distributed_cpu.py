@@ -96,7 +96,9 @@ def test_split_rows_and_local_rows():
 # partition-emulating run built from the reference kernel's row_start/row_stop slicing on a
 # frozen copy, written out independently here.
 # ---------------------------------------------------------------------------
-def _hybrid_sweep(lib, A, x, b, bounds, reverse, bsr):
+def _hybrid_sweep(lib, A, x, b, bounds, reverse, bsr, indices=None):
+    """indices: the index list of gauss_seidel_indexed (multicolour ordering) -- every partition relaxes ITS entries of
+    the list, in list order, on the frozen copy (relaxation.h:395-430 with the partition's sub-list)"""
     from oracle_lib import dp, ip
     Ac = A.tocsr() if not bsr else A
     Ap = np.ascontiguousarray(A.indptr, dtype=np.intc); Aj = np.ascontiguousarray(A.indices, dtype=np.intc)
@@ -106,7 +108,15 @@ def _hybrid_sweep(lib, A, x, b, bounds, reverse, bsr):
         lo, hi = int(bounds[p]), int(bounds[p + 1])
         xp = frozen.copy()
         rs, re, rt = (hi - 1, lo - 1, -1) if reverse else (lo, hi, 1)
-        if bsr:
+        if indices is not None:
+            idx = np.asarray(indices, dtype=np.int64)
+            sub = np.ascontiguousarray(idx[(idx >= lo) & (idx < hi)], dtype=np.intc)
+            Acs = A.tocsr()
+            Sp = np.ascontiguousarray(Acs.indptr, dtype=np.intc); Sj = np.ascontiguousarray(Acs.indices, dtype=np.intc)
+            Sx = np.ascontiguousarray(Acs.data, dtype=np.float64)
+            rs, re, rt = (len(sub) - 1, -1, -1) if reverse else (0, len(sub), 1)
+            lib.oracle_gauss_seidel_indexed(ip(Sp), ip(Sj), dp(Sx), dp(xp), dp(b), ip(sub), rs, re, rt)
+        elif bsr:
             lib.oracle_bsr_gauss_seidel(ip(Ap), ip(Aj), dp(Ax), dp(xp), dp(b), rs, re, rt, 1)
         else:
             lib.oracle_gauss_seidel(ip(Ap), ip(Aj), dp(Ax), dp(xp), dp(b), rs, re, rt)
@@ -132,11 +142,12 @@ def _hybrid_cycle(lib, levels, coarse, bounds, l, x, b):
                 _hybrid_cycle(lib, levels, coarse, bounds, l + 1, cx, cb)
             x += L["P"] * cx
         sm = L[side]
+        idx = sm.get("indices") if sm.get("name") == "gauss_seidel_indexed" else None
         for _ in range(int(sm.get("iterations", 1))):
             if sm["sweep"] in ("forward", "symmetric"):
-                _hybrid_sweep(lib, A, x, b, bounds[l], False, bsr)
+                _hybrid_sweep(lib, A, x, b, bounds[l], False, bsr, idx)
             if sm["sweep"] in ("backward", "symmetric"):
-                _hybrid_sweep(lib, A, x, b, bounds[l], True, bsr)
+                _hybrid_sweep(lib, A, x, b, bounds[l], True, bsr, idx)
 
 
 def _worker_hybrid(rank, world, port, case, out_dir, rep=0):
@@ -191,6 +202,59 @@ def test_hybrid_gauss_seidel_matches_partition_emulation(case, rep, tmp_path):
     xs, _ = H.solve(g["b"], tol=0.0, maxiter=3)
     assert not np.array_equal(x, xs)
     assert np.linalg.norm(x - xs) < 0.5 * np.linalg.norm(xs)
+
+
+def multicolour_hierarchy(path, grid=(14, 13, 12)):
+    """BASELINE configuration C4's smoother at a size the emulation affords: SA on a 3-D Poisson operator with
+    multicolour Gauss-Seidel (gauss_seidel_indexed over a greedy colouring), written where the rank processes find it"""
+    from pyamg_amd.aggregation import poisson, smoothed_aggregation_solver
+    from pyamg_amd.distributed import levels_from_ml, save_levels
+    np.random.seed(0)
+    sm = ("multicolor_gauss_seidel", {"sweep": "symmetric"})
+    ml = smoothed_aggregation_solver(poisson(grid), presmoother=sm, postsmoother=sm, max_coarse=30)
+    levels, coarse = levels_from_ml(ml)
+    save_levels(path, levels, coarse)
+    b = np.random.RandomState(4).rand(levels[0]["A"].shape[0])
+    np.save(os.path.join(path, "b.npy"), b)
+    return levels, coarse, b
+
+
+def _worker_multicolour(rank, world, port, path, rep):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cpu_backend import OracleBackend
+        from pyamg_amd.distributed import DistributedSolver, load_levels, split_rows
+        levels, coarse = load_levels(path)
+        b = np.load(os.path.join(path, "b.npy"))
+        S = DistributedSolver(levels, coarse, OracleBackend(), rank, world, replicate_below=rep)
+        bnd = split_rows(len(b), world); lo, hi = int(bnd[rank]), int(bnd[rank + 1])
+        x, res = S.solve(b[lo:hi], None, tol=0.0, maxiter=3, cycle="V", fixed=True)
+        np.save(os.path.join(path, "x_%d.npy" % rank), x)
+    finally:
+        dist.destroy_process_group()
+
+
+def multicolour_emulation(levels, coarse, b, world, rep, cycles=3):
+    g = {"levels": levels}
+    bounds = hybrid_bounds(g, world, rep)
+    xe = np.zeros_like(b)
+    for _ in range(cycles):
+        _hybrid_cycle(oracle_lib.load(), levels, coarse, bounds, 0, xe, np.ascontiguousarray(b))
+    return xe
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_hybrid_multicolour_gauss_seidel_matches_partition_emulation(world, tmp_path):
+    """C4 as SURVEY 8(e) specifies it: multicolour Gauss-Seidel inside a rank, Jacobi across ranks; oracle = every
+    partition relaxing its part of the index list with the reference kernel on a frozen copy"""
+    levels, coarse, b = multicolour_hierarchy(str(tmp_path))
+    mp.spawn(_worker_multicolour, args=(world, _free_port(), str(tmp_path), 100), nprocs=world, join=True)
+    x = np.concatenate([np.load(tmp_path / ("x_%d.npy" % r)) for r in range(world)])
+    xe = multicolour_emulation(levels, coarse, b, world, 100)
+    assert np.array_equal(x, xe), np.abs(x - xe).max()
+    x1 = multicolour_emulation(levels, coarse, b, 1, 100)          # one rank: the plain multicolour sweep -- a different iteration
+    assert not np.array_equal(x, x1) and np.linalg.norm(x - x1) < 0.5 * np.linalg.norm(x1)
 
 
 def test_coarse_bounds_follow_the_prolongator():

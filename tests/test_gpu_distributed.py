@@ -207,6 +207,124 @@ def test_hybrid_gauss_seidel_on_gpu_matches_partition_emulation(case, rep, trans
     assert np.array_equal(x, xe), np.abs(x - xe).max()
 
 
+def _worker_one_way(rank, world, port, out_dir):
+    """a channel on which data travels in ONE direction only (rank 0 -> rank 1 -> rank 2, nothing back), driven for many
+    back-to-back exchanges: the double-buffered staging slots must not be overwritten before they were unpacked"""
+    import ctypes as C
+    import torch
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pyamg_amd import _lib
+    L = _lib.lib()
+    comm = None
+    try:
+        torch.cuda.set_device(0)
+        N = 40000
+        comm = L.amg_comm_create(rank, world, 0, 0)
+        counts = np.zeros((world, world), dtype=np.intc)           # counts[dst][src]
+        for src in range(world - 1):
+            counts[src + 1, src] = N
+        ch = L.amg_comm_add_channel(comm, _lib.ip(counts))
+        assert ch >= 0
+        handle = np.zeros(64, dtype=np.uint8)
+        _lib.check(L.amg_comm_commit(comm, handle.ctypes.data))
+        out = [torch.zeros(64, dtype=torch.uint8) for _ in range(world)]
+        dist.all_gather(out, torch.from_numpy(handle.copy()))
+        handles = np.ascontiguousarray(np.concatenate([t.numpy() for t in out]), dtype=np.uint8)
+        _lib.check(L.amg_comm_connect(comm, handles.ctypes.data))
+        dist.barrier()
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        v = torch.zeros(N, dtype=torch.float64, device="cuda")
+        halo = torch.zeros(max(N, 1), dtype=torch.float64, device="cuda")
+        bad = torch.zeros(1, dtype=torch.int64, device="cuda")
+        base = torch.arange(N, dtype=torch.float64, device="cuda")
+        for k in range(300):
+            v.copy_(base + (1000.0 * rank + k))
+            if rank == 0 and k % 50 == 0:
+                torch.cuda._sleep(2000000)                           # the producer falls behind now and then ...
+            if rank == world - 1 and k % 37 == 0:
+                torch.cuda._sleep(3000000)                           # ... and so does the last consumer
+            _lib.check(L.amg_comm_exchange(comm, ch, C.c_void_p(v.data_ptr()), None, C.c_void_p(halo.data_ptr()), st))
+            if rank > 0:
+                bad += (halo != base + (1000.0 * (rank - 1) + k)).sum()
+        torch.cuda.synchronize()
+        _lib.check(L.amg_comm_check(comm))
+        np.save(os.path.join(out_dir, "bad_%d.npy" % rank), bad.cpu().numpy())
+        dist.barrier()
+    finally:
+        if comm:
+            L.amg_comm_destroy(comm)
+        dist.destroy_process_group()
+
+
+def test_one_directional_channel_keeps_its_staging_slots(tmp_path):
+    """a rank that only RECEIVES on a channel still acknowledges every exchange (flags travel
+    between partners in either direction), so a producer cannot run two exchanges ahead and overwrite a staging slot
+    that is still being unpacked.  300 back-to-back one-way exchanges over a chain of 3 ranks with stalls injected on both
+    ends; every received entry checked."""
+    world = 3
+    mp.spawn(_worker_one_way, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert int(np.load(tmp_path / ("bad_%d.npy" % r))[0]) == 0, r
+
+
+def _worker_multicolour_gpu(rank, world, port, path, rep, transport):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    _transport_env(rank, transport)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    S = None
+    try:
+        from pyamg_amd.distributed import DistributedSolver, HipBackend, load_levels, split_rows
+        levels, coarse = load_levels(path)
+        b = np.load(os.path.join(path, "b.npy"))
+        S = DistributedSolver(levels, coarse, HipBackend(0), rank, world, replicate_below=rep)
+        bnd = split_rows(len(b), world)
+        lo, hi = int(bnd[rank]), int(bnd[rank + 1])
+        x, res = S.solve(b[lo:hi], None, tol=0.0, maxiter=3, cycle="V", fixed=True)
+        np.save(os.path.join(path, "x_%d.npy" % rank), x)
+    finally:
+        if S is not None:
+            S.close()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,transport", [(2, "peer"), (3, "peer"), (2, "python")])
+def test_hybrid_multicolour_gauss_seidel_on_gpu_matches_partition_emulation(world, transport, tmp_path):
+    """BASELINE configuration C4 as SURVEY 8(e) specifies it -- multicolour Gauss-Seidel (gauss_seidel_indexed,
+    relaxation.h:395-430) inside a rank, Jacobi across ranks -- with 2 and 3 ranks sharing the device: gathered
+    iterates bit-identical to the partition-emulating oracle (every partition relaxes its part of the index list with
+    the reference kernel on a frozen copy)."""
+    from test_distributed_cpu import multicolour_emulation, multicolour_hierarchy
+    levels, coarse, b = multicolour_hierarchy(str(tmp_path), grid=(18, 16, 15))
+    mp.spawn(_worker_multicolour_gpu, args=(world, _free_port(), str(tmp_path), 100, transport), nprocs=world, join=True)
+    x = np.concatenate([np.load(tmp_path / ("x_%d.npy" % r)) for r in range(world)])
+    xe = multicolour_emulation(levels, coarse, b, world, 100)
+    assert np.array_equal(x, xe), np.abs(x - xe).max()
+
+
+def test_bench_config_c4_runs_partitioned_hybrid_gauss_seidel(tmp_path):
+    """`python bench.py --config C4 --gpus 2`: the hybrid (multicolour) Gauss-Seidel configuration row-partitioned over two
+    ranks (sharing the one GPU here), and `--smoother hybrid_gs_lex` on one rank"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "AMG_DIST_TRANSPORT")}
+    for extra in (["--gpus", "2"], ["--smoother", "hybrid_gs_lex"]):
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "C4", "--grid", "40", "--steps", "3",
+                            "--warmup", "2"] + extra, env=env, capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stderr[-3000:]
+        line = json.loads(p.stdout.strip().splitlines()[-1])
+        assert line["steps"] == 3 and line["roofline"]["frac"] > 0 and line["cpu_baseline"]["value"] > 0
+        if extra[0] == "--gpus":
+            assert line["n_gpus"] == 2 and line["scaling"] == "strong" and "hybrid_gs" in line["config"]["workload"]
+        else:
+            assert line["cpu_baseline"]["first_step_iterate_bit_identical_to_gpu"] is True
+            assert "cpu_model" in line["cpu_baseline"]
+
+
 def test_bench_gpus_2_runs_two_ranks(tmp_path):
     """`python bench.py --gpus 2` starts two rank processes itself (here they share the one GPU) and the line it
     prints is the partitioned run's: n_gpus 2, strong scaling, the C++ engine's transport, roofline and cpu_baseline."""
