@@ -619,7 +619,7 @@ int build_block_flow_form(BlockFlowForm &F, int nb, int bs, int ntasks, const st
             m.row0 = r0; m.nrows = std::min(R, hi - r0);
             m.nslots = (cnt[(size_t)ord[(size_t)r0]] + lpr - 1) / lpr;
             m.lvl_lo = lo; m.lvl_hi = hi;
-            if (slot_rows > 2000000000L / (64L * bs)) return 0;
+            if (slot_rows > 2000000000L) return 0;                              // FlowChunk::off is an int (entries are addressed in 64 bits)
             m.off = (int)slot_rows;
             slot_rows += m.nslots;
             meta.push_back(m);
@@ -779,7 +779,7 @@ int build_flow_form(FlowForm &F, int n, int ntasks, const std::vector<int> &leve
             m.row0 = r0; m.nrows = std::min(R, hi - r0);
             m.nslots = (cnt[(size_t)ord[(size_t)r0]] + lpr - 1) / lpr;          // per lane; the chunk's first row is its longest
             m.lvl_lo = lo; m.lvl_hi = hi;
-            if (slot_rows > 2000000000L / 64) return 0;
+            if (slot_rows > 2000000000L) return 0;                              // FlowChunk::off is an int (entries are addressed in 64 bits)
             m.off = (int)slot_rows;
             slot_rows += m.nslots;
             meta.push_back(m);
