@@ -317,7 +317,7 @@ int gs_flow_sweep(const FlowForm &F, bool bsr1, double *x, const double *b, cons
 // blocks per lane; positions count block rows, the iterate buffers hold bs scalars per block row
 struct BlockFlowForm {
     bool ready = false;
-    int nb = 0, bs = 0, nchunks = 0, nlevels = 0, lpr = 1;
+    int nb = 0, bs = 0, nchunks = 0, nlevels = 0, lpr = 1, seg = 8;     // seg blocks per lane, lpr lanes per scalar row
     long slot_rows = 0;
     int *rows = nullptr;                // [nb] original block row of position k
     FlowChunk *meta = nullptr;

@@ -331,7 +331,7 @@ int amgcore_block_gauss_seidel_f64(const int Ap[], int Ap_size, const int Aj[], 
     if (tasks.empty()) return 0;
     if ((long)nb * blocksize * blocksize > Tx_size) { set_error("Dinv too short"); return AMG_EINVAL; }
     SchedHolder sh;
-    CHK(build_block_schedule(Ap, Aj, nb, tasks.data(), (int)tasks.size(), sh.S, nullptr, Ax, blocksize));
+    CHK(build_block_schedule(Ap, Aj, nb, tasks.data(), (int)tasks.size(), sh.S, nullptr, Ax, blocksize, false, true));
     DBuf dx, db, dd;
     CHK(dx.from_host(x, sizeof(double) * (size_t)x_size));
     CHK(db.from_host(b, sizeof(double) * (size_t)b_size));

@@ -253,7 +253,6 @@ struct BlockFlowArgs {
     long long budget;
     int nchunks, nseq, nb;
     unsigned dirmask;
-    int prefetch;               // request the next task's matrix data before waiting for the current task's operands
 };
 
 template <int BS>
@@ -278,25 +277,28 @@ __global__ __launch_bounds__(256) void bflow_gather_kernel(const int *rows, cons
 }
 
 // what a block task needs that does not depend on the sweep's values: chunk descriptor, block columns, values, and the
-// block row's own right-hand side / gate / row number.  Two of these live in registers: the NEXT task's is requested
-// before the current task starts waiting for its operands, so that on wide levels (more chunks per level than resident
-// waves: no look-ahead left between tasks) the matrix stream does not wait for the dependency chain.
-template <int BS>
+// block row's own right-hand side / gate / row number.  (Requesting the NEXT task's share before waiting for the current
+// task's operands was tried -- two of these in registers -- and gained nothing: vector-memory results return in issue
+// order, so the operand polls queue behind the prefetch; C5 at 252^3: 5.17 vs 5.10 ms per level-0 application.)
+// SEG blocks per lane, LPR lanes per scalar row: (8, 1) up to 8 off-diagonal blocks per block row, (5, 3) up to 15 -- the
+// tet-mesh operator of configuration C5, 7 block rows per wave without a padded slot and few enough registers for four
+// waves per SIMD --, (8, 2), (8, 4), ... beyond.
+template <int BS, int SEG>
 struct BlockTask {
     FlowChunk m;
-    int bc[FLOW_SEG];
-    double v[FLOW_SEG][BS];
+    int bc[SEG];
+    double v[SEG][BS];
     double bb;
     int gate, orow, s;
     bool valid;
 };
 
-template <int BS, int LPR>
-__device__ __forceinline__ void bflow_load(BlockTask<BS> &T, int s, int q, const FlowChunk *__restrict__ meta, const int *__restrict__ col,
+template <int BS, int SEG, int LPR>
+__device__ __forceinline__ void bflow_load(BlockTask<BS, SEG> &T, int s, int q, const FlowChunk *__restrict__ meta, const int *__restrict__ col,
                                             const double *__restrict__ val, const double *__restrict__ bp, const int *__restrict__ rows,
                                             const int *__restrict__ gate_f, const int *__restrict__ gate_b, const BlockFlowArgs &a)
 {
-    constexpr int SEG = FLOW_SEG, NG = 64 / BS, LW = BS * LPR, NBR = 64 / LW;
+    constexpr int NG = 64 / BS, LW = BS * LPR, NBR = 64 / LW;
     T.valid = s < a.nseq;
     T.s = s;
     if (!T.valid) return;
@@ -327,10 +329,10 @@ __device__ __forceinline__ void bflow_load(BlockTask<BS> &T, int s, int q, const
 }
 
 // returns false when the wave ran out of its time budget
-template <int BS, int LPR>
-__device__ __forceinline__ bool bflow_run(BlockTask<BS> &T, double *prod, long long t0, const BlockFlowArgs &a)
+template <int BS, int SEG, int LPR>
+__device__ __forceinline__ bool bflow_run(BlockTask<BS, SEG> &T, double *prod, long long t0, const BlockFlowArgs &a)
 {
-    constexpr int SEG = FLOW_SEG, NG = 64 / BS, LW = BS * LPR, NBR = 64 / LW;
+    constexpr int NG = 64 / BS, LW = BS * LPR, NBR = 64 / LW;
     const int lane = threadIdx.x;
     const int br = lane / LW, grp = lane / BS, r = lane - grp * BS;
     const FlowChunk &m = T.m;
@@ -434,30 +436,23 @@ __device__ __forceinline__ bool bflow_run(BlockTask<BS> &T, double *prod, long l
     return true;
 }
 
-template <int BS, int LPR>
+template <int BS, int SEG, int LPR>
 __global__ __launch_bounds__(64) void bgs_flow_kernel(const FlowChunk *__restrict__ meta, const int *__restrict__ col,
                                                        const double *__restrict__ val, const double *__restrict__ bp,
                                                        const int *__restrict__ rows, const int *__restrict__ gate_f,
                                                        const int *__restrict__ gate_b, BlockFlowArgs a)
 {
-    __shared__ double prod[LPR > 1 ? FLOW_SEG * 64 : 1];
+    __shared__ double prod[LPR > 1 ? SEG * 64 : 1];
     const int NW = (int)gridDim.x;
     const long long t0 = wall_clock64();
     int s = 0, q = (int)blockIdx.x;
     while (q >= a.nchunks) { q -= a.nchunks; ++s; }
-    auto advance = [&]() { q += NW; while (q >= a.nchunks) { q -= a.nchunks; ++s; } };
-    BlockTask<BS> A, B;
-    bflow_load<BS, LPR>(A, s, q, meta, col, val, bp, rows, gate_f, gate_b, a);
-    while (A.valid) {
-        advance();
-        if (a.prefetch) bflow_load<BS, LPR>(B, s, q, meta, col, val, bp, rows, gate_f, gate_b, a);
-        if (!bflow_run<BS, LPR>(A, prod, t0, a)) return;
-        if (!a.prefetch) bflow_load<BS, LPR>(B, s, q, meta, col, val, bp, rows, gate_f, gate_b, a);
-        if (!B.valid) break;
-        advance();
-        if (a.prefetch) bflow_load<BS, LPR>(A, s, q, meta, col, val, bp, rows, gate_f, gate_b, a);
-        if (!bflow_run<BS, LPR>(B, prod, t0, a)) return;
-        if (!a.prefetch) bflow_load<BS, LPR>(A, s, q, meta, col, val, bp, rows, gate_f, gate_b, a);
+    BlockTask<BS, SEG> T;
+    while (s < a.nseq) {
+        bflow_load<BS, SEG, LPR>(T, s, q, meta, col, val, bp, rows, gate_f, gate_b, a);
+        if (!bflow_run<BS, SEG, LPR>(T, prod, t0, a)) return;
+        q += NW;
+        while (q >= a.nchunks) { q -= a.nchunks; ++s; }
     }
 }
 
@@ -485,7 +480,7 @@ int flow_status_word(int **out)
 // one-wave workgroups a compute unit is asked to hold at most (the occupancy query is the other bound)
 int flow_wpc()
 {
-    static const int w = std::getenv("AMG_FLOW_WPC") ? std::atoi(std::getenv("AMG_FLOW_WPC")) : 8;
+    static const int w = std::getenv("AMG_FLOW_WPC") ? std::atoi(std::getenv("AMG_FLOW_WPC")) : 16;
     return std::max(1, w);
 }
 
@@ -524,13 +519,13 @@ int launch_flow(const FlowForm &F, bool bsr1, const FlowArgs &a, hipStream_t st)
     return 0;
 }
 
-template <int BS, int LPR>
+template <int BS, int SEG, int LPR>
 int launch_bflow(const BlockFlowForm &F, const BlockFlowArgs &a, hipStream_t st)
 {
     static int cap = 0;
     if (cap == 0) {
         int nb = 0, dev = 0, ncu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, bgs_flow_kernel<BS, LPR>, 64, 0) != hipSuccess || nb < 1) nb = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, bgs_flow_kernel<BS, SEG, LPR>, 64, 0) != hipSuccess || nb < 1) nb = 1;
         hipDeviceProp_t pr;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount;
         if (ncu < 1) ncu = 64;
@@ -542,7 +537,7 @@ int launch_bflow(const BlockFlowForm &F, const BlockFlowArgs &a, hipStream_t st)
     nw = std::max<long>(nw, minw);
     nw = std::min<long>(nw, cap);
     nw = std::min<long>(nw, (long)a.nseq * F.nchunks);
-    hipLaunchKernelGGL((bgs_flow_kernel<BS, LPR>), dim3((unsigned)nw), dim3(64), 0, st, F.meta, F.col, F.val, F.bp, F.rows, F.gate_f, F.gate_b, a);
+    hipLaunchKernelGGL((bgs_flow_kernel<BS, SEG, LPR>), dim3((unsigned)nw), dim3(64), 0, st, F.meta, F.col, F.val, F.bp, F.rows, F.gate_f, F.gate_b, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "dataflow block Gauss-Seidel launch", __FILE__, __LINE__);
     return 0;
@@ -551,12 +546,13 @@ int launch_bflow(const BlockFlowForm &F, const BlockFlowArgs &a, hipStream_t st)
 template <int BS>
 int launch_bflow_bs(const BlockFlowForm &F, const BlockFlowArgs &a, hipStream_t st)
 {
+    if (F.seg == 5 && F.lpr == 3) return launch_bflow<BS, 5, 3>(F, a, st);
     switch (F.lpr) {
-    case 1: return launch_bflow<BS, 1>(F, a, st);
-    case 2: return launch_bflow<BS, 2>(F, a, st);
-    case 4: return launch_bflow<BS, 4>(F, a, st);
-    case 8: return launch_bflow<BS, 8>(F, a, st);
-    default: return launch_bflow<BS, 16>(F, a, st);
+    case 1: return launch_bflow<BS, 8, 1>(F, a, st);
+    case 2: return launch_bflow<BS, 8, 2>(F, a, st);
+    case 4: return launch_bflow<BS, 8, 4>(F, a, st);
+    case 8: return launch_bflow<BS, 8, 8>(F, a, st);
+    default: return launch_bflow<BS, 8, 16>(F, a, st);
     }
 }
 
@@ -597,9 +593,11 @@ int build_block_flow_form(BlockFlowForm &F, int nb, int bs, int ntasks, const st
         longest = std::max(longest, c);
     }
     if (longest > FLOW_SEG * 16) return 0;
-    int lpr = 1;
-    while (lpr * FLOW_SEG < longest) lpr *= 2;
-    F.lpr = lpr; F.bs = bs;
+    int lpr = 1, seg = FLOW_SEG;
+    while (lpr * seg < longest) lpr *= 2;
+    static const int allow53 = std::getenv("AMG_FLOW_53") ? std::atoi(std::getenv("AMG_FLOW_53")) : 1;
+    if (allow53 && longest > 8 && longest <= 15) { seg = 5; lpr = 3; }          // 15 = 3 lanes x 5 blocks: the C5 operator's block rows
+    F.lpr = lpr; F.seg = seg; F.bs = bs;
     const int NG = 64 / bs, R = 64 / (bs * lpr);                                // groups per wave, block rows per chunk
     if (R < 1) return 0;
     std::vector<int> ord((size_t)nb), pos_of((size_t)nb);
@@ -690,8 +688,6 @@ int block_flow_sweep(const BlockFlowForm &F, const double *Dinv, double *x, cons
         a.X = (unsigned long long *)F.X; a.x_out = x; a.Dinv = Dinv; a.status = status;
         a.xstride = F.xstride; a.budget = 100000000LL * 4;
         a.nchunks = F.nchunks; a.nseq = ns; a.nb = F.nb;
-        static const int pf = std::getenv("AMG_FLOW_PREFETCH") ? std::atoi(std::getenv("AMG_FLOW_PREFETCH")) : 1;
-        a.prefetch = pf;
         for (int k = 0; k < ns; ++k) a.dirmask |= (seq[s0 + k] != 0 ? 1u : 0u) << k;
         if (F.bs == 3) FCHK(launch_bflow_bs<3>(F, a, st));
         else FCHK(launch_bflow_bs<2>(F, a, st));

@@ -420,6 +420,20 @@ void Schedule::release()
     chain_width.clear();
 }
 
+void Schedule::drop_level_copies()
+{
+    free_csr(G);
+    G = DevCsr();
+    for (int *p : {rowmap, diagpos, level_ptr_dev, c2_code_f, c2_code_b, c2_off, perm_Aj, cl_code_f, cl_code_b}) if (p) hipFree(p);
+    for (double *p : {c2_diag, c2_val, c2_dummy, xp, bp, bd}) if (p) hipFree(p);
+    rowmap = diagpos = level_ptr_dev = c2_code_f = c2_code_b = c2_off = perm_Aj = cl_code_f = cl_code_b = nullptr;
+    c2_diag = c2_val = c2_dummy = xp = bp = bd = nullptr;
+    chain2 = perm = chain_long = false;
+    chains.clear(); chain_width.clear();
+    std::vector<int>().swap(gp_host);
+    level_copy_bytes = 0;
+}
+
 int build_levels(int n, const int *Ap, const int *Aj, const int *tasks, int ntasks,
                  std::vector<int> &level_ptr, std::vector<int> &order)
 {
@@ -457,7 +471,7 @@ int build_levels(int n, const int *Ap, const int *Aj, const int *tasks, int ntas
 }
 
 int build_csr_schedule(const int *Ap, const int *Aj, const double *Ax, int n, const int *tasks,
-                       int ntasks, Schedule &S, hipStream_t st)
+                       int ntasks, Schedule &S, hipStream_t st, bool allow_flow)
 {
     (void)st;
     std::vector<int> order;
@@ -735,7 +749,8 @@ int build_csr_schedule(const int *Ap, const int *Aj, const double *Ax, int n, co
     }
     // ---- dataflow form (gsflow.hip): one persistent launch per smoother application
     S.flow_auto = false;
-    if (gs_flow_mode() != 0 && ntasks == n) {
+    S.level_copy_bytes = 12L * (long)nnz + 12L * ntasks;
+    if (allow_flow && gs_flow_mode() != 0 && ntasks == n) {
         // by default only where levels would otherwise be launches of their own or long-row chains: the sweeps of
         // narrow short-row levels (2-D operators) hand their values on through LDS faster than any memory hand-off
         int chained = 0;
@@ -746,13 +761,16 @@ int build_csr_schedule(const int *Ap, const int *Aj, const double *Ax, int n, co
         if (wanted || gs_flow_mode() == 2) {
             CHK(build_flow_form(S.flow, n, ntasks, S.level_ptr, rowmap, gp, gj, gx));
             S.flow_auto = wanted && S.flow.ready;
+            // the default serves this schedule from the dataflow form alone: the level-ordered copies of the other
+            // paths (12-28 B per entry) are not kept beside it
+            if (S.flow_auto && gs_flow_mode() == 1) S.drop_level_copies();
         }
     }
     return 0;
 }
 
 int build_block_schedule(const int *Ap, const int *Aj, int nb, const int *tasks, int ntasks,
-                         Schedule &S, hipStream_t st, const double *Ax, int bs, bool independent)
+                         Schedule &S, hipStream_t st, const double *Ax, int bs, bool independent, bool block_flow)
 {
     (void)st;
     std::vector<int> order;
@@ -787,12 +805,16 @@ int build_block_schedule(const int *Ap, const int *Aj, int nb, const int *tasks,
             std::memcpy(gj.data() + gp[k], Aj + Ap[i], sizeof(int) * (size_t)len);
             std::memcpy(gx.data() + (long)gp[k] * B2, Ax + (long)Ap[i] * B2, sizeof(double) * (size_t)(len * B2));
         }
-        CHK(upload_bsr(S.Gb, ntasks, bs, gp.data(), gj.data(), gx.data(), nullptr));
-        // block Gauss-Seidel: the dataflow form (one persistent launch per smoother application), else for the levels of
-        // a large operator one launch per level from the sliced block form
-        if (!independent && gs_flow_mode() != 0 && (bs == 2 || bs == 3))
+        // block Gauss-Seidel: the dataflow form (one persistent launch per smoother application) serves the schedule
+        // alone; otherwise the level-ordered copy, and for the levels of a large operator its sliced block form
+        if (block_flow && !independent && gs_flow_mode() != 0 && (bs == 2 || bs == 3))
             CHK(build_block_flow_form(S.bflow, nb, bs, ntasks, S.level_ptr, rows, gp, gj, gx));
-        if (!independent && !S.bflow.ready) CHK(build_bsell_levels(S.Gb, S.level_ptr, S.rows, S.gb_level_slice, nullptr));
+        if (!S.bflow.ready) {
+            long acct = 0;
+            CHK(upload_bsr(S.Gb, ntasks, bs, gp.data(), gj.data(), gx.data(), &acct));
+            if (!independent) CHK(build_bsell_levels(S.Gb, S.level_ptr, S.rows, S.gb_level_slice, &acct));
+            S.level_copy_bytes = acct;
+        }
     }
     return 0;
 }
@@ -864,7 +886,7 @@ int gs_sweep_csr(const Schedule &S, bool bsr1, double *x, const double *b, const
                  hipStream_t st, bool allow_flow)
 {
     if (nseq <= 0) return 0;
-    if (allow_flow && S.flow.ready && (gs_flow_mode() == 2 || (gs_flow_mode() == 1 && S.flow_auto)))
+    if (S.flow.ready && (!S.G.Ap || (allow_flow && (gs_flow_mode() == 2 || (gs_flow_mode() == 1 && S.flow_auto)))))
         return gs_flow_sweep(S.flow, bsr1, x, b, seq, nseq, st);
     const bool perm = S.perm && gs_chain_enabled() && gs_chain_generation() == 2;
     DevCsr G = S.G;
@@ -955,7 +977,8 @@ static int gs_sweep_block(const Schedule &S, const DevBsr &Ab, BlockMode mode, c
 int block_gs_sweeps(const Schedule &S, const double *Dinv, double *x, const double *b, const unsigned char *seq, int nseq, hipStream_t st,
                     bool allow_flow)
 {
-    if (allow_flow && S.bflow.ready && gs_flow_mode() != 0) return block_flow_sweep(S.bflow, Dinv, x, b, seq, nseq, st);
+    (void)allow_flow;                  // (a schedule built with the dataflow form holds nothing else)
+    if (S.bflow.ready) return block_flow_sweep(S.bflow, Dinv, x, b, seq, nseq, st);
     for (int k = 0; k < nseq; ++k) CHK(sweep_block_schedule(S, BM_BLOCK_GS, Dinv, x, x, b, 1.0, seq[k] != 0, st));
     return 0;
 }
@@ -1548,6 +1571,7 @@ void amg_hier_destroy(amg_hier *h)
         free_smoother(L.sm[1]);
         if (L.sched_csr && L.sched_csr.use_count() == 1) L.sched_csr->release();
         if (L.sched_blk && L.sched_blk.use_count() == 1) L.sched_blk->release();
+        if (L.sched_bgs && L.sched_bgs.use_count() == 1) L.sched_bgs->release();
         free_csr(L.A); free_csr(L.P); free_csr(L.Rm); free_bsr(L.Ab);
         if (L.part.send_idx) hipFree(L.part.send_idx);
         if (L.part.gather_idx) hipFree(L.part.gather_idx);
@@ -1788,7 +1812,7 @@ static int need_schedule(amg_hier *h, Level &L, Smoother &s)
                 L.sched_blk = std::make_shared<Schedule>();
                 CHK(build_block_schedule(bp.data(), bj.data(), L.Ab.nbrows, nullptr, L.Ab.nbrows, *L.sched_blk, h->stream,
                                          bx.data(), L.Ab.bs));
-                h->dev_bytes += L.sched_blk->bflow.bytes;
+                h->dev_bytes += L.sched_blk->level_copy_bytes;
             }
             s.sched = L.sched_blk;
         } else {
@@ -1801,8 +1825,8 @@ static int need_schedule(amg_hier *h, Level &L, Smoother &s)
                     AMG_HIP(hipMemcpy(ax.data(), L.A.Ax, sizeof(double) * ax.size(), hipMemcpyDeviceToHost));
                 }
                 L.sched_csr = std::make_shared<Schedule>();
-                CHK(build_csr_schedule(ap.data(), aj.data(), ax.data(), n, nullptr, n, *L.sched_csr, h->stream));
-                h->dev_bytes += 12L * L.A.nnz + 12L * n + L.sched_csr->flow.bytes;
+                CHK(build_csr_schedule(ap.data(), aj.data(), ax.data(), n, nullptr, n, *L.sched_csr, h->stream, !h->comm));
+                h->dev_bytes += L.sched_csr->level_copy_bytes + L.sched_csr->flow.bytes;
             }
             s.sched = L.sched_csr;
         }
@@ -1840,14 +1864,17 @@ static int need_schedule(amg_hier *h, Level &L, Smoother &s)
             AMG_HIP(hipMemcpy(ax.data(), L.A.Ax, sizeof(double) * ax.size(), hipMemcpyDeviceToHost));
         }
         s.sched = std::make_shared<Schedule>();
-        CHK(build_csr_schedule(ap.data(), aj.data(), ax.data(), n, s.indices.data(), (int)s.indices.size(), *s.sched, h->stream));
+        CHK(build_csr_schedule(ap.data(), aj.data(), ax.data(), n, s.indices.data(), (int)s.indices.size(), *s.sched, h->stream, !h->comm));
+        h->dev_bytes += s.sched->level_copy_bytes + s.sched->flow.bytes;
     } else if (s.kind == AMG_SM_BLOCK_GAUSS_SEIDEL || s.kind == AMG_SM_BLOCK_JACOBI) {
         const DevBsr *Ab = s.Ablk_owned ? &s.Ablk : &L.Ab;
         if (!Ab->Ap || Ab->bs != s.bs) {
             set_error("block smoother: no BSR copy of A with the smoother's blocksize (amg_hier_set_block_matrix)");
             return AMG_ESTATE;
         }
-        if (s.kind == AMG_SM_BLOCK_GAUSS_SEIDEL) {
+        if (s.kind == AMG_SM_BLOCK_GAUSS_SEIDEL && !s.Ablk_owned && L.sched_bgs) {
+            s.sched = L.sched_bgs;                                     // pre- and post-smoother sweep the same blocks
+        } else if (s.kind == AMG_SM_BLOCK_GAUSS_SEIDEL) {
             std::vector<int> bp((size_t)Ab->nbrows + 1), bj((size_t)Ab->nblocks);
             std::vector<double> bx((size_t)Ab->nblocks * Ab->bs * Ab->bs);
             AMG_HIP(hipMemcpy(bp.data(), Ab->Ap, sizeof(int) * bp.size(), hipMemcpyDeviceToHost));
@@ -1857,7 +1884,9 @@ static int need_schedule(amg_hier *h, Level &L, Smoother &s)
             }
             s.sched = std::make_shared<Schedule>();
             CHK(build_block_schedule(bp.data(), bj.data(), Ab->nbrows, nullptr, Ab->nbrows, *s.sched, h->stream,
-                                     bx.data(), Ab->bs));
+                                     bx.data(), Ab->bs, false, !h->comm));
+            h->dev_bytes += s.sched->level_copy_bytes + s.sched->bflow.bytes;
+            if (!s.Ablk_owned) L.sched_bgs = s.sched;
         }
     }
     return 0;

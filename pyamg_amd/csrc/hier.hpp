@@ -54,14 +54,20 @@ struct Schedule {
     bool flow_auto = false;            // the default picks it for this schedule (wide or long-row levels that would be launches)
     int nlevels() const { return (int)level_ptr.size() - 1; }
     void release();
+    void drop_level_copies();          // the dataflow form serves this schedule: free the level-ordered copies of the other paths
+    long level_copy_bytes = 0;         // HBM held by those copies (0 after drop_level_copies)
 };
 
 int build_levels(int n, const int *Ap, const int *Aj, const int *tasks, int ntasks,
                  std::vector<int> &level_ptr, std::vector<int> &order);
+// allow_flow: the dataflow form may be built (and, where the default picks it, replaces the level-ordered copies);
+// false for row-partitioned hierarchies (several ranks may share a device)
 int build_csr_schedule(const int *Ap, const int *Aj, const double *Ax, int n, const int *tasks,
-                       int ntasks, Schedule &S, hipStream_t st);
+                       int ntasks, Schedule &S, hipStream_t st, bool allow_flow = true);
+// block_flow: the schedule is for BLOCK Gauss-Seidel (relaxation.h:756-810) and may be served by the dataflow form alone
 int build_block_schedule(const int *Ap, const int *Aj, int nb, const int *tasks, int ntasks,
-                         Schedule &S, hipStream_t st, const double *Ax = nullptr, int bs = 0, bool independent = false);
+                         Schedule &S, hipStream_t st, const double *Ax = nullptr, int bs = 0, bool independent = false,
+                         bool block_flow = false);
 int sweep_block_schedule(const Schedule &S, BlockMode mode, const double *Dinv, const double *xin, double *x, const double *b,
                          double omega, bool reverse, hipStream_t st);
 // block Gauss-Seidel: all directional sweeps of a smoother application (seq[k] != 0: backward); the dataflow form where built
@@ -126,6 +132,7 @@ struct Level {
     double *x = nullptr, *xalt = nullptr, *b = nullptr, *r = nullptr, *h = nullptr, *h2 = nullptr;
     double *amli[4] = {nullptr, nullptr, nullptr, nullptr};   // p0, p1, A*p, A*p_j (AMLI cycles, lazily)
     std::shared_ptr<Schedule> sched_csr, sched_blk;   // natural-order schedules, shared pre/post
+    std::shared_ptr<Schedule> sched_bgs;              // block Gauss-Seidel over the level's own blocks, shared pre/post
 };
 
 }  // namespace amg

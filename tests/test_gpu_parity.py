@@ -1395,6 +1395,67 @@ def test_dataflow_block_gauss_seidel_same_bits(bs, oracle):
     assert L.amg_gs_flow_status() == 0
 
 
+def test_config2_at_full_size_vs_oracle():
+    """BASELINE configuration C2 at the size BASELINE.json names: 2D Poisson 2000 x 2000 (4 M rows), our own SA setup
+    (six levels, the level sizes BASELINE.md lists), weighted Jacobi omega = 4/3 -- three cycles, iterates bit-identical to
+    the oracle's, history to 1e-12."""
+    from pyamg_amd.aggregation import poisson as native, smoothed_aggregation_solver
+    A = native((2000, 2000))
+    np.random.seed(0)
+    sm = ("jacobi", {"omega": 4.0 / 3.0})
+    ml = smoothed_aggregation_solver(A, presmoother=sm, postsmoother=sm)
+    assert [l.A.shape[0] for l in ml.levels] == [4000000, 667000, 74315, 8316, 931, 104]
+    np.random.seed(0)
+    b = np.random.rand(A.shape[0])
+    res = []
+    x = ml.solve(b, tol=0.0, maxiter=3, residuals=res)
+    levels, M = _oracle_levels(ml)
+    xo, reso = oracle_lib.Hierarchy(levels, M).solve(b, tol=0.0, maxiter=3)
+    assert np.array_equal(x, xo), np.abs(x - xo).max()
+    assert np.allclose(res, reso, rtol=1e-12)
+
+
+def test_config5_at_a_million_unknowns_vs_oracle():
+    """BASELINE configuration C5 above 10^6 unknowns (102^3 = 1 061 208, BSR 3x3, 5.2 M blocks): block-SA setup, symmetric
+    block Gauss-Seidel through the dataflow sweep (the (5, 3) kernel: three lanes per scalar row, five blocks each) --
+    two cycles, iterates bit-identical to the oracle's."""
+    from pyamg_amd.gallery import tet_diffusion
+    from pyamg_amd.aggregation import smoothed_aggregation_solver
+    A = tet_diffusion(102, blocksize=3)
+    assert A.shape[0] > 10 ** 6 and A.blocksize == (3, 3)
+    np.random.seed(0)
+    sm = ("block_gauss_seidel", {"sweep": "symmetric", "blocksize": 3})
+    ml = smoothed_aggregation_solver(A, presmoother=sm, postsmoother=sm)
+    np.random.seed(0)
+    b = np.random.rand(A.shape[0])
+    res = []
+    x = ml.solve(b, tol=0.0, maxiter=2, residuals=res)
+    levels, M = _oracle_levels(ml)
+    xo, reso = oracle_lib.Hierarchy(levels, M).solve(b, tol=0.0, maxiter=2)
+    assert np.array_equal(x, xo), np.abs(x - xo).max()
+    assert np.allclose(res, reso, rtol=1e-12)
+
+
+def test_config4_multicolour_gauss_seidel_on_one_gpu_vs_oracle():
+    """BASELINE configuration C4's smoother on one rank (no frozen halo): SA on a 3-D Poisson operator with multicolour
+    Gauss-Seidel -- gauss_seidel_indexed (relaxation.h:395-430) over a greedy colouring, two dependency levels per
+    sweep on the 7-point level -- against the oracle running the same index lists."""
+    from pyamg_amd.aggregation import poisson as native, smoothed_aggregation_solver
+    A = native((72, 70, 68))
+    np.random.seed(0)
+    sm = ("multicolor_gauss_seidel", {"sweep": "symmetric"})
+    ml = smoothed_aggregation_solver(A, presmoother=sm, postsmoother=sm)
+    assert ml.levels[0].presmoother.ncolours == 2
+    np.random.seed(0)
+    b = np.random.rand(A.shape[0])
+    res = []
+    x = ml.solve(b, tol=0.0, maxiter=3, residuals=res)
+    levels, M = _oracle_levels(ml)
+    xo, reso = oracle_lib.Hierarchy(levels, M).solve(b, tol=0.0, maxiter=3)
+    assert np.array_equal(x, xo), np.abs(x - xo).max()
+    assert np.allclose(res, reso, rtol=1e-12)
+
+
 # ---------------------------------------------------------------------------
 # device-resident Krylov methods (pyamg_amd/krylov.py): acceleration, smoothers, coarse solvers
 # ---------------------------------------------------------------------------
