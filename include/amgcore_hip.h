@@ -391,6 +391,10 @@ void amg_set_stencil_pairs(int on);
  * the sliced form (rows sorted by length in windows of 256 -- restrictions 64 --, slices of 64 rows stored entry-major: one lane per row,
  * no row pointer, no LDS); 0: from CSR.  Same bits. */
 void amg_set_sell_form(int on);
+/* the sliced form's column indices as 16-bit window codes (two per word, 16 window origins per slice; slices whose
+ * columns need more windows keep their 32-bit indices): 1 (default) built with the form and read by the kernel,
+ * 0: 32-bit indices.  10 B per stored entry instead of 12; same columns, same order, same bits. */
+void amg_set_sell_index16(int on);
 /* runs of narrow Gauss-Seidel dependency levels are swept by one workgroup in one launch: 2 (default) the sweep runs
  * in level-order numbering, new values are handed from level to level through LDS and everything else is requested
  * two levels ahead; 1 operands gathered back from L2 after each barrier (also what index lists and partitioned

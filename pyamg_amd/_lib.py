@@ -223,6 +223,8 @@ def lib():
     L.amg_set_stencil_pairs.restype = None
     L.amg_set_sell_form.argtypes = [I]
     L.amg_set_sell_form.restype = None
+    L.amg_set_sell_index16.argtypes = [I]
+    L.amg_set_sell_index16.restype = None
     L.amg_set_xcd_period.argtypes = [I]
     L.amg_set_xcd_period.restype = None
     L.amg_set_xcd_chunk.argtypes = [I]

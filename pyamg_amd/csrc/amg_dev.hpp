@@ -58,6 +58,15 @@ struct DevCsr {
     int *sl_col = nullptr;
     double *sl_val = nullptr;
     int sl_nslices = 0;
+    // 16-bit column codes of the sliced form (lossless): the columns a slice's 64 rows reference fall into a few narrow
+    // clusters; when at most 16 aligned windows of 4096 columns cover them, entry k of a row is stored as
+    // (window slot << 12) | (column & 4095), two codes per 32-bit word, and the slice's 16 window origins travel in one
+    // 64-byte load: 10 B per entry instead of 12.  Slices that need more windows keep reading sl_col (flag per slice).
+    unsigned *sl_code = nullptr;       // [sl_coff[nslices]] pairs of codes, pair-major per slice: [k / 2][64 lanes]
+    int *sl_org = nullptr;             // [nslices * 16] window origins (multiples of 4096)
+    long *sl_coff = nullptr;           // [nslices + 1] first code word of the slice
+    unsigned char *sl_flag16 = nullptr;// [nslices] 1 = this slice's entries are coded
+    double sl_frac16 = 0.0;            // fraction of the slices that are coded
     long sl_entries = 0;           // padded entries stored
     int sl_lo = 0, sl_hi = 0;      // rows the sliced form covers (all of them; a partitioned level: its interior rows)
     double *st_vals = nullptr;     // [nblocks256 * st_nu * 256]
@@ -163,6 +172,7 @@ int launch_stencil(StreamMode mode, const StreamArgs &a, const DevCsr &M, hipStr
 bool sell_supports(StreamMode mode);
 bool sell_enabled();
 void set_sell_form(int on);
+void set_sell_index16(int on);              // 1 (default): sliced forms built from now on also get 16-bit column codes and the kernel reads those
 int launch_sell(StreamMode mode, const StreamArgs &a, const DevCsr &M, hipStream_t st);
 int build_sell(DevCsr &M, long *acct, int row_lo = 0, int row_hi = -1);   // from the CSR arrays already in HBM (rows [lo, hi), default all); leaves M untouched if not worth it
 void free_sell(DevCsr &M);

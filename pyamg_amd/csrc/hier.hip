@@ -2634,6 +2634,7 @@ void amg_set_xcd_period(int on) { amg::set_xcd_period(on); }
 void amg_set_stencil_form(int on) { amg::set_stencil_form(on); }
 void amg_set_stencil_pairs(int on) { amg::set_stencil_pairs(on); }
 void amg_set_sell_form(int on) { amg::set_sell_form(on); }
+void amg_set_sell_index16(int on) { amg::set_sell_index16(on); }
 void amg_set_gs_chain(int on) { amg::set_gs_chain(on); }
 void amg_set_gs_level_hint(int on) { amg::set_gs_level_hint(on); }
 void amg_set_gs_flow(int mode) { amg::set_gs_flow(mode); }

@@ -102,9 +102,64 @@ struct SellArgs {
     const int *col;
     const double *val;
     int nslices;
+    const unsigned *code;        // 16-bit column codes (DevCsr::sl_code) or null
+    const int *org;
+    const long *coff;
+    const unsigned char *flag16;
 };
 
-template <int MODE>
+// 16-bit codes of one slice (one wave per slice): the distinct values of column >> 12 over the slice's real entries,
+// in order of first appearance (row of 64 entries by row, lanes in order) -- at most 16, else the slice keeps its
+// 32-bit columns; then the codes, two per word.
+__global__ __launch_bounds__(SL_WG) void sell_code_kernel(int nslices, const unsigned short *sl_len, const long *sl_off, const int *sl_col,
+                                                         const long *sl_coff, unsigned *sl_code, int *sl_org, unsigned char *sl_flag16)
+{
+    const int s = blockIdx.x * (SL_WG / SL_C) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (s >= nslices) return;
+    const long off = sl_off[s];
+    const int w = (int)((sl_off[s + 1] - off) >> 6);
+    const int len = sl_len[s * SL_C + lane];
+    int tab = -1;                                   // lane t < 16 holds window t's value of column >> 12
+    int cnt = 0;
+    bool ok = true;
+    for (int k = 0; k < w && ok; ++k) {
+        const bool real = k < len;
+        const int hi = real ? (sl_col[off + (long)k * SL_C + lane] >> 12) : -1;
+        bool pending = real;
+        while (true) {
+            // drop the lanes whose window is already in the table
+            bool found = false;
+            for (int t = 0; t < cnt; ++t) found |= (__shfl(tab, t, 64) == hi);
+            pending = pending && !found;
+            const unsigned long long m = __ballot(pending);
+            if (m == 0ULL) break;
+            if (cnt >= 16) { ok = false; break; }
+            const int first = __ffsll((long long)m) - 1;
+            const int nv = __shfl(hi, first, 64);
+            if (lane == cnt) tab = nv;
+            ++cnt;
+        }
+    }
+    if (lane < 16) sl_org[s * 16 + lane] = (ok && lane < cnt) ? (tab << 12) : 0;
+    if (lane == 0) sl_flag16[s] = ok ? 1 : 0;
+    if (!ok) return;
+    const long coff = sl_coff[s];
+    for (int k = 0; k < w; k += 2) {
+        unsigned word = 0;
+        for (int h = 0; h < 2; ++h) {
+            // (every lane runs the table look-up -- the shuffles read lanes 0 .. 15, which must be active; a padding
+            //  entry's column is 0 and its code is dropped)
+            const int c = (k + h < w) ? sl_col[off + (long)(k + h) * SL_C + lane] : 0;
+            int slot = 0;
+            for (int t = 0; t < cnt; ++t) slot = (__shfl(tab, t, 64) == (c >> 12)) ? t : slot;
+            const unsigned code = (k + h < len) ? (((unsigned)slot << 12) | ((unsigned)c & 4095u)) : 0u;
+            word |= code << (16 * h);
+        }
+        sl_code[coff + (long)(k >> 1) * SL_C + lane] = word;
+    }
+}
+
+template <int MODE, bool IDX16>
 __global__ __launch_bounds__(SL_WG) void sell_kernel(StreamArgs a, SellArgs S, int xcd_chunk)
 {
     const int blk = remap((int)blockIdx.x, (int)gridDim.x, xcd_chunk);
@@ -125,16 +180,45 @@ __global__ __launch_bounds__(SL_WG) void sell_kernel(StreamArgs a, SellArgs S, i
     }
     const int *cp = S.col + off + lane;
     const double *vp = S.val + off + lane;
+    bool coded = false;
+    int org = 0;
+    const unsigned *wp = nullptr;
+    if constexpr (IDX16) {
+        coded = S.flag16[s] != 0;                                   // uniform over the wave
+        if (coded) {
+            org = S.org[s * 16 + (lane & 15)];
+            wp = S.code + S.coff[s] + lane;
+        }
+    }
     double acc = 0.0;
     for (int k0 = 0; k0 < w; k0 += SL_PASS) {
         int c[SL_PASS];
         double v[SL_PASS], xv[SL_PASS];
+        if (IDX16 && coded) {
+            unsigned wd[SL_PASS / 2];
 #pragma unroll
-        for (int u = 0; u < SL_PASS; ++u) {
-            c[u] = 0; v[u] = 0.0;
-            if (k0 + u < w) {                                       // uniform: the whole wave requests or skips
-                c[u] = __builtin_nontemporal_load(&cp[(long)(k0 + u) * SL_C]);
-                v[u] = __builtin_nontemporal_load(&vp[(long)(k0 + u) * SL_C]);
+            for (int u = 0; u < SL_PASS; u += 2) {
+                wd[u / 2] = 0u;
+                if (k0 + u < w) wd[u / 2] = __builtin_nontemporal_load(&wp[(long)((k0 + u) >> 1) * SL_C]);
+            }
+#pragma unroll
+            for (int u = 0; u < SL_PASS; ++u) {
+                v[u] = 0.0;
+                if (k0 + u < w) v[u] = __builtin_nontemporal_load(&vp[(long)(k0 + u) * SL_C]);
+            }
+#pragma unroll
+            for (int u = 0; u < SL_PASS; ++u) {
+                const unsigned code = (wd[u / 2] >> (16 * (u & 1))) & 0xffffu;
+                c[u] = __shfl(org, (int)(code >> 12), 64) + (int)(code & 4095u);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < SL_PASS; ++u) {
+                c[u] = 0; v[u] = 0.0;
+                if (k0 + u < w) {                                       // uniform: the whole wave requests or skips
+                    c[u] = __builtin_nontemporal_load(&cp[(long)(k0 + u) * SL_C]);
+                    v[u] = __builtin_nontemporal_load(&vp[(long)(k0 + u) * SL_C]);
+                }
             }
         }
 #pragma unroll
@@ -168,6 +252,7 @@ __global__ __launch_bounds__(SL_WG) void sell_kernel(StreamArgs a, SellArgs S, i
 }
 
 int g_sell = 1;
+int g_sell_idx16 = std::getenv("AMG_SELL_IDX16") ? std::atoi(std::getenv("AMG_SELL_IDX16")) : 1;
 
 }   // namespace
 
@@ -178,7 +263,12 @@ void free_sell(DevCsr &M)
     if (M.sl_off) hipFree(M.sl_off);
     if (M.sl_col) hipFree(M.sl_col);
     if (M.sl_val) hipFree(M.sl_val);
+    if (M.sl_code) hipFree(M.sl_code);
+    if (M.sl_org) hipFree(M.sl_org);
+    if (M.sl_coff) hipFree(M.sl_coff);
+    if (M.sl_flag16) hipFree(M.sl_flag16);
     M.sl_row = nullptr; M.sl_len = nullptr; M.sl_off = nullptr; M.sl_col = nullptr; M.sl_val = nullptr;
+    M.sl_code = nullptr; M.sl_org = nullptr; M.sl_coff = nullptr; M.sl_flag16 = nullptr; M.sl_frac16 = 0.0;
     M.sl_nslices = 0; M.sl_entries = 0; M.sl_lo = M.sl_hi = 0;
 }
 
@@ -189,19 +279,22 @@ bool sell_supports(StreamMode mode)
 }
 bool sell_enabled() { return g_sell != 0; }
 void set_sell_form(int on) { g_sell = on; bump_config_epoch(); }
+void set_sell_index16(int on) { g_sell_idx16 = on; bump_config_epoch(); }
 
 int launch_sell(StreamMode mode, const StreamArgs &a, const DevCsr &M, hipStream_t st)
 {
     StreamArgs b = a;
     if (b.gscale == 0.0) b.gscale = 1.0;
-    SellArgs S{M.sl_row, M.sl_len, M.sl_off, M.sl_col, M.sl_val, M.sl_nslices};
+    const bool idx16 = M.sl_code != nullptr && g_sell_idx16 != 0;
+    SellArgs S{M.sl_row, M.sl_len, M.sl_off, M.sl_col, M.sl_val, M.sl_nslices, M.sl_code, M.sl_org, M.sl_coff, M.sl_flag16};
     const int grid = (M.sl_nslices + SL_WG / SL_C - 1) / (SL_WG / SL_C);
     // consecutive workgroups per XCD (speed only).  Measured at 400^3: 8 .. 128 equal within 1 %, 0 (round-robin over
     // the XCDs) 20 % slower, 512 2 % slower.  AMG_SELL_CHUNK overrides for A/B runs.
     static const int chunk_env = std::getenv("AMG_SELL_CHUNK") ? std::atoi(std::getenv("AMG_SELL_CHUNK")) : 32;
     const int chunk = grid >= 4096 ? chunk_env : 0;
     switch (mode) {
-#define SELL_CASE(MODE) case MODE: hipLaunchKernelGGL((sell_kernel<MODE>), dim3(grid), dim3(SL_WG), 0, st, b, S, chunk); break
+#define SELL_CASE(MODE) case MODE: if (idx16) hipLaunchKernelGGL((sell_kernel<MODE, true>), dim3(grid), dim3(SL_WG), 0, st, b, S, chunk); \
+                        else hipLaunchKernelGGL((sell_kernel<MODE, false>), dim3(grid), dim3(SL_WG), 0, st, b, S, chunk); break
     SELL_CASE(SM_MATVEC);
     SELL_CASE(SM_MATVEC_ACC);
     SELL_CASE(SM_RESIDUAL);
@@ -273,6 +366,32 @@ int build_sell(DevCsr &M, long *acct, int row_lo, int row_hi)
     AMG_HIP(hipDeviceSynchronize());
     M.sl_row = row; M.sl_len = len; M.sl_off = off_dev; M.sl_col = col; M.sl_val = val;
     M.sl_nslices = nslices; M.sl_entries = entries; M.sl_lo = row_lo; M.sl_hi = row_hi;
+    if (g_sell_idx16 && M.ncols >= 4096) {
+        // 16-bit column codes, two per word: code words of slice s start at coff[s] (ceil(width / 2) rows of 64 words)
+        std::vector<long> coff((size_t)nslices + 1);
+        coff[0] = 0;
+        for (int s = 0; s < nslices; ++s) coff[(size_t)s + 1] = coff[(size_t)s] + (long)((hw[(size_t)s] + 1) / 2) * SL_C;
+        AMG_HIP(hipMalloc((void **)&M.sl_coff, sizeof(long) * ((size_t)nslices + 1)));
+        AMG_HIP(hipMalloc((void **)&M.sl_code, sizeof(unsigned) * (size_t)std::max(coff[(size_t)nslices], 1L)));
+        AMG_HIP(hipMalloc((void **)&M.sl_org, sizeof(int) * (size_t)nslices * 16));
+        AMG_HIP(hipMalloc((void **)&M.sl_flag16, (size_t)nslices));
+        AMG_HIP(hipMemcpy(M.sl_coff, coff.data(), sizeof(long) * ((size_t)nslices + 1), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(sell_code_kernel, dim3((nslices + SL_WG / SL_C - 1) / (SL_WG / SL_C)), dim3(SL_WG), 0, nullptr, nslices, len, off_dev, col,
+                           M.sl_coff, M.sl_code, M.sl_org, M.sl_flag16);
+        e = hipGetLastError();
+        if (e != hipSuccess) return hip_fail(e, "sell code launch", __FILE__, __LINE__);
+        std::vector<unsigned char> hf((size_t)nslices);
+        AMG_HIP(hipMemcpy(hf.data(), M.sl_flag16, (size_t)nslices, hipMemcpyDeviceToHost));
+        long coded = 0;
+        for (unsigned char f : hf) coded += f ? 1 : 0;
+        M.sl_frac16 = nslices ? (double)coded / (double)nslices : 0.0;
+        if (acct) *acct += (long)(4L * coff[(size_t)nslices] + 65L * nslices + 8L * (nslices + 1));
+        if (M.sl_frac16 < 0.5) {                                    // mostly fall-back slices: not worth the second array
+            if (acct) *acct -= (long)(4L * coff[(size_t)nslices] + 65L * nslices + 8L * (nslices + 1));
+            hipFree(M.sl_code); hipFree(M.sl_org); hipFree(M.sl_coff); hipFree(M.sl_flag16);
+            M.sl_code = nullptr; M.sl_org = nullptr; M.sl_coff = nullptr; M.sl_flag16 = nullptr; M.sl_frac16 = 0.0;
+        }
+    }
     if (acct) *acct += (long)(sizeof(int) * (size_t)nslices * SL_C + sizeof(unsigned short) * (size_t)nslices * SL_C +
                               sizeof(long) * ((size_t)nslices + 1) + 12L * entries);
     return 0;

@@ -858,8 +858,18 @@ def save_levels(path, levels, coarse):
         for side in ("pre", "post"):
             if side in L:
                 d = L[side]
-                m[side] = None if d is None else {k: (v if not isinstance(v, np.ndarray) else v.tolist())
-                                                  for k, v in d.items()}
+                if d is None:
+                    m[side] = None
+                    continue
+                m[side] = {}
+                for k, v in d.items():
+                    if isinstance(v, np.ndarray) and v.size > 64:
+                        # (an index list of a multicolour ordering has one entry per unknown: a file of its own)
+                        fn = "%s%d_%s.npy" % (side, l, k)
+                        np.save(os.path.join(path, fn), v)
+                        m[side][k] = {"__npy__": fn}
+                    else:
+                        m[side][k] = v if not isinstance(v, np.ndarray) else v.tolist()
         meta["levels"].append(m)
     if coarse is not None:
         np.save(os.path.join(path, "coarse.npy"), np.asarray(coarse))
@@ -883,7 +893,11 @@ def load_levels(path):
                 L[nm] = _Lazy(Ap, Aj, Ax, tuple(m[nm]["shape"]), m[nm]["bsr"])
         for side in ("pre", "post"):
             if side in m:
-                L[side] = m[side]
+                d = m[side]
+                if d is not None:
+                    d = {k: (np.load(os.path.join(path, v["__npy__"]), mmap_mode="r") if isinstance(v, dict) and "__npy__" in v else v)
+                         for k, v in d.items()}
+                L[side] = d
         levels.append(L)
     coarse = np.load(os.path.join(path, "coarse.npy")) if meta["coarse"] else None
     return levels, coarse

@@ -1726,22 +1726,49 @@ def test_sliced_form_same_bits_as_csr():
                 assert np.array_equal(out[1], A @ x)
             finally:
                 op.close()
+        # 16-bit column codes of the sliced form (window slot << 12 | column & 4095, 16 windows per slice): rows whose
+        # columns sit in a few clusters around the row (coded slices) with a band of rows scattered over all columns in
+        # between (slices that keep their 32-bit indices), 300 k columns -> window slots up to 73
+        n = 300000
+        lens = rng.randint(18, 33, size=n)
+        rows = np.repeat(np.arange(n), lens)
+        cluster = rng.choice(np.array([-70000, -4100, -300, 0, 300, 4100, 70000]), size=rows.size)
+        cols = np.clip(rows + cluster + rng.randint(-140, 141, size=rows.size), 0, n - 1)
+        wild = (rows >= 120000) & (rows < 121000)
+        cols[wild] = rng.randint(0, n, size=int(wild.sum()))
+        A = sps.csr_matrix((rng.randn(rows.size), (rows, cols)), shape=(n, n)); A.sum_duplicates()
+        x = rng.randn(n)
+        out = {}
+        L.amg_set_sell_form(1)
+        for idx16 in (1, 0):
+            L.amg_set_sell_index16(idx16)
+            op = _DeviceOperator(A)
+            try:
+                _lib.check(L.amg_hier_finalize(op.h))
+                assert L.amg_hier_operator_form(op.h, 0) == 3
+                y = np.zeros(n)
+                _lib.check(L.amg_hier_matvec(op.h, 0, 0, _lib.dp(x), _lib.dp(y)))
+                out[idx16] = y
+            finally:
+                op.close()
+        assert np.array_equal(out[0], out[1]) and np.array_equal(out[1], A @ x)
         for sm in (("chebyshev", {"degree": 3}), ("jacobi", {"omega": 4.0 / 3.0})):
             np.random.seed(2)
             ml = smoothed_aggregation_solver(native((96, 90, 84)), presmoother=sm, postsmoother=sm)     # A_1: ~90 k rows
             b = np.random.rand(ml.levels[0].A.shape[0])
             out = {}
-            for on in (1, 0):
-                L.amg_set_sell_form(on)
+            for on, idx16 in ((1, 1), (1, 0), (0, 1)):
+                L.amg_set_sell_form(on); L.amg_set_sell_index16(idx16)
                 ml._invalidate_device()
                 res = []
                 x = ml.solve(b, tol=1e-30, maxiter=5, residuals=res)
                 if on:
                     assert L.amg_hier_operator_form(ml.device_hierarchy().h, 1) == 3
-                out[on] = (x, np.array(res))
-            assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+                out[(on, idx16)] = (x, np.array(res))
+            for key in ((1, 0), (0, 1)):
+                assert np.array_equal(out[(1, 1)][0], out[key][0]) and np.array_equal(out[(1, 1)][1], out[key][1]), key
     finally:
-        L.amg_set_sell_form(1)
+        L.amg_set_sell_form(1); L.amg_set_sell_index16(1)
 
 
 @pytest.mark.gpu
