@@ -212,6 +212,11 @@ int amg_hier_apply_aux(amg_hier *h, int lvl, int which, int slot, const double *
 double *amg_hier_scratch(amg_hier *h);
 /* allocate work vectors, build Gauss-Seidel level schedules */
 int amg_hier_finalize(amg_hier *h);
+/* After amg_hier_finalize: free the CSR arrays of operators whose stencil / sliced form serves every application the
+ * hierarchy's cycles make of them (A_l under polynomial / Jacobi smoothers from a complete stencil form; A_l (l >= 1),
+ * P_l, R_l under polynomial smoothers from a complete sliced form).  Lossless forms: same bits.  Returns the bytes
+ * freed (0 for partitioned hierarchies).  Afterwards a smoother that needs the arrays cannot be attached (AMG_ESTATE). */
+long amg_hier_release_sources(amg_hier *h);
 
 /* multilevel_solver.solve(b, x0, tol, maxiter, cycle) with accel=None
  * (multilevel.py:316-471).  x holds x0 on entry and the solution on exit;

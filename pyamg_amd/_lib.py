@@ -181,6 +181,8 @@ def lib():
     L.amg_comm_create.restype = V
     L.amg_comm_destroy.argtypes = [V]
     L.amg_comm_destroy.restype = None
+    L.amg_hier_release_sources.argtypes = [V]
+    L.amg_hier_release_sources.restype = C.c_long
     L.amg_mat_create.argtypes = [I, I, I, c_int_p, c_int_p, c_dbl_p]
     L.amg_mat_create.restype = V
     L.amg_mat_destroy.argtypes = [V]

@@ -172,7 +172,8 @@ int launch_stencil(StreamMode mode, const StreamArgs &a, const DevCsr &M, hipStr
 bool sell_supports(StreamMode mode);
 bool sell_enabled();
 void set_sell_form(int on);
-void set_sell_index16(int on);              // 1 (default): sliced forms built from now on also get 16-bit column codes and the kernel reads those
+void set_sell_index16(int on);
+bool sell_index16_enabled();              // 1 (default): sliced forms built from now on also get 16-bit column codes and the kernel reads those
 int launch_sell(StreamMode mode, const StreamArgs &a, const DevCsr &M, hipStream_t st);
 int build_sell(DevCsr &M, long *acct, int row_lo = 0, int row_hi = -1);   // from the CSR arrays already in HBM (rows [lo, hi), default all); leaves M untouched if not worth it
 void free_sell(DevCsr &M);

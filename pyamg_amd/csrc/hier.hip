@@ -864,10 +864,14 @@ int apply_operator(const DevCsr &M, StreamMode mode, const StreamArgs &a, hipStr
         if (bsell_applies(*M.blk, BM_SPMV, q)) return launch_bsell(*M.blk, BM_SPMV, q, st);
         return launch_bsr_stream(BM_SPMV, q, M.blk->nblocks, st);
     }
-    if (M.st_vals && stencil_enabled() && pattern_supports(mode)) return launch_stencil(mode, a, M, st);
+    if (M.st_vals && (stencil_enabled() || !M.Ap) && pattern_supports(mode)) return launch_stencil(mode, a, M, st);
     if (M.pat && pattern_supports(mode)) return launch_pattern(mode, a, M, st);
-    if (M.sl_val && sell_enabled() && sell_supports(mode) && a.row_lo == M.sl_lo && a.row_hi == M.sl_hi && !a.rowmap && a.Aj == M.Aj)
+    if (M.sl_val && (sell_enabled() || !M.Ap) && sell_supports(mode) && a.row_lo == M.sl_lo && a.row_hi == M.sl_hi && !a.rowmap && a.Aj == M.Aj)
         return launch_sell(mode, a, M, st);
+    if (!M.Ap || !a.Ap) {
+        set_error("this operator's CSR arrays were released (amg_hier_release_sources): the requested application needs them");
+        return AMG_ESTATE;
+    }
     return launch_stream(mode, a, st);
 }
 
@@ -1798,6 +1802,11 @@ int amg_hier_set_coarse_smoother(amg_hier *h, const amg_smoother_desc *d)
 static int need_schedule(amg_hier *h, Level &L, Smoother &s)
 {
     const int n = L.A.nrows;
+    if (!L.A.Ap && L.hasA && !(L.fmt == AMG_FMT_BSR && L.R > 1) &&
+        !(s.kind == AMG_SM_NONE || s.kind == AMG_SM_POLYNOMIAL || s.kind == AMG_SM_JACOBI || s.kind == AMG_SM_CALLBACK)) {
+        set_error("this level's CSR arrays were released (amg_hier_release_sources): rebuild the hierarchy to attach this smoother");
+        return AMG_ESTATE;
+    }
     const bool bsr_pt = (L.fmt == AMG_FMT_BSR && L.R > 1);
     if (s.kind == AMG_SM_GAUSS_SEIDEL || s.kind == AMG_SM_SOR) {
         if (bsr_pt) {
@@ -1921,7 +1930,7 @@ int amg_hier_apply(amg_hier *h, int lvl, int which, const double *x_dev, double 
     if (lvl < 0 || lvl >= h->nlevels || which < 0 || which > 2) { set_error("bad level/which"); return AMG_EINVAL; }
     Level &L = h->lv[lvl];
     const DevCsr &M = (which == AMG_MAT_A) ? L.A : (which == AMG_MAT_P ? L.P : L.Rm);
-    if (!M.Ap && !(M.blk && M.blk->Ap)) { set_error("operator not set"); return AMG_ESTATE; }
+    if (!M.Ap && !(M.blk && M.blk->Ap) && !M.st_vals && !M.sl_val) { set_error("operator not set"); return AMG_ESTATE; }
     return spmv(M, SM_MATVEC, x_dev, nullptr, nullptr, y_dev, nullptr, 0.0, h->stream);
 }
 
@@ -2043,6 +2052,63 @@ int amg_hier_comm_check(amg_hier *h)
 {
     ENTER(h);
     return h->comm ? comm_check(h->comm) : 0;
+}
+
+// Frees the CSR arrays of operators whose derived form (stencil / sliced) serves every application this hierarchy's
+// cycles make of them: A_l applied from a complete stencil form under polynomial / Jacobi smoothers, A_l (l >= 1), P_l,
+// R_l applied from a complete sliced form under polynomial smoothers.  Gauss-Seidel-type smoothers, partitioned
+// hierarchies and operators with fall-back row ranges keep theirs.  The forms are lossless, so iterates are unchanged;
+// afterwards the forms are used whatever the amg_set_stencil_form / amg_set_sell_form knobs say, and a smoother that
+// needs the CSR arrays cannot be attached any more (AMG_ESTATE).
+static bool csr_free_smoother(const Smoother &s, bool jacobi_ok)
+{
+    return s.kind == AMG_SM_NONE || s.kind == AMG_SM_POLYNOMIAL || (jacobi_ok && s.kind == AMG_SM_JACOBI);
+}
+
+static long release_csr_arrays(DevCsr &M)
+{
+    long freed = 0;
+    if (M.Ap) { hipFree(M.Ap); freed += 4L * (M.nrows + 1 + PAD); }
+    if (M.Aj) { hipFree(M.Aj); freed += 4L * (M.nnz + PAD); }
+    if (M.Ax) { hipFree(M.Ax); freed += 8L * (M.nnz + PAD); }
+    if (M.pat) { hipFree(M.pat); freed += 4L * M.nrows; }
+    if (M.dict_ptr) hipFree(M.dict_ptr);
+    if (M.dict_off) hipFree(M.dict_off);
+    if (M.Aj16) { hipFree(M.Aj16); freed += 2L * M.nnz; }
+    if (M.wg_base) hipFree(M.wg_base);
+    if (M.wg_flag) hipFree(M.wg_flag);
+    M.Ap = M.Aj = nullptr; M.Ax = nullptr; M.pat = nullptr; M.dict_ptr = M.dict_off = nullptr; M.npat = M.ndict = 0;
+    M.Aj16 = nullptr; M.wg_base = nullptr; M.wg_flag = nullptr;
+    return freed;
+}
+
+long amg_hier_release_sources(amg_hier *h)
+{
+    if (!h) return -1;
+    if (hipSetDevice(h->device) != hipSuccess || !h->finalized || h->comm) return 0;
+    if (h->stream) hipStreamSynchronize(h->stream);
+    drop_graphs(h);
+    long freed = 0;
+    for (int l = 0; l < h->nlevels; ++l) {
+        Level &L = h->lv[l];
+        const bool last = l == h->nlevels - 1;
+        const bool coarse_uses_A = last && h->coarse_kind != 1 && h->coarse_kind != 0;      // relaxation / callback coarse solvers
+        if (L.fmt == AMG_FMT_BSR && L.R > 1) continue;                                      // block levels keep their arrays
+        const bool sm_poly = last ? true : (csr_free_smoother(L.sm[0], false) && csr_free_smoother(L.sm[1], false));
+        const bool sm_jac = last ? true : (csr_free_smoother(L.sm[0], true) && csr_free_smoother(L.sm[1], true));
+        DevCsr &A = L.A;
+        if (A.Ap && !coarse_uses_A && !A.blk) {
+            const bool stencil_all = A.st_vals && A.st_nranges == 0 && !A.st_vi_on;
+            const bool sliced_all = A.sl_val && A.sl_lo == 0 && A.sl_hi == A.nrows && l > 0;    // (level 0 needs the fused norm)
+            if ((stencil_all && sm_jac) || (sliced_all && sm_poly)) freed += release_csr_arrays(A);
+        }
+        if (!last) {
+            for (DevCsr *M : {&L.P, &L.Rm})
+                if (M->Ap && M->sl_val && M->sl_lo == 0 && M->sl_hi == M->nrows && !M->blk) freed += release_csr_arrays(*M);
+        }
+    }
+    h->dev_bytes -= freed;
+    return freed;
 }
 
 int amg_hier_finalize(amg_hier *h)
@@ -2314,7 +2380,7 @@ int amg_hier_matvec(amg_hier *h, int lvl, int which, const double *x, double *y)
     if (lvl < 0 || lvl >= h->nlevels || which < 0 || which > 2) { set_error("bad level/which"); return AMG_EINVAL; }
     Level &L = h->lv[lvl];
     const DevCsr &M = (which == AMG_MAT_A) ? L.A : (which == AMG_MAT_P ? L.P : L.Rm);
-    if (!M.Ap && !(M.blk && M.blk->Ap)) { set_error("operator not set"); return AMG_ESTATE; }
+    if (!M.Ap && !(M.blk && M.blk->Ap) && !M.st_vals && !M.sl_val) { set_error("operator not set"); return AMG_ESTATE; }
     double *dx = nullptr, *dy = nullptr;
     CHK(dev_alloc(&dx, M.ncols, (long *)nullptr));
     CHK(dev_alloc(&dy, M.nrows, (long *)nullptr));
@@ -2359,11 +2425,15 @@ static double smoother_apps(const Smoother &s, bool x_zero)
 static double bytes_spmv_moved(const DevCsr &M)
 {
     if (M.blk && M.blk->Ap && (!M.Ap || bsr_spmv_enabled(M.blk->bs))) return bytes_spmv(M);
-    if (M.st_vals && stencil_enabled())     // padded values (or one-byte codes) + one mask word per row; no row pointer
+    if (M.st_vals && (stencil_enabled() || !M.Ap))     // padded values (or one-byte codes) + one mask word per row; no row pointer
         return ((M.st_vi_on && M.st_codes) ? 8.0 * (double)((M.st_nu + 7) / 8) : 8.0 * (double)M.st_nu) * 256.0 * (double)((M.nrows + 255) / 256) + (M.st_nu <= 7 ? 1.0 : 4.0) * M.nrows +
                8.0 * M.ncols + 8.0 * M.nrows;
-    if (!M.pat && M.sl_val && sell_enabled() && M.sl_lo == 0 && M.sl_hi == M.nrows)    // padded entries, slot bookkeeping (row id + length), slice offsets; no row pointer
-        return 12.0 * (double)M.sl_entries + 6.0 * 64.0 * M.sl_nslices + 8.0 * (M.sl_nslices + 1.0) + 8.0 * M.ncols + 8.0 * M.nrows;
+    if (!M.pat && M.sl_val && (sell_enabled() || !M.Ap) && M.sl_lo == 0 && M.sl_hi == M.nrows)    // padded entries, slot bookkeeping (row id + length), slice offsets; no row pointer
+    {
+        // (16-bit column codes: 2 B instead of 4 B per entry of a coded slice, + its 16 window origins)
+        const double f16 = (M.sl_code && sell_index16_enabled()) ? M.sl_frac16 : 0.0;
+        return (12.0 - 2.0 * f16) * (double)M.sl_entries + (6.0 * 64.0 + 64.0 * f16 + 1.0) * M.sl_nslices + 8.0 * (M.sl_nslices + 1.0) + 8.0 * M.ncols + 8.0 * M.nrows;
+    }
     if (!M.pat) {
         double idx = (M.Aj16 && index16_enabled()) ? (2.0 * M.i16_frac + 4.0 * (1.0 - M.i16_frac)) : 4.0;
         return (8.0 + idx) * (double)M.nnz + 4.0 * (M.nrows + 1.0) + 8.0 * M.ncols + 8.0 * M.nrows;
@@ -2453,9 +2523,9 @@ int amg_hier_operator_form(amg_hier *h, int lvl)
 {
     if (!h || lvl < 0 || lvl >= h->nlevels) return -1;
     const DevCsr &M = h->lv[lvl].A;
-    if (M.st_vals && stencil_enabled()) return 2;
+    if (M.st_vals && (stencil_enabled() || !M.Ap)) return 2;
     if (M.pat) return 1;
-    return (M.sl_val && sell_enabled()) ? 3 : 0;      // 3: sliced form (sell.hip)
+    return (M.sl_val && (sell_enabled() || !M.Ap)) ? 3 : 0;      // 3: sliced form (sell.hip)
 }
 double amg_hier_operator_bytes(amg_hier *h, int lvl, int moved)
 {
@@ -2479,7 +2549,7 @@ int amg_hier_time_spmv(amg_hier *h, int lvl, int which, int mode, int reps, doub
     if (lvl < 0 || lvl >= h->nlevels || reps < 1 || !ms) { set_error("bad arguments"); return AMG_EINVAL; }
     Level &L = h->lv[lvl];
     const DevCsr &M = (which == AMG_MAT_A) ? L.A : (which == AMG_MAT_P ? L.P : L.Rm);
-    if (!M.Ap && !(M.blk && M.blk->Ap)) { set_error("operator not set"); return AMG_ESTATE; }
+    if (!M.Ap && !(M.blk && M.blk->Ap) && !M.st_vals && !M.sl_val) { set_error("operator not set"); return AMG_ESTATE; }
     // vectors: A: x -> r ; P: coarse x -> h ; R: r -> coarse b
     const double *in; double *out;
     if (which == AMG_MAT_A) { in = L.x; out = L.r; }

@@ -280,6 +280,7 @@ bool sell_supports(StreamMode mode)
 bool sell_enabled() { return g_sell != 0; }
 void set_sell_form(int on) { g_sell = on; bump_config_epoch(); }
 void set_sell_index16(int on) { g_sell_idx16 = on; bump_config_epoch(); }
+bool sell_index16_enabled() { return g_sell_idx16 != 0; }
 
 int launch_sell(StreamMode mode, const StreamArgs &a, const DevCsr &M, hipStream_t st)
 {

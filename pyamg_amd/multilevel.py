@@ -10,6 +10,8 @@ multilevel.py:316-548 entirely on the device through libamgcore_hip.so.
 """
 from warnings import warn
 
+import os
+
 import numpy as np
 import scipy.linalg
 import scipy.sparse as sparse
@@ -213,6 +215,15 @@ class _DeviceHierarchy(object):
         elif kind != "none":
             raise NotImplementedError("coarse solver %s has no device implementation" % cs.name())
         _lib.check(self.L.amg_hier_finalize(self.h))
+        # Large hierarchies: the CSR arrays of operators that are only ever applied from their stencil / sliced form
+        # are not kept beside it (500^3 Chebyshev hierarchy: 56.6 -> 34 GB in HBM, same bits).  The host copies stay in
+        # ml.levels, so change_smoothers / a rebuilt mirror have everything they need.  AMG_RELEASE_SOURCES=0 keeps
+        # them (A/B runs of the other kernels on a live hierarchy), =1 releases at any size.
+        rel = os.environ.get("AMG_RELEASE_SOURCES")
+        big = levels[0].A.shape[0] >= 4000000
+        self.released_bytes = 0
+        if rel == "1" or (rel is None and big):
+            self.released_bytes = int(self.L.amg_hier_release_sources(self.h))
 
     def _check(self, rc):
         err, self._callback_error = self._callback_error, None

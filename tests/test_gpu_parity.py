@@ -1456,6 +1456,48 @@ def test_config4_multicolour_gauss_seidel_on_one_gpu_vs_oracle():
     assert np.allclose(res, reso, rtol=1e-12)
 
 
+def test_released_csr_sources_same_bits(monkeypatch):
+    """amg_hier_release_sources: operators that are only ever applied from their stencil / sliced form do not keep their
+    CSR arrays beside it (default for hierarchies of 4 M unknowns and more).  Same iterates and history as with the
+    arrays kept, for Chebyshev and Jacobi hierarchies, V and W cycles and PCG; less HBM; a Gauss-Seidel hierarchy keeps
+    everything; and change_smoothers afterwards rebuilds the mirror from the host copies."""
+    import pyamg_amd
+    from pyamg_amd.aggregation import poisson as native, smoothed_aggregation_solver
+    for sm in (("chebyshev", {"degree": 2}), ("jacobi", {"omega": 4.0 / 3.0})):
+        np.random.seed(3)
+        ml = smoothed_aggregation_solver(native((96, 92, 88)), presmoother=sm, postsmoother=sm)
+        b = np.random.rand(ml.levels[0].A.shape[0])
+        out = {}
+        for rel in ("0", "1"):
+            monkeypatch.setenv("AMG_RELEASE_SOURCES", rel)
+            ml._invalidate_device()
+            dev = ml.device_hierarchy()
+            res = []
+            x = ml.solve(b, tol=0.0, maxiter=4, residuals=res)
+            res2 = []
+            x2 = ml.solve(b, tol=0.0, maxiter=2, cycle="W", residuals=res2)
+            res3 = []
+            x3 = ml.solve(b, tol=1e-8, maxiter=6, accel="cg", residuals=res3)
+            out[rel] = (x, list(res), x2, list(res2), x3, list(res3), dev.device_bytes(), dev.released_bytes)
+        assert out["1"][7] > 0 and out["0"][7] == 0
+        assert out["1"][6] < out["0"][6] - 0.2 * out["1"][7]
+        for k in (0, 2, 4):
+            assert np.array_equal(out["0"][k], out["1"][k]), (sm[0], k)
+        for k in (1, 3, 5):
+            assert out["0"][k] == out["1"][k], (sm[0], k)
+    # Gauss-Seidel smoothers read the CSR arrays: nothing of A is released; and a released mirror is rebuilt on demand
+    monkeypatch.setenv("AMG_RELEASE_SOURCES", "1")
+    gs = ("gauss_seidel", {"sweep": "symmetric"})
+    pyamg_amd.change_smoothers(ml, gs, gs)
+    res = []
+    x = ml.solve(b, tol=0.0, maxiter=2, residuals=res)
+    levels, M = _oracle_levels(ml)
+    xo, reso = oracle_lib.Hierarchy(levels, M).solve(b, tol=0.0, maxiter=2)
+    assert np.array_equal(x, xo)
+    monkeypatch.delenv("AMG_RELEASE_SOURCES")
+    ml._invalidate_device()
+
+
 # ---------------------------------------------------------------------------
 # device-resident Krylov methods (pyamg_amd/krylov.py): acceleration, smoothers, coarse solvers
 # ---------------------------------------------------------------------------
