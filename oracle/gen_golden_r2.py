@@ -58,6 +58,16 @@ def main():
     gg.gen_hier(pyamg, "accel_bicgstab_F_2d", P((36, 36)), sa(20), jac, jac,
                 dict(tol=1e-9, maxiter=25, accel="bicgstab", cycle="F"))
 
+    # round 3: the remaining methods of pyamg.krylov as accelerators (krylov/_cr.py, _steepest_descent.py,
+    # _minimal_residual.py)
+    gg.gen_hier(pyamg, "accel_cr_V_2d", P((36, 36)), sa(20), jac, jac, dict(tol=1e-9, maxiter=25, accel="cr"))
+    gg.gen_hier(pyamg, "accel_cr_gs_3d", P((11, 12, 13)), sa(30), sgs, sgs, dict(tol=1e-9, maxiter=30, accel="cr"),
+                x0_random=True)
+    gg.gen_hier(pyamg, "accel_steepest_descent_V_2d", P((32, 32)), sa(20), sgs, sgs,
+                dict(tol=1e-9, maxiter=60, accel="steepest_descent"))
+    gg.gen_hier(pyamg, "accel_minimal_residual_W_2d", P((30, 30)), sa(10), jac, jac,
+                dict(tol=1e-9, maxiter=60, accel="minimal_residual", cycle="W"), x0_random=True)
+
     # ---- Krylov iterations as smoothers (smoothing.py:481-509; relaxation/tests/test_smoothing.py:25-30) and as
     #      coarse solvers (multilevel.py:642-660).  The C oracle has no Krylov methods: these are pinned by the
     #      reference's histories alone (file prefix krylov_).

@@ -251,6 +251,7 @@ int launch_copy_strided(double *dst, const double *src, int start, int count, in
 int launch_norm2(const double *x, long n, double *scratch, double *result_dev, hipStream_t st);
 int launch_dot(const double *x, const double *y, long n, double *scratch, double *result_dev, hipStream_t st);
 int launch_axmy(double *w, const double *v, double a, long n, hipStream_t st);      // w -= a*v
+int launch_axmy_ratio(double *w, const double *v, const double *num, const double *den, double sign, long n, hipStream_t st);   // w -= (sign * *num / *den) * v, scalars in device memory
 int launch_divide(double *w, double a, long n, hipStream_t st);                     // w /= a
 int launch_mul_elem(double *w, const double *d, long n, hipStream_t st);            // w *= d (elementwise)
 int launch_combine(double *out, const double *V, const double *coef_dev, int m, long n, long ld, hipStream_t st);

@@ -1323,22 +1323,16 @@ static int cycle(amg_hier *h, int lvl, double *&x, double *&xalt, const double *
         set_error("AMLI cycles have no row-partitioned form");
         return AMG_ENOTIMPL;
     } else {
-        // AMLI (multilevel.py:512-540): two coarse cycles from an all-ones guess, A-orthogonalised
-        // and combined with optimal step lengths.  The inner products come back to the host
-        // (5 scalars per level), so AMLI iterations are not graph-replayed.
+        // AMLI (multilevel.py:512-540): two coarse cycles from an all-ones guess, A-orthogonalised and combined with
+        // optimal step lengths.  The inner products stay in device memory and the updates read them from there
+        // (launch_axmy_ratio): no host round trip inside the cycle, so AMLI iterations are graph-replayed like the others.
         const int nAMLI = 2;
         const size_t bytes = sizeof(double) * (size_t)nc;
         for (int q = 0; q < 4; ++q)
             if (!Lc.amli[q]) CHK(dev_alloc(&Lc.amli[q], nc, &h->dev_bytes));
         double *p[2] = {Lc.amli[0], Lc.amli[1]};
         double *Apk = Lc.amli[2], *Apj = Lc.amli[3];
-        double *slot = h->norm_scratch + 1030;
-        auto dot = [&](const double *a, const double *bb, double *out) -> int {
-            CHK(launch_dot(a, bb, nc, h->norm_scratch, slot, st));
-            AMG_HIP(hipMemcpyAsync(out, slot, sizeof(double), hipMemcpyDeviceToHost, st));
-            AMG_HIP(hipStreamSynchronize(st));
-            return 0;
-        };
+        double *num = h->norm_scratch + 1027, *den = h->norm_scratch + 1029;
         for (int k = 0; k < nAMLI; ++k) {
             CHK(launch_fill(p[k], 1.0, nc, st));                           // p[k,:] = 1
             double *pk = p[k], *alt = Lc.xalt;
@@ -1347,20 +1341,17 @@ static int cycle(amg_hier *h, int lvl, double *&x, double *&xalt, const double *
                 AMG_HIP(hipMemcpyAsync(p[k], pk, bytes, hipMemcpyDeviceToDevice, st));
             }
             for (int j = 0; j < k; ++j) {
-                double num = 0, den = 0;
                 CHK(spmv(Lc.A, SM_MATVEC, p[k], nullptr, nullptr, Apk, nullptr, 0.0, st));
                 CHK(spmv(Lc.A, SM_MATVEC, p[j], nullptr, nullptr, Apj, nullptr, 0.0, st));
-                CHK(dot(p[j], Apk, &num));
-                CHK(dot(p[j], Apj, &den));
-                CHK(launch_axmy(p[k], p[j], num / den, nc, st));           // p[k] -= beta*p[j]
+                CHK(launch_dot(p[j], Apk, nc, h->norm_scratch, num, st));
+                CHK(launch_dot(p[j], Apj, nc, h->norm_scratch, den, st));
+                CHK(launch_axmy_ratio(p[k], p[j], num, den, 1.0, nc, st));  // p[k] -= beta*p[j], beta = num / den
             }
-            double num = 0, den = 0;
             CHK(spmv(Lc.A, SM_MATVEC, p[k], nullptr, nullptr, Apk, nullptr, 0.0, st));
-            CHK(dot(p[k], Lc.b, &num));
-            CHK(dot(p[k], Apk, &den));
-            const double alpha = num / den;
-            CHK(launch_axmy(Lc.x, p[k], -alpha, nc, st));                  // coarse_x += alpha*p[k]
-            CHK(launch_axmy(Lc.b, Apk, alpha, nc, st));                    // coarse_b -= alpha*Ap
+            CHK(launch_dot(p[k], Lc.b, nc, h->norm_scratch, num, st));
+            CHK(launch_dot(p[k], Apk, nc, h->norm_scratch, den, st));
+            CHK(launch_axmy_ratio(Lc.x, p[k], num, den, -1.0, nc, st));     // coarse_x += alpha*p[k], alpha = num / den
+            CHK(launch_axmy_ratio(Lc.b, Apk, num, den, 1.0, nc, st));       // coarse_b -= alpha*Ap
         }
     }
 
@@ -1439,7 +1430,7 @@ static int graph_iteration(amg_hier *h, int cyc, bool x_zero, double *dst)
 {
     hipStream_t st = h->stream;
     double *slot = h->norm_scratch + 1028;
-    if (!h->use_graphs || cyc == AMG_CYCLE_AMLI || h->has_callbacks) return iteration_with_norm(h, cyc, x_zero, dst);
+    if (!h->use_graphs || h->has_callbacks) return iteration_with_norm(h, cyc, x_zero, dst);
     if (h->graph_epoch != config_epoch()) {      // a launch knob changed: the captured launches are stale
         drop_graphs(h);
         h->graph_epoch = config_epoch();

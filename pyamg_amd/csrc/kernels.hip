@@ -2544,6 +2544,20 @@ __global__ void axpy_kernel(double *w, const double *v, double a, long n)   // w
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
         w[i] = w[i] - a * v[i];
 }
+// w = w - (sign * num / den) * v with the two scalars read from device memory (AMLI step lengths, multilevel.py:523-537:
+// the quotient is formed in fp64 exactly as the host would, sign = +-1 is exact)
+__global__ void axpy_ratio_kernel(double *w, const double *v, const double *num, const double *den, double sign, long n)
+{
+    const double a = sign * (*num / *den);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        w[i] = w[i] - a * v[i];
+}
+int launch_axmy_ratio(double *w, const double *v, const double *num, const double *den, double sign, long n, hipStream_t st)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(axpy_ratio_kernel, dim3(vec_grid(n)), dim3(256), 0, st, w, v, num, den, sign, n);
+    LAUNCH_CHECK("axmy ratio");
+}
 int launch_axmy(double *w, const double *v, double a, long n, hipStream_t st)
 {
     if (n <= 0) return 0;

@@ -197,6 +197,152 @@ def cg(V, b, x, tol=1e-5, maxiter=None, residuals=None, callback=None):
             return it
 
 
+def cr(V, b, x, tol=1e-5, maxiter=None, residuals=None, callback=None):
+    """Preconditioned conjugate residuals (krylov/_cr.py:86-187): history sqrt(<z, z>) with z = M r; the true residual is
+    recomputed at iterations 0, 8, 16, ... (`if mod(iter, 8) and iter > 0: r -= alpha Ap else: r = b - A x`)."""
+    if maxiter is None:
+        maxiter = int(1.3 * V.n) + 2
+    elif maxiter < 1:
+        raise ValueError("Number of iterations must be positive")
+    r, z, p, Ap, Az = V.new(), V.new(), V.new(), V.new(), V.new()
+    V.residual(r, b, x, Ap)
+    V.M(r, z)
+    V.copy(p, z)
+    zz = V.dot(z, z)
+    normr = np.sqrt(zz)
+    if residuals is not None:
+        residuals[:] = [normr]
+    normb = V.norm(b) or 1.0
+    if normr < tol * normb:
+        return 0
+    if normr != 0.0:
+        tol = tol * normr
+    it = 0
+    V.A(z, Az)
+    rAz = V.dot(r, Az)
+    V.A(p, Ap)
+    while True:
+        rAz_old = rAz
+        alpha = rAz / V.dot(Ap, Ap)
+        V.axpy(x, alpha, p)
+        if (it % 8) and it > 0:
+            V.axpy(r, -alpha, Ap)
+        else:
+            V.residual(r, b, x, z)
+        V.M(r, z)
+        V.A(z, Az)
+        rAz = V.dot(r, Az)
+        beta = rAz / rAz_old
+        V.xpby(p, beta, z)
+        V.xpby(Ap, beta, Az)
+        it += 1
+        zz = V.dot(z, z)
+        normr = np.sqrt(zz)
+        if residuals is not None:
+            residuals.append(normr)
+        if callback is not None:
+            callback(V.download(x))
+        if normr < tol:
+            return 0
+        if zz == 0.0:
+            return -1
+        if it == maxiter:
+            return it
+
+
+def steepest_descent(V, b, x, tol=1e-5, maxiter=None, residuals=None, callback=None):
+    """Preconditioned steepest descent (krylov/_steepest_descent.py:83-165): history sqrt(<r, M r>); the reference
+    recomputes r = b - A x whenever `mod(iter, 50)` is non-zero and updates it only at iterations 50, 100, ..."""
+    if maxiter is None:
+        maxiter = int(V.n)
+    elif maxiter < 1:
+        raise ValueError("Number of iterations must be positive")
+    r, z, q = V.new(), V.new(), V.new()
+    V.residual(r, b, x, q)
+    V.M(r, z)
+    rz = V.dot(r, z)
+    normr = np.sqrt(rz)
+    if residuals is not None:
+        residuals[:] = [normr]
+    normb = V.norm(b) or 1.0
+    if normr < tol * normb:
+        return 0
+    if normr != 0.0:
+        tol = tol * normr
+    it = 0
+    while True:
+        it += 1
+        V.A(z, q)
+        zAz = V.dot(z, q)
+        if zAz < 0.0:
+            return -1
+        alpha = rz / zAz
+        V.axpy(x, alpha, z)
+        if (it % 50) and it > 0:
+            V.residual(r, b, x, z)
+        else:
+            V.axpy(r, -alpha, q)
+        V.M(r, z)
+        rz = V.dot(r, z)
+        if rz < 0.0:
+            return -1
+        normr = np.sqrt(rz)
+        if residuals is not None:
+            residuals.append(normr)
+        if callback is not None:
+            callback(V.download(x))
+        if normr < tol:
+            return 0
+        if rz == 0.0:
+            return -1
+        if it == maxiter:
+            return it
+
+
+def minimal_residual(V, b, x, tol=1e-5, maxiter=None, residuals=None, callback=None):
+    """Preconditioned minimal residual iteration (krylov/_minimal_residual.py:83-145): r = M (b - A x), p = M A r,
+    alpha = <p, r> / <p, p>; history ||r||_2; same recompute pattern as steepest_descent."""
+    if maxiter is None:
+        maxiter = int(V.n)
+    elif maxiter < 1:
+        raise ValueError("Number of iterations must be positive")
+    r, p, t, u = V.new(), V.new(), V.new(), V.new()
+    V.residual(t, b, x, u)
+    V.M(t, r)
+    normr = V.norm(r)
+    if residuals is not None:
+        residuals[:] = [normr]
+    normb = V.norm(b) or 1.0
+    if normr < tol * normb:
+        return 0
+    if normr != 0.0:
+        tol = tol * normr
+    it = 0
+    while True:
+        it += 1
+        V.A(r, t)
+        V.M(t, p)
+        rMAr = V.dot(p, r)
+        if rMAr < 0.0:
+            return -1
+        alpha = rMAr / V.dot(p, p)
+        V.axpy(x, alpha, r)
+        if (it % 50) and it > 0:
+            V.residual(t, b, x, u)
+            V.M(t, r)
+        else:
+            V.axpy(r, -alpha, p)
+        normr = V.norm(r)
+        if residuals is not None:
+            residuals.append(normr)
+        if callback is not None:
+            callback(V.download(x))
+        if normr < tol:
+            return 0
+        if it == maxiter:
+            return it
+
+
 def cgne(V, b, x, tol=1e-5, maxiter=None, residuals=None, callback=None):
     """CG on A A^H y = b, x = A^H y (krylov/_cgne.py:85-170): 2-norm history."""
     maxiter = _ne_maxiter(V.n, maxiter)
@@ -347,6 +493,16 @@ def _inner_limits(n, restrt, maxiter):
     return 1, min(int(maxiter), n)
 
 
+def _solve_1x1(V, b, x):
+    """a 1 x 1 system is solved directly: x = b / A[0, 0] (krylov/_fgmres.py:157-160, _gmres_householder.py:151-154)"""
+    e, a = V.new(), V.new()
+    V.fill(e, 1.0)
+    V.A(e, a)
+    V.copy(x, b)
+    V.scale(x, x, 1.0 / V.peek(a, 0))
+    return 0
+
+
 def _reflect(V, v, W, j):
     """v <- (I - 2 w_j w_j^T) v  (amg_core/krylov.h:35-53: alpha = <w_j, v>; alpha *= -2; v += alpha w_j)"""
     V.axpy(v, -2.0 * V.dot(W[j], v), W[j])
@@ -358,12 +514,15 @@ def _hessenberg_step(V, v, W, inner, max_inner, Q, g, H):
     inner + 2 non-zero leading entries now -- the accumulated Givens rotations, the new rotation, the Hessenberg column."""
     n = V.n
     if inner != n - 1:
+        if inner < max_inner - 1:
+            # the reference starts every restart cycle from zeroed reflectors (W = zeros(...), _fgmres.py:195): after a
+            # breakdown (alpha == 0) the next step must not find the previous cycle's vector here (ADVICE r2)
+            V.fill(W[inner + 1], 0.0)
         alpha = V.norm(v, off=inner + 1)
         if alpha != 0:
             alpha = _sign(V.peek(v, inner + 1)) * alpha
             if inner < max_inner - 1:
                 w = W[inner + 1]
-                V.fill(w, 0.0)
                 V.copy(w, v, off=inner + 1)
                 V.poke(w, inner + 1, V.peek(w, inner + 1) + alpha)
                 V.scale(w, w, 1.0 / V.norm(w))
@@ -389,6 +548,8 @@ def fgmres(V, b, x, tol=1e-5, restrt=None, maxiter=None, residuals=None, callbac
     """Flexible GMRES, right preconditioning, Householder orthogonalisation (krylov/_fgmres.py:118-305); history:
     the 2-norm of the (true) residual, estimated through the rotated right-hand side inside a restart cycle."""
     n = V.n
+    if n == 1:
+        return _solve_1x1(V, b, x)
     max_outer, max_inner = _inner_limits(n, restrt, maxiter)
     r, v, t = V.new(), V.new(), V.new()
     V.residual(r, b, x, t)
@@ -457,6 +618,8 @@ def gmres(V, b, x, tol=1e-5, restrt=None, maxiter=None, residuals=None, callback
     """GMRES with LEFT preconditioning and Householder orthogonalisation (krylov/_gmres_householder.py:107-268, the
     reference's default `orthog`); history: the norm of the preconditioned residual M (b - A x)."""
     n = V.n
+    if n == 1:
+        return _solve_1x1(V, b, x)
     max_outer, max_inner = _inner_limits(n, restrt, maxiter)
     r, v, t = V.new(), V.new(), V.new()
     V.residual(t, b, x, v)
@@ -536,7 +699,8 @@ def _stagnated(V, update, x):
 
 
 # --------------------------------------------------------------------------- convenience: host vectors in and out
-METHODS = {"cg": cg, "fgmres": fgmres, "gmres": gmres, "bicgstab": bicgstab, "cgne": cgne, "cgnr": cgnr}
+METHODS = {"cg": cg, "fgmres": fgmres, "gmres": gmres, "bicgstab": bicgstab, "cgne": cgne, "cgnr": cgnr,
+           "cr": cr, "steepest_descent": steepest_descent, "minimal_residual": minimal_residual}
 _RESTARTED = ("fgmres", "gmres")
 
 

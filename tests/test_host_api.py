@@ -232,3 +232,39 @@ def test_hierarchy_save_load_round_trip(tmp_path):
             assert np.array_equal(pa, pb)
         else:
             assert pa.desc["name"] == pb.desc["name"] and pa.desc["iterations"] == pb.desc["iterations"]
+
+
+def test_gmres_drivers_restart_breakdown_and_1x1_on_host_vectors():
+    """pyamg_amd/krylov.py fgmres / gmres (krylov/_fgmres.py:118-305, _gmres_householder.py:107-268) on a NumPy stand-in for
+    the device vectors: restarted runs converge to the direct solution; a Krylov space that is exhausted inside a restart
+    cycle (breakdown, alpha == 0) with tol = 0 -- the fixed-count use of the Krylov smoothers -- leaves the exact solution
+    alone in the following cycles (the reflectors of a new cycle start from zero); a 1 x 1 system is solved
+    directly."""
+    import scipy.sparse as sps
+    from krylov_numpy import NumpyVectors
+    from pyamg_amd import krylov
+    rng = np.random.RandomState(0)
+    n = 40
+    A = sps.diags([-1.0, 2.5, -1.0], [-1, 0, 1], shape=(n, n)).tocsr()
+    b = rng.rand(n)
+    xs = np.linalg.solve(A.toarray(), b)
+    for method in (krylov.fgmres, krylov.gmres):
+        V = NumpyVectors(A)
+        bd, xd = V.upload(b), V.upload(np.zeros(n))
+        res = []
+        method(V, bd, xd, tol=1e-12, restrt=12, maxiter=20, residuals=res)
+        assert np.allclose(V.download(xd), xs, rtol=1e-9, atol=1e-12), method.__name__
+        assert res[-1] < 1e-9 * res[0]
+        # breakdown: A = I + rank-2 has a 3-dimensional Krylov space; restart length 6, three cycles, tol = 0
+        u, w = rng.rand(n), rng.rand(n)
+        B = np.eye(n) + np.outer(u, u) + np.outer(w, w)
+        V = NumpyVectors(B)
+        bd, xd = V.upload(b), V.upload(np.zeros(n))
+        method(V, bd, xd, tol=0.0, restrt=6, maxiter=3)
+        x = V.download(xd)
+        assert np.all(np.isfinite(x)) and np.allclose(B @ x, b, rtol=1e-8, atol=1e-10), method.__name__
+        # 1 x 1
+        V = NumpyVectors(np.array([[4.0]]))
+        bd, xd = V.upload([2.0]), V.upload([0.0])
+        assert method(V, bd, xd, tol=1e-8, restrt=3, maxiter=2) == 0
+        assert V.download(xd)[0] == 0.5
