@@ -2,8 +2,10 @@
 //
 // Transport "peer": every rank owns an ARENA in fine-grained device memory, exported once through HIP IPC and
 // mapped by all other ranks.  A hand-off is a PUSH over xGMI -- the producer's kernel stores straight into the
-// consumer's arena -- followed by a system-scope flag store; the consumer's stream runs a one-wave kernel that
-// polls its own flag (bounded by a wall-clock budget) and then unpacks.  Everything is an ordinary kernel on the
+// consumer's arena -- followed by a system-scope flag store; the consumer's stream polls its own flag (bounded by a
+// wall-clock budget) and then unpacks: four launches per hand-off (push, signal, wait, unpack).  AMG_COMM_FUSED=1: two -- the
+// push kernel's last workgroup raises the flags, every workgroup of the unpack kernel polls them before it copies
+// (correct, tested, but slower when ranks share one device; opt-in until measured on separate GPUs).  Everything is an ordinary kernel on the
 // hierarchy's stream: no host synchronisation, no library call, capturable in a hipGraph.  Sequence numbers live in
 // device memory (a replayed graph keeps counting), staging is double-buffered by the parity of the sequence number:
 // a producer can run at most one exchange ahead of its consumer on a channel because its next wait needs the
@@ -43,6 +45,7 @@ struct amg_comm {
     size_t arena_bytes = 0, flag_bytes = 0;
     std::vector<char *> peer;             // mapped arenas, peer[rank] == arena
     unsigned long long *seq = nullptr;    // device: [2 * nchannels] send / recv sequence numbers
+    unsigned *ticket = nullptr;           // device: [2 * nchannels] last-workgroup tickets of the fused push / unpack kernels
     int *timeout_flag = nullptr;          // device: set by a wait kernel whose budget ran out
     long long budget_ticks = 100000000LL * 20;   // 20 s of the 100 MHz wall clock
     // rccl transport

@@ -258,12 +258,14 @@ def _worker_one_way(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
-def test_one_directional_channel_keeps_its_staging_slots(tmp_path):
+@pytest.mark.parametrize("fused", ["0", "1"])
+def test_one_directional_channel_keeps_its_staging_slots(fused, tmp_path, monkeypatch):
     """a rank that only RECEIVES on a channel still acknowledges every exchange (flags travel
     between partners in either direction), so a producer cannot run two exchanges ahead and overwrite a staging slot
     that is still being unpacked.  300 back-to-back one-way exchanges over a chain of 3 ranks with stalls injected on both
     ends; every received entry checked."""
     world = 3
+    monkeypatch.setenv("AMG_COMM_FUSED", fused)        # four launches per hand-off (default) / two (push + signal, wait + unpack)
     mp.spawn(_worker_one_way, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     for r in range(world):
         assert int(np.load(tmp_path / ("bad_%d.npy" % r))[0]) == 0, r
@@ -290,13 +292,16 @@ def _worker_multicolour_gpu(rank, world, port, path, rep, transport):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,transport", [(2, "peer"), (3, "peer"), (2, "python")])
-def test_hybrid_multicolour_gauss_seidel_on_gpu_matches_partition_emulation(world, transport, tmp_path):
+@pytest.mark.parametrize("world,transport", [(2, "peer"), (3, "peer"), (2, "python"), (3, "peer-fused")])
+def test_hybrid_multicolour_gauss_seidel_on_gpu_matches_partition_emulation(world, transport, tmp_path, monkeypatch):
     """BASELINE configuration C4 as SURVEY 8(e) specifies it -- multicolour Gauss-Seidel (gauss_seidel_indexed,
     relaxation.h:395-430) inside a rank, Jacobi across ranks -- with 2 and 3 ranks sharing the device: gathered
     iterates bit-identical to the partition-emulating oracle (every partition relaxes its part of the index list with
     the reference kernel on a frozen copy)."""
     from test_distributed_cpu import multicolour_emulation, multicolour_hierarchy
+    if transport == "peer-fused":                     # the two-launch hand-off (opt-in)
+        monkeypatch.setenv("AMG_COMM_FUSED", "1")
+        transport = "peer"
     levels, coarse, b = multicolour_hierarchy(str(tmp_path), grid=(18, 16, 15))
     mp.spawn(_worker_multicolour_gpu, args=(world, _free_port(), str(tmp_path), 100, transport), nprocs=world, join=True)
     x = np.concatenate([np.load(tmp_path / ("x_%d.npy" % r)) for r in range(world)])
