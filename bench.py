@@ -706,7 +706,7 @@ def main():
                 value_index = {"error": repr(e)}
                 L.amg_hier_value_index(h, 0, 0)
         roofline["value_index_extra"] = value_index
-        for name in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
+        for name in ("r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
             pmc = os.path.join(ROOT, "profiles", name)
             if os.path.exists(pmc):
                 pj = json.load(open(pmc))

@@ -9,8 +9,13 @@ before, its off-rank operands arriving through a halo appended to the local
 vector, so Jacobi / polynomial (Chebyshev) cycles produce iterates that are
 BIT-IDENTICAL to the one-GPU run whatever the number of ranks; only the
 residual norm differs in the last bits (per-rank partial sums are all-reduced).
-Gauss-Seidel sweeps are inherently sequential across ranks and are not offered
-here (hybrid GS is the C4 item still open).
+Gauss-Seidel sweeps are inherently sequential across ranks: they are offered as
+HYBRID sweeps -- Gauss-Seidel inside a rank (lexicographic `gauss_seidel`, or an
+index list such as the multicolour ordering: `gauss_seidel_indexed`), Jacobi
+across ranks: the halo is refreshed once per directional sweep and frozen
+during it (BASELINE configuration C4).  Their iterates differ from the one-GPU
+sweep by construction; the oracle is the partition-emulating CPU run
+(tests/test_distributed_cpu.py::_hybrid_sweep).
 
 Layout per rank and level l (vector space V_l):  [ owned entries | halo ]
  * owned = the contiguous index range bounds[l][rank] .. bounds[l][rank+1]

@@ -1,0 +1,26 @@
+#!/bin/bash
+# Round-3 measurement pass on the GPU box (run from the repo root): the bench line of the metric configuration, the
+# rocprofv3 kernel trace of the same command, the FETCH_SIZE / WRITE_SIZE PMC passes of the level-0 kernel (separate
+# runs, counters only), and the bench lines of the other BASELINE configurations.
+set -o pipefail
+export TMPDIR=/tmp
+O=gpurun_out
+mkdir -p $O
+python bench.py > $O/r03_bench500.json 2> $O/r03_bench500.err && tail -c 400 $O/r03_bench500.json && \
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_r03 -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-value-index > $O/r03_bench500_under_rocprof.json 2> $O/r03_rocprof.err && \
+python tools/trace_cycle.py $(ls $O/prof_r03/*/*kernel_trace.csv | head -1) 10 > $O/r03_bench500_timed_region.txt && \
+cp $(ls $O/prof_r03/*/*kernel_stats.csv | head -1) $O/r03_bench500_kernel_stats.csv && \
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch_r03 -- python3 tools/pmc_spmv.py 500 1 32 1 > $O/r03_pmc_fetch.log 2>&1 && \
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write_r03 -- python3 tools/pmc_spmv.py 500 1 32 1 > $O/r03_pmc_write.log 2>&1 && \
+cp $(ls $O/pmc_fetch_r03/*/*counter_collection.csv | head -1) $O/r03_pmc_fetch_stencil_500_counter_collection.csv && \
+cp $(ls $O/pmc_write_r03/*/*counter_collection.csv | head -1) $O/r03_pmc_write_stencil_500_counter_collection.csv && \
+python tools/pmc_summary.py $O/r03_pmc_fetch_stencil_500_counter_collection.csv $O/r03_pmc_write_stencil_500_counter_collection.csv 500 $O/r03_pmc_summary.json $O/r03_bench500.json > /dev/null && \
+head -24 $O/r03_bench500_timed_region.txt && \
+python bench.py --config C1 > $O/r03_bench_C1.json 2> $O/r03_bench_C1.err && \
+python bench.py --config C2 > $O/r03_bench_C2.json 2> $O/r03_bench_C2.err && \
+python bench.py --config C5 --steps 20 > $O/r03_bench_C5.json 2> $O/r03_bench_C5.err && \
+python -c "
+import json
+for c in ('C1','C2','C5'):
+    d=json.load(open('$O/r03_bench_%s.json'%c)); r=d['roofline']; print(c, d['value'], d['ms_per_step'], r['achieved'], r['frac'], r['ms_per_launch'], d['cpu_baseline']['first_step_iterate_bit_identical_to_gpu'])
+"
