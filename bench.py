@@ -430,7 +430,12 @@ def config_main(args, rank, local_rank, world, torch, dist, L):
     res = np.zeros(max(args.steps, args.warmup) + 2)
     nres = C.c_int(0)
     NO_EARLY_STOP, DEVICE_VECTORS, X0_ZERO = 2, 4, 1
-    _lib.check(L.amg_hier_solve(h, b.ctypes.data, x.ctypes.data, 0.0, args.warmup, 0, _lib.dp(res), C.byref(nres), NO_EARLY_STOP | X0_ZERO))
+    # warm-up: at least 12 steps for the sub-millisecond configurations -- an iteration is captured into a hipGraph the
+    # second time its buffer state is seen (Jacobi swaps x / xalt level by level: several states), and a capture +
+    # instantiation inside a 20 ms timed region would be most of it; the count actually run is what the line reports
+    warmup = max(args.warmup, 12) if cfg in ("C1", "C2") else args.warmup
+    res = np.zeros(max(args.steps, warmup) + 2)
+    _lib.check(L.amg_hier_solve(h, b.ctypes.data, x.ctypes.data, 0.0, warmup, 0, _lib.dp(res), C.byref(nres), NO_EARLY_STOP | X0_ZERO))
     warm_res = res[:nres.value].copy()
 
     def sync_all():
@@ -497,7 +502,7 @@ def config_main(args, rank, local_rank, world, torch, dist, L):
         out = {
             "metric": "V-cycle iterations/sec (BASELINE configuration %s)" % cfg,
             "value": round(world * args.steps / wall, 4), "unit": "V-cycle iterations/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * wall / args.steps, 4),
+            "steps": args.steps, "warmup": warmup, "ms_per_step": round(1e3 * wall / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: %s, %d levels, V(1,1), b=rand seed 0" % (cfg, what, len(ml.levels)),
                        "baseline_config": cfg,
