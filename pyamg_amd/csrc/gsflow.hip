@@ -131,10 +131,14 @@ __global__ __launch_bounds__(64) void gs_flow_kernel(const FlowChunk *__restrict
     const long long t0 = wall_clock64();
     int s = 0, q = (int)blockIdx.x;
     while (q >= a.nchunks) { q -= a.nchunks; ++s; }
+    auto chunk_of = [&](int ss, int qq) { return (((a.dirmask >> ss) & 1u) != 0) ? a.nchunks - 1 - qq : qq; };
+    FlowChunk mnext = meta[s < a.nseq ? chunk_of(s, q) : 0];
     while (s < a.nseq) {
         const bool rev = ((a.dirmask >> s) & 1u) != 0;
-        const int c = rev ? a.nchunks - 1 - q : q;
-        const FlowChunk m = meta[c];
+        const FlowChunk m = mnext;
+        int s2 = s, q2 = q + NW;
+        while (q2 >= a.nchunks) { q2 -= a.nchunks; ++s2; }
+        mnext = meta[s2 < a.nseq ? chunk_of(s2, q2) : 0];      // the next task's descriptor: a scalar load, not needed before then
         const int seg = m.nslots;                       // slots per lane in this chunk (<= SEG)
         const bool leader = (lane % LPR) == 0 && t < m.nrows;
         const int k = m.row0 + (t < m.nrows ? t : 0);
@@ -162,19 +166,19 @@ __global__ __launch_bounds__(64) void gs_flow_kernel(const FlowChunk *__restrict
         const unsigned long long *Xo = a.X + (long)s * a.xstride;
         unsigned long long *Xn = a.X + (long)(s + 1) * a.xstride;
         // Gate: the row's latest operand of this sweep that is produced at least TWO levels earlier.  Until it exists the
-        // wave is far ahead of the sweep and polls this one word per row instead of all its operands.
-        {
-            unsigned long long gv = ald(Xn + gate);
-            for (unsigned spin = 0; __any(gv == FLOW_SENT); ++spin) {
-                __builtin_amdgcn_s_sleep(4);
-                if ((spin & 31u) == 31u && wall_clock64() - t0 > a.budget) {
-                    if (lane == 0) __hip_atomic_store(a.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    return;
-                }
-                if (gv == FLOW_SENT) gv = ald(Xn + gate);
+        // wave is far ahead of the sweep and polls this one word per row instead of all its operands; then the operands:
+        // produced by THIS sweep (earlier levels in sweep order) from the new buffer, everything else from the old one.
+        // (Requesting gate and operands together -- one round trip less when everything is ready -- measured SLOWER:
+        //  1.19 -> 1.46 us per level on the 7-point level, and level on the wide block levels.)
+        unsigned long long gv = ald(Xn + gate);
+        for (unsigned spin = 0; __any(gv == FLOW_SENT); ++spin) {
+            __builtin_amdgcn_s_sleep(4);
+            if ((spin & 31u) == 31u && wall_clock64() - t0 > a.budget) {
+                if (lane == 0) __hip_atomic_store(a.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
             }
+            if (gv == FLOW_SENT) gv = ald(Xn + gate);
         }
-        // operands: produced by THIS sweep (earlier levels in sweep order) -> new buffer, everything else -> old one
         const int xs = (int)a.xstride;
         unsigned long long xb[SEG];
 #pragma unroll
@@ -233,8 +237,7 @@ __global__ __launch_bounds__(64) void gs_flow_kernel(const FlowChunk *__restrict
             __hip_atomic_store(Xn + k, (unsigned long long)__double_as_longlong(xn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (last) a.x_out[orow] = xn;
         }
-        q += NW;
-        while (q >= a.nchunks) { q -= a.nchunks; ++s; }
+        s = s2; q = q2;
     }
 }
 
@@ -294,7 +297,7 @@ struct BlockTask {
 };
 
 template <int BS, int SEG, int LPR>
-__device__ __forceinline__ void bflow_load(BlockTask<BS, SEG> &T, int s, int q, const FlowChunk *__restrict__ meta, const int *__restrict__ col,
+__device__ __forceinline__ void bflow_load(BlockTask<BS, SEG> &T, int s, const FlowChunk &mpre, const int *__restrict__ col,
                                             const double *__restrict__ val, const double *__restrict__ bp, const int *__restrict__ rows,
                                             const int *__restrict__ gate_f, const int *__restrict__ gate_b, const BlockFlowArgs &a)
 {
@@ -305,8 +308,7 @@ __device__ __forceinline__ void bflow_load(BlockTask<BS, SEG> &T, int s, int q, 
     const int lane = threadIdx.x;
     const int br = lane / LW, grp = lane / BS, r = lane - grp * BS;
     const bool rev = ((a.dirmask >> s) & 1u) != 0;
-    const int c = rev ? a.nchunks - 1 - q : q;
-    T.m = meta[c];
+    T.m = mpre;                                     // the chunk descriptor was requested one task ahead (scalar load)
     const int seg = T.m.nslots;
     const int smax = seg > 0 ? seg - 1 : 0;
     const int gcl = min(grp, NG - 1);
@@ -344,17 +346,15 @@ __device__ __forceinline__ bool bflow_run(BlockTask<BS, SEG> &T, double *prod, l
     const int kb = m.row0 + (rowok ? br : 0);
     const unsigned long long *Xo = a.X + (long)s * a.xstride;
     unsigned long long *Xn = a.X + (long)(s + 1) * a.xstride;
-    {
-        const unsigned long long *gp_ = Xn + (long)T.gate * BS + r;
-        unsigned long long gv = ald(gp_);
-        for (unsigned spin = 0; __any(gv == FLOW_SENT); ++spin) {
-            __builtin_amdgcn_s_sleep(4);
-            if ((spin & 31u) == 31u && wall_clock64() - t0 > a.budget) {
-                if (lane == 0) __hip_atomic_store(a.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                return false;
-            }
-            if (gv == FLOW_SENT) gv = ald(gp_);
+    const unsigned long long *gp_ = Xn + (long)T.gate * BS + r;
+    unsigned long long gv = ald(gp_);
+    for (unsigned spin = 0; __any(gv == FLOW_SENT); ++spin) {
+        __builtin_amdgcn_s_sleep(4);
+        if ((spin & 31u) == 31u && wall_clock64() - t0 > a.budget) {
+            if (lane == 0) __hip_atomic_store(a.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
         }
+        if (gv == FLOW_SENT) gv = ald(gp_);
     }
     const int xs = (int)a.xstride;
     int idx[SEG];
@@ -448,11 +448,16 @@ __global__ __launch_bounds__(64) void bgs_flow_kernel(const FlowChunk *__restric
     int s = 0, q = (int)blockIdx.x;
     while (q >= a.nchunks) { q -= a.nchunks; ++s; }
     BlockTask<BS, SEG> T;
+    auto chunk_of = [&](int ss, int qq) { return (((a.dirmask >> ss) & 1u) != 0) ? a.nchunks - 1 - qq : qq; };
+    FlowChunk mnext = meta[s < a.nseq ? chunk_of(s, q) : 0];
     while (s < a.nseq) {
-        bflow_load<BS, SEG, LPR>(T, s, q, meta, col, val, bp, rows, gate_f, gate_b, a);
+        const FlowChunk mcur = mnext;
+        int s2 = s, q2 = q + NW;
+        while (q2 >= a.nchunks) { q2 -= a.nchunks; ++s2; }
+        mnext = meta[s2 < a.nseq ? chunk_of(s2, q2) : 0];      // scalar load, not needed before the next task
+        bflow_load<BS, SEG, LPR>(T, s, mcur, col, val, bp, rows, gate_f, gate_b, a);
         if (!bflow_run<BS, SEG, LPR>(T, prod, t0, a)) return;
-        q += NW;
-        while (q >= a.nchunks) { q -= a.nchunks; ++s; }
+        s = s2; q = q2;
     }
 }
 
