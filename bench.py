@@ -265,9 +265,12 @@ def partitioned_main(args, rank, local_rank, world, torch, dist):
         if flag.item() > 0.5:
             transport = cand
             break
+        # some rank could not use this transport: every rank tears down what IT built without barriers (the ranks whose
+        # constructor failed have nothing to close), then all of them meet once before the next candidate
         if S is not None and ok > 0.5:
-            S.close()
+            S.close(collective=False)
         S = None
+        dist.barrier(group=host_group)
     if S is None:
         raise SystemExit("no working inter-GPU transport")
     log("[bench] rank %d: rows %d..%d, halos per level %s, transport %s, partition+upload %.1fs" %

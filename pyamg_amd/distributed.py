@@ -346,7 +346,20 @@ class DistributedSolver(object):
             out[~m] = self.lv[l].n_own + np.searchsorted(halos[l], cols[~m])
             return out
         if self.transport != "python":
-            self._build_native(levels, coarse_dense, loc, own, rrows, renum)
+            self._comm = self._h = None
+            try:
+                self._build_native(levels, coarse_dense, loc, own, rrows, renum)
+            except Exception:
+                # a half-built engine must not outlive the failed constructor (its IPC arena would stay exported)
+                from . import _lib
+                Lb = _lib.lib()
+                if self._h:
+                    Lb.amg_hier_destroy(self._h)
+                if self._comm:
+                    Lb.amg_comm_destroy(self._comm)
+                self._comm = self._h = None
+                self.native = None
+                raise
             return
         for l, L in enumerate(levels):
             lv = self.lv[l]
@@ -589,14 +602,16 @@ class DistributedSolver(object):
         Lb, h, comm = self.native
         return int(Lb.amg_hier_device_bytes(h))
 
-    def close(self):
-        """collective: every rank's arena stays mapped in its peers until all have stopped exchanging"""
+    def close(self, collective=True):
+        """collective (default): every rank's arena stays mapped in its peers until all have stopped exchanging -- two
+        barriers, so EVERY rank must call it.  collective=False: tear down this rank's objects alone (a transport that
+        only some ranks could set up: the ranks whose constructor failed have nothing to close and join no barrier)."""
         if self.native is not None:
             Lb, h, comm = self.native
-            if self.world > 1:
+            if self.world > 1 and collective:
                 self.dist.barrier(group=self.host_group)
             Lb.amg_hier_destroy(h)
-            if self.world > 1:
+            if self.world > 1 and collective:
                 self.dist.barrier(group=self.host_group)
             Lb.amg_comm_destroy(comm)
             self.native = None
