@@ -101,6 +101,48 @@ def local_rows(M, lo, hi):
             np.asarray(Ax[s:e], dtype=np.float64))
 
 
+def local_rows_of(M, rows, col_map=None):
+    """the listed rows of a global operator, in list order, entries of a row in STORED order (the summation order):
+    (Ap rebased, Aj -- relabelled through col_map when given --, Ax)"""
+    Ap, Aj, Ax, _ = _csr_view(M)
+    rows = np.asarray(rows, dtype=np.int64)
+    Ap = np.asarray(Ap, dtype=np.int64)
+    start = Ap[rows]
+    lens = Ap[rows + 1] - start
+    out_p = np.zeros(len(rows) + 1, dtype=np.int64)
+    np.cumsum(lens, out=out_p[1:])
+    # position k of the output reads entry start[row of k] + (k - out_p[row of k])
+    src = np.repeat(start - out_p[:-1], lens) + np.arange(int(out_p[-1]), dtype=np.int64)
+    cols = np.asarray(Aj)[src].astype(np.int64)
+    if col_map is not None:
+        cols = col_map[cols]
+    return out_p, cols, np.asarray(Ax)[src].astype(np.float64)
+
+
+def owners_by_aggregate(levels, owner0, world):
+    """Ownership of every level by INDEX SET for an arbitrary numbering: level 0 as given (owner0[i] = rank of unknown i),
+    a coarse unknown goes to the rank that owns the fine row interpolating from it most strongly (its aggregate's
+    root for smoothed aggregation, the C-point itself for classical interpolation) -- aggregates are never split from
+    their strongest member, whatever the numbering."""
+    owners = [np.asarray(owner0, dtype=np.int64)]
+    for l in range(len(levels) - 1):
+        P = levels[l].get("P")
+        Ap, Aj, Ax, _ = _csr_view(P)
+        n, nc = P.shape
+        Ap = np.asarray(Ap, dtype=np.int64)
+        rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(Ap))
+        w = np.abs(np.asarray(Ax, dtype=np.float64))
+        cols = np.asarray(Aj, dtype=np.int64)
+        # strongest fine row of every coarse column (ties: the lowest row)
+        order = np.lexsort((rows, -w, cols))
+        first = np.ones(len(order), dtype=bool)
+        first[1:] = cols[order][1:] != cols[order][:-1]
+        oc = np.zeros(nc, dtype=np.int64)
+        oc[cols[order][first]] = owners[l][rows[order][first]]
+        owners.append(oc)
+    return owners
+
+
 class HipBackend(object):
     """csr_stream kernels + vector kernels on torch CUDA tensors (the product path)."""
 
@@ -218,10 +260,17 @@ class DistributedSolver(object):
     coarse_dense : dense coarse operator (x = M b) or None
     group : torch.distributed group for the halos / all-reduce (device tensors)
     host_group : group able to move CPU tensors (gloo) for the setup-time index exchange
+    owners : None (contiguous row blocks: level 0 cut evenly, coarser levels following it through P), or a list with
+             one integer array per level -- owners[l][i] = rank that owns unknown i of level l -- for OWNERSHIP BY INDEX
+             SET (arbitrary numberings; `owners_by_aggregate` derives the coarse levels from level 0).  A rank's local
+             numbering is then its owned indices in ascending order: internally the level is relabelled so that every
+             rank's set becomes a contiguous block (rows reordered, column indices relabelled, the entries of a row kept
+             in stored order -- hence the same row sums), and everything below works on blocks.  `owned(l)` lists a rank's
+             indices; solve() takes and returns the entries of b / x at owned(0), in that order.
     """
 
     def __init__(self, levels, coarse_dense, backend, rank, world, group=None, host_group=None,
-                 replicate_below=500000):
+                 replicate_below=500000, owners=None):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -233,6 +282,7 @@ class DistributedSolver(object):
         self.nlevels = len(levels)
         # level 0 is cut evenly; every coarser level follows the cut of the level above through P (coarse_bounds).
         # AMG_DIST_EVEN_SPLIT=1 cuts every level evenly instead (the round-1 behaviour, kept for A/B).
+        self.perm = None                 # index-set ownership: perm[l][k] = original index of relabelled unknown k
         self.bounds = [split_rows(levels[0]["A"].shape[0], world)]
         even = _os.environ.get("AMG_DIST_EVEN_SPLIT", "0") != "0"
         for l in range(1, self.nlevels):
@@ -240,6 +290,17 @@ class DistributedSolver(object):
                 self.bounds.append(split_rows(levels[l]["A"].shape[0], world))
             else:
                 self.bounds.append(coarse_bounds(levels[l - 1]["P"], self.bounds[l - 1]))
+        if owners is not None:
+            if len(owners) != self.nlevels:
+                raise ValueError("owners: one array per level")
+            self.perm, self.bounds = [], []
+            for l in range(self.nlevels):
+                o = np.asarray(owners[l], dtype=np.int64)
+                n_l = levels[l]["A"].shape[0]
+                if o.shape != (n_l,) or (n_l and (o.min() < 0 or o.max() >= world)):
+                    raise ValueError("owners[%d]: one rank in 0..%d per unknown" % (l, world - 1))
+                self.perm.append(np.argsort(o, kind="stable"))          # a rank's indices in ascending order
+                self.bounds.append(np.concatenate(([0], np.cumsum(np.bincount(o, minlength=world)))).astype(np.int64))
         # Coarse levels at or below `replicate_below` unknowns are REPLICATED: every rank holds them
         # whole and computes them redundantly (bit-identical everywhere), so they need no halo
         # exchange at all -- one all-gather of the restricted right-hand side enters the replicated
@@ -279,13 +340,29 @@ class DistributedSolver(object):
         if fr < nl and fr >= 1:
             rrows[fr - 1] = (int(self.bounds[fr][r]), int(self.bounds[fr][r + 1]))
         self.rrows = rrows
+        # index-set ownership: partitioned levels are relabelled (replicated ones keep their numbering)
+        relabel = [None] * nl
+        if self.perm is not None:
+            for l in range(min(fr, nl)):
+                inv = np.empty(len(self.perm[l]), dtype=np.int64)
+                inv[self.perm[l]] = np.arange(len(self.perm[l]), dtype=np.int64)
+                relabel[l] = inv
+            for l in range(fr, nl):
+                self.perm[l] = None
+        self._relabel = relabel
+
+        def rows_of(M, l_rows, lo, hi, l_cols):
+            if relabel[l_rows] is None and relabel[l_cols] is None:
+                return local_rows(M, lo, hi)
+            ids = np.arange(lo, hi, dtype=np.int64) if relabel[l_rows] is None else self.perm[l_rows][lo:hi]
+            return local_rows_of(M, ids, relabel[l_cols])
         loc = []
         for l, L in enumerate(levels):
-            d = {"A": local_rows(L["A"], *own[l])}
+            d = {"A": rows_of(L["A"], l, own[l][0], own[l][1], l)}
             d["bsr"] = bool(_csr_view(L["A"])[3])
             if l < nl - 1:
-                d["P"] = local_rows(L["P"], *own[l])            # fine rows, coarse columns (V_{l+1})
-                d["R"] = local_rows(L["R"], *rrows[l])          # coarse rows, fine columns (V_l)
+                d["P"] = rows_of(L["P"], l, own[l][0], own[l][1], l + 1)        # fine rows, coarse columns (V_{l+1})
+                d["R"] = rows_of(L["R"], l + 1, rrows[l][0], rrows[l][1], l)    # coarse rows, fine columns (V_l)
             loc.append(d)
         # union halo of every vector space
         halos = []
@@ -403,6 +480,8 @@ class DistributedSolver(object):
                         raise NotImplementedError("hybrid Gauss-Seidel disabled")
                     if nm == "gauss_seidel_indexed":
                         idx = np.asarray(s["indices"], dtype=np.int64)
+                        if self._relabel[l] is not None:
+                            idx = self._relabel[l][idx]                  # the list in the relabelled numbering, order kept
                         lo_, hi_ = own[l]
                         s["_local_order"] = (idx[(idx >= lo_) & (idx < hi_)] - lo_).astype(np.intc)
                         self.be.build_gs(lv.A, s["_local_order"])
@@ -558,6 +637,8 @@ class DistributedSolver(object):
                     d = None if sdesc is None else dict(sdesc)
                     if nm == "gauss_seidel_indexed":
                         idx = np.asarray(d["indices"], dtype=np.int64)
+                        if self._relabel[l] is not None:
+                            idx = self._relabel[l][idx]
                         lo_, hi_ = own[l]
                         d["indices"] = (idx[(idx >= lo_) & (idx < hi_)] - lo_).astype(np.intc)
                     _lib.check(Lb.amg_hier_set_smoother(h, l, which, _desc_struct(d, keep)))
@@ -789,6 +870,15 @@ class DistributedSolver(object):
             self.coarse_solve()
         else:
             self.cycle(0, cyc, x_zero, r_ready)
+
+    def owned(self, l=0):
+        """the indices of level l's unknowns this rank owns, in its local order (ascending)"""
+        lo, hi = int(self.bounds[l][self.rank]), int(self.bounds[l][self.rank + 1])
+        if l >= self.first_rep:
+            return np.arange(int(self.bounds[l][-1]), dtype=np.int64)
+        if self.perm is not None and self.perm[l] is not None:
+            return np.asarray(self.perm[l][lo:hi], dtype=np.int64)
+        return np.arange(lo, hi, dtype=np.int64)
 
     def solve(self, b_local, x0_local=None, tol=1e-5, maxiter=100, cycle="V", fixed=False):
         """multilevel.py:316-471 on the local slices; returns (x_local, residuals)"""

@@ -257,6 +257,86 @@ def test_hybrid_multicolour_gauss_seidel_matches_partition_emulation(world, tmp_
     assert not np.array_equal(x, x1) and np.linalg.norm(x - x1) < 0.5 * np.linalg.norm(x1)
 
 
+def _permuted_hierarchy(case, seed):
+    """a reference-built hierarchy with every level renumbered by a random permutation (rows reordered, columns
+    relabelled, the entries of a row in stored order): contiguous row blocks are then arbitrary subsets of the grid"""
+    import scipy.sparse as sps
+    g = golden_io.load_hier(case)
+    rng = np.random.RandomState(seed)
+    L = g["levels"]
+    q = [rng.permutation(lv["A"].shape[0]) for lv in L]               # new index k holds old unknown q[l][k]
+    q[-1] = np.arange(L[-1]["A"].shape[0])                            # (the dense coarse operator keeps its numbering)
+    inv = [np.argsort(p) for p in q]
+
+    def relabel(M, lr, lc):
+        M = sps.csr_matrix(M)
+        Ap, Aj, Ax = local_rows_of_host(M, q[lr], inv[lc])
+        return sps.csr_matrix((Ax, Aj, Ap), shape=M.shape)
+    out = []
+    for l, lv in enumerate(L):
+        d = {"A": relabel(lv["A"], l, l)}
+        if "P" in lv:
+            d["P"] = relabel(lv["P"], l, l + 1)
+            d["R"] = relabel(lv["R"], l + 1, l)
+            d["pre"], d["post"] = lv["pre"], lv["post"]
+        out.append(d)
+    return g, out, q
+
+
+def local_rows_of_host(M, rows, col_map):
+    from pyamg_amd.distributed import local_rows_of
+    return local_rows_of(M, rows, col_map)
+
+
+def _worker_index_sets(rank, world, port, path, case, seed):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cpu_backend import OracleBackend
+        from pyamg_amd.distributed import DistributedSolver, owners_by_aggregate, split_rows
+        g, levels, q = _permuted_hierarchy(case, seed)
+        n = levels[0]["A"].shape[0]
+        # ownership of level 0: the block of the ORIGINAL numbering an unknown sits in -- an index set in the permuted one
+        bnd = split_rows(n, world)
+        owner0 = np.searchsorted(bnd, q[0], side="right") - 1
+        owners = owners_by_aggregate(levels, owner0, world)
+        S = DistributedSolver(levels, g["coarse_pinv"], OracleBackend(), rank, world, replicate_below=40, owners=owners)
+        mine = S.owned(0)
+        assert np.array_equal(np.sort(mine), mine) and np.all(owner0[mine] == rank)
+        b = np.asarray(g["b"])[q[0]]
+        x, res = S.solve(b[mine], None, tol=0.0, maxiter=4, cycle="V", fixed=True)
+        np.save(os.path.join(path, "x_%d.npy" % rank), x)
+        np.save(os.path.join(path, "i_%d.npy" % rank), mine)
+        np.save(os.path.join(path, "halo_%d.npy" % rank), np.array([lv.n_halo for lv in S.lv]))
+        # the same ranks with contiguous blocks of the permuted numbering: what ownership by range would exchange
+        S2 = DistributedSolver(levels, g["coarse_pinv"], OracleBackend(), rank, world, replicate_below=40)
+        np.save(os.path.join(path, "halo_range_%d.npy" % rank), np.array([lv.n_halo for lv in S2.lv]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["sa_jacobi_2d", "sa_cheb2_3d"])
+def test_ownership_by_index_set_on_a_permuted_hierarchy(case, tmp_path):
+    """a hierarchy in an ARBITRARY numbering (every level randomly permuted), partitioned over 8 ranks by
+    index set -- level 0 by the grid block an unknown sits in, coarser levels by `owners_by_aggregate` -- gives the
+    single-process iterates bit for bit (a rank's local numbering is its owned indices in ascending order, entries of a
+    row keep their stored order), and exchanges far smaller halos than contiguous blocks of that numbering would."""
+    world = 8
+    seed = 7
+    mp.spawn(_worker_index_sets, args=(world, _free_port(), str(tmp_path), case, seed), nprocs=world, join=True)
+    g, levels, q = _permuted_hierarchy(case, seed)
+    n = levels[0]["A"].shape[0]
+    x = np.zeros(n)
+    for r in range(world):
+        x[np.load(tmp_path / ("i_%d.npy" % r))] = np.load(tmp_path / ("x_%d.npy" % r))
+    b = np.asarray(g["b"])[q[0]]
+    xs, _ = oracle_lib.Hierarchy(levels, g["coarse_pinv"]).solve(b, tol=0.0, maxiter=4)
+    assert np.array_equal(x, xs), np.abs(x - xs).max()
+    halo = sum(int(np.load(tmp_path / ("halo_%d.npy" % r))[0]) for r in range(world))
+    halo_range = sum(int(np.load(tmp_path / ("halo_range_%d.npy" % r))[0]) for r in range(world))
+    assert halo < 0.5 * halo_range, (halo, halo_range)
+
+
 def test_coarse_bounds_follow_the_prolongator():
     """distributed.coarse_bounds: a coarse cut that follows the fine cut through P never needs more off-rank
     columns of P than the even split does by more than a few rows, stays balanced, and degenerates to the even

@@ -271,6 +271,49 @@ def test_one_directional_channel_keeps_its_staging_slots(fused, tmp_path, monkey
         assert int(np.load(tmp_path / ("bad_%d.npy" % r))[0]) == 0, r
 
 
+def _worker_index_sets_gpu(rank, world, port, path, case, seed):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    _transport_env(rank, "peer")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    S = None
+    try:
+        from pyamg_amd.distributed import DistributedSolver, HipBackend, owners_by_aggregate, split_rows
+        from test_distributed_cpu import _permuted_hierarchy
+        g, levels, q = _permuted_hierarchy(case, seed)
+        n = levels[0]["A"].shape[0]
+        owner0 = np.searchsorted(split_rows(n, world), q[0], side="right") - 1
+        owners = owners_by_aggregate(levels, owner0, world)
+        S = DistributedSolver(levels, g["coarse_pinv"], HipBackend(0), rank, world, replicate_below=40, owners=owners)
+        assert S.native is not None
+        mine = S.owned(0)
+        b = np.asarray(g["b"])[q[0]]
+        x, res = S.solve(b[mine], None, tol=0.0, maxiter=4, cycle="V", fixed=True)
+        np.save(os.path.join(path, "x_%d.npy" % rank), x)
+        np.save(os.path.join(path, "i_%d.npy" % rank), mine)
+    finally:
+        if S is not None:
+            S.close()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["sa_jacobi_2d", "sa_cheb2_3d"])
+def test_ownership_by_index_set_on_gpu(case, tmp_path):
+    """a randomly renumbered hierarchy partitioned by INDEX SET over 3 ranks sharing the device (C++ engine, peer
+    transport): gathered iterates bit-identical to the single-process oracle solve of the renumbered hierarchy"""
+    import oracle_lib
+    from test_distributed_cpu import _permuted_hierarchy
+    world, seed = 3, 11
+    mp.spawn(_worker_index_sets_gpu, args=(world, _free_port(), str(tmp_path), case, seed), nprocs=world, join=True)
+    g, levels, q = _permuted_hierarchy(case, seed)
+    x = np.zeros(levels[0]["A"].shape[0])
+    for r in range(world):
+        x[np.load(tmp_path / ("i_%d.npy" % r))] = np.load(tmp_path / ("x_%d.npy" % r))
+    b = np.asarray(g["b"])[q[0]]
+    xs, _ = oracle_lib.Hierarchy(levels, g["coarse_pinv"]).solve(b, tol=0.0, maxiter=4)
+    assert np.array_equal(x, xs), np.abs(x - xs).max()
+
+
 def _worker_multicolour_gpu(rank, world, port, path, rep, transport):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
