@@ -137,6 +137,7 @@ int gs_csr_common(const int *Ap, int Ap_size, const int *Aj, const double *Ax, d
     CHK(db.from_host(b, sizeof(double) * (size_t)b_size));
     CHK(run_csr_levels(sh.S, bsr1, dx.d(), db.d()));
     AMG_HIP(hipDeviceSynchronize());
+    if (gs_flow_status() != 0) { set_error("a dataflow Gauss-Seidel sweep ran out of its time budget"); return AMG_ESTATE; }
     return dx.to_host(x, sizeof(double) * (size_t)x_size);
 }
 
@@ -339,6 +340,7 @@ int amgcore_block_gauss_seidel_f64(const int Ap[], int Ap_size, const int Aj[], 
     const unsigned char fwd = 0;
     CHK(block_gs_sweeps(sh.S, dd.d(), dx.d(), db.d(), &fwd, 1, nullptr));
     AMG_HIP(hipDeviceSynchronize());
+    if (gs_flow_status() != 0) { set_error("a dataflow block Gauss-Seidel sweep ran out of its time budget"); return AMG_ESTATE; }
     return dx.to_host(x, sizeof(double) * (size_t)x_size);
 }
 
