@@ -307,7 +307,7 @@ constexpr int FLOW_MAXSEQ = 4;          // directional sweeps per launch (buffer
 struct FlowChunk { int row0, nrows, nslots, lvl_lo, lvl_hi, off, pad0, pad1; };   // nslots: slots per LANE; off: first slot row of the chunk (x 64 entries)
 struct FlowForm {
     bool ready = false;
-    int n = 0, nchunks = 0, nlevels = 0, lpr = 1;    // lpr: lanes sharing a row (1 .. 64, by the longest row: 8 slots per lane)
+    int n = 0, ncols = 0, nchunks = 0, nlevels = 0, lpr = 1;    // ncols >= n: columns n .. ncols-1 are frozen operands (a partitioned level's halo); lpr: lanes sharing a row (1 .. 64, by the longest row: 8 slots per lane)
     long slot_rows = 0;                 // rows of 64 (value, column) pairs stored
     int *rowmap = nullptr;              // [n] original row of level-order position k (rows of a level sorted by length)
     FlowChunk *meta = nullptr;          // [nchunks]
@@ -323,7 +323,7 @@ struct FlowForm {
 };
 // from the level-ordered copy of a schedule (host arrays): leaves F.ready false when the form does not apply
 int build_flow_form(FlowForm &F, int n, int ntasks, const std::vector<int> &level_ptr, const std::vector<int> &rowmap,
-                    const std::vector<int> &gp, const std::vector<int> &gj, const std::vector<double> &gx);
+                    const std::vector<int> &gp, const std::vector<int> &gj, const std::vector<double> &gx, int ncols = 0);
 int gs_flow_sweep(const FlowForm &F, bool bsr1, double *x, const double *b, const unsigned char *seq, int nseq, hipStream_t st);
 // block Gauss-Seidel (relaxation.h:756-810) the same way: a lane per SCALAR row, LPR lanes per scalar row, FLOW_SEG
 // blocks per lane; positions count block rows, the iterate buffers hold bs scalars per block row

@@ -4,6 +4,7 @@
 // torch tensors so that torch.distributed (RCCL) can move the halos.
 #include "hier.hpp"
 
+#include <cstdlib>
 #include <cstring>
 
 namespace amg {
@@ -91,7 +92,10 @@ int amg_mat_build_gs(amg_mat *m, const int *order, int norder)
     }
     if (m->sched) { m->sched->release(); delete m->sched; m->sched = nullptr; }
     m->sched = new Schedule();
-    int rc = build_csr_schedule(ap.data(), aj.data(), ax.data(), n, order, order ? norder : n, *m->sched, nullptr);
+    // halo columns (ncols > nrows) mean a rank of a partitioned solve: dataflow sweeps only where ranks do not share a device
+    const char *df = std::getenv("AMG_DIST_FLOW");
+    const bool allow_flow = m->M.ncols == n || (df && std::atoi(df) != 0);
+    int rc = build_csr_schedule(ap.data(), aj.data(), ax.data(), n, order, order ? norder : n, *m->sched, nullptr, allow_flow, m->M.ncols);
     if (rc != 0) { m->sched->release(); delete m->sched; m->sched = nullptr; }
     return rc;
 }

@@ -95,13 +95,20 @@ __device__ __forceinline__ void flow_wave_sync()
 }
 
 // x (original numbering) -> X[0] (level order), b -> bp; X[1..nseq] = sentinel; entry n of every buffer = 0.0
+// (columns n .. ncols-1 are a partitioned level's HALO: operands no local row writes, frozen during the sweep -- they sit
+//  behind the owned unknowns in every buffer; entry ncols of every buffer is the permanent 0.0)
 __global__ __launch_bounds__(256) void flow_gather_kernel(const int *rowmap, const double *x, const double *b, unsigned long long *X,
-                                                           double *bp, long xstride, int n, int nseq)
+                                                           double *bp, long xstride, int n, int ncols, int nseq)
 {
     const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k > n) return;
-    if (k == n) {
-        for (int s = 0; s <= nseq; ++s) X[(long)s * xstride + n] = 0ULL;
+    if (k > ncols) return;
+    if (k >= n) {
+        unsigned long long hb = 0ULL;
+        if (k < ncols) {
+            hb = (unsigned long long)__double_as_longlong(x[k]);
+            if (hb == FLOW_SENT) hb |= FLOW_QUIET;
+        }
+        for (int s = 0; s <= nseq; ++s) X[(long)s * xstride + k] = hb;
         return;
     }
     const int i = rowmap[k];
@@ -728,12 +735,13 @@ int gs_flow_status()
 
 // rowmap / gp / gj / gx: the schedule's level-ordered copy (row k of it = original row rowmap[k], ORIGINAL columns)
 int build_flow_form(FlowForm &F, int n, int ntasks, const std::vector<int> &level_ptr, const std::vector<int> &rowmap,
-                    const std::vector<int> &gp, const std::vector<int> &gj, const std::vector<double> &gx)
+                    const std::vector<int> &gp, const std::vector<int> &gj, const std::vector<double> &gx, int ncols)
 {
     F.release();
     const int nl = (int)level_ptr.size() - 1;
+    if (ncols < n) ncols = n;
     if (n <= 0 || ntasks != n || nl <= 0) return 0;
-    if ((double)n * (FLOW_MAXSEQ + 1) >= 2.0e9) return 0;                      // operand positions are 32-bit offsets across the buffers
+    if ((double)ncols * (FLOW_MAXSEQ + 1) >= 2.0e9) return 0;                  // operand positions are 32-bit offsets across the buffers
     // every unknown listed exactly once, all columns inside, a nonzero diagonal in every row (relaxation.h:58-60
     // leaves a row with a zero diagonal untouched: such operators keep the level-scheduled kernels)
     std::vector<int> cnt((size_t)n), seen((size_t)n, 0);
@@ -748,7 +756,7 @@ int build_flow_form(FlowForm &F, int n, int ntasks, const std::vector<int> &leve
         double d = 0.0;
         for (int q = gp[(size_t)k]; q < gp[(size_t)k + 1]; ++q) {
             const int j = gj[(size_t)q];
-            if (j < 0 || j >= n) return 0;
+            if (j < 0 || j >= ncols) return 0;
             if (j == i) { d = gx[(size_t)q]; has_d = true; }                   // the last diagonal entry wins (relaxation.h:51-52)
             else ++c;
         }
@@ -786,7 +794,7 @@ int build_flow_form(FlowForm &F, int n, int ntasks, const std::vector<int> &leve
             meta.push_back(m);
         }
     }
-    std::vector<int> col((size_t)slot_rows * 64, n), rmap((size_t)n), lev((size_t)n), gf((size_t)n, n), gb((size_t)n, n);
+    std::vector<int> col((size_t)slot_rows * 64, ncols), rmap((size_t)n), lev((size_t)n), gf((size_t)n, ncols), gb((size_t)n, ncols);
     std::vector<double> val((size_t)slot_rows * 64, 0.0), dgs((size_t)n);
     for (int l = 0; l < nl; ++l)
         for (int k = level_ptr[(size_t)l]; k < level_ptr[(size_t)l + 1]; ++k) lev[(size_t)k] = l;
@@ -803,6 +811,12 @@ int build_flow_form(FlowForm &F, int n, int ntasks, const std::vector<int> &leve
                 if (cj == i) continue;
                 const int g = j / m.nslots, u = j % m.nslots;                   // lane g of the row's group, its slot u
                 const size_t at = ((size_t)m.off + (size_t)u) * 64 + (size_t)t * lpr + (size_t)g;
+                if (cj >= n) {                                                  // halo column: a frozen operand at its own position
+                    col[at] = cj;
+                    val[at] = gx[(size_t)q];
+                    ++j;
+                    continue;
+                }
                 const int pc = pos_of[(size_t)cj], lc = lev[(size_t)pc];
                 col[at] = pc;
                 val[at] = gx[(size_t)q];
@@ -811,8 +825,8 @@ int build_flow_form(FlowForm &F, int n, int ntasks, const std::vector<int> &leve
                 ++j;
             }
         }
-    F.n = n; F.nchunks = (int)meta.size(); F.nlevels = nl; F.slot_rows = slot_rows;
-    F.xstride = ((long)n + 1 + 15) / 16 * 16;
+    F.n = n; F.ncols = ncols; F.nchunks = (int)meta.size(); F.nlevels = nl; F.slot_rows = slot_rows;
+    F.xstride = ((long)ncols + 1 + 15) / 16 * 16;
     long acct = 0;
     FCHK(falloc(&F.rowmap, n, &acct));
     FCHK(falloc(&F.meta, (long)meta.size(), &acct));
@@ -845,15 +859,15 @@ int gs_flow_sweep(const FlowForm &F, bool bsr1, double *x, const double *b, cons
     FCHK(flow_status_word(&status));
     for (int s0 = 0; s0 < nseq; s0 += FLOW_MAXSEQ) {
         const int ns = std::min(FLOW_MAXSEQ, nseq - s0);
-        hipLaunchKernelGGL(flow_gather_kernel, dim3((unsigned)((F.n + 1 + 255) / 256)), dim3(256), 0, st, F.rowmap, x, b,
-                           (unsigned long long *)F.X, F.bp, F.xstride, F.n, ns);
+        hipLaunchKernelGGL(flow_gather_kernel, dim3((unsigned)((F.ncols + 1 + 255) / 256)), dim3(256), 0, st, F.rowmap, x, b,
+                           (unsigned long long *)F.X, F.bp, F.xstride, F.n, F.ncols, ns);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return hip_fail(e, "dataflow gather launch", __FILE__, __LINE__);
         FlowArgs a;
         std::memset(&a, 0, sizeof(a));
         a.X = (unsigned long long *)F.X; a.x_out = x; a.status = status;
         a.xstride = F.xstride; a.budget = 100000000LL * 4;                   // 4 s of the 100 MHz wall clock
-        a.nchunks = F.nchunks; a.nseq = ns; a.n = F.n;
+        a.nchunks = F.nchunks; a.nseq = ns; a.n = F.ncols;          // position of the permanent 0.0
         a.dirmask = 0;
         for (int k = 0; k < ns; ++k) a.dirmask |= (seq[s0 + k] != 0 ? 1u : 0u) << k;
         switch (F.lpr) {

@@ -471,7 +471,7 @@ int build_levels(int n, const int *Ap, const int *Aj, const int *tasks, int ntas
 }
 
 int build_csr_schedule(const int *Ap, const int *Aj, const double *Ax, int n, const int *tasks,
-                       int ntasks, Schedule &S, hipStream_t st, bool allow_flow)
+                       int ntasks, Schedule &S, hipStream_t st, bool allow_flow, int ncols)
 {
     (void)st;
     std::vector<int> order;
@@ -759,7 +759,7 @@ int build_csr_schedule(const int *Ap, const int *Aj, const double *Ax, int n, co
         // per level then runs at streaming speed and the second copy of the operator would only cost memory
         const bool wanted = (S.chain_long || chained * 10 < nl * 9) && (long)ntasks < (long)nl * 200000L;
         if (wanted || gs_flow_mode() == 2) {
-            CHK(build_flow_form(S.flow, n, ntasks, S.level_ptr, rowmap, gp, gj, gx));
+            CHK(build_flow_form(S.flow, n, ntasks, S.level_ptr, rowmap, gp, gj, gx, ncols));
             S.flow_auto = wanted && S.flow.ready;
             // the default serves this schedule from the dataflow form alone: the level-ordered copies of the other
             // paths (12-28 B per entry) are not kept beside it
@@ -1003,6 +1003,19 @@ static int bsr_stream_all(const DevBsr &Ab, BlockMode mode, const double *Dinv, 
 
 using namespace amg;
 
+// Dataflow Gauss-Seidel sweeps are persistent launches whose waves wait for each other: fine for one process per device.
+// A partitioned hierarchy uses them when every rank has a device of its own (world <= devices of the node; halo columns
+// are frozen operands of the form), not when ranks share one.  AMG_DIST_FLOW=0 | 1 overrides.
+static bool flow_allowed(const amg_hier *h)
+{
+    if (!h->comm) return true;
+    const char *e = std::getenv("AMG_DIST_FLOW");
+    if (e) return std::atoi(e) != 0;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess) return false;
+    return h->comm->world <= ndev;
+}
+
 // ------------------------------------------------------------------ row-partitioned levels
 // refresh the halo part of v (a level-lvl vector of n_own + n_halo entries) from its owners
 static int exchange(amg_hier *h, Level &L, double *v)
@@ -1087,9 +1100,9 @@ static int relax(amg_hier *h, Level &L, Smoother &s, double *&x, double *&xalt, 
             CHK(exchange(h, L, x));
             if (point_block)
                 return gs_sweep_block(*s.sched, L.Ab, BM_BSR_GS, nullptr, x, b, reverse, st);
-            // (several ranks may share one device: persistent dataflow launches of different processes could keep each
-            //  other's waves from becoming resident, so a partitioned hierarchy stays with the level-scheduled sweeps)
-            return gs_sweep_csr(*s.sched, bsr && s.kind != AMG_SM_GAUSS_SEIDEL_INDEXED, x, b, reverse, st, !h->comm);
+            // (ranks that SHARE a device -- tests, rehearsals -- keep the level-scheduled sweeps: persistent dataflow
+            //  launches of different processes could keep each other's waves from becoming resident; flow_allowed())
+            return gs_sweep_csr(*s.sched, bsr && s.kind != AMG_SM_GAUSS_SEIDEL_INDEXED, x, b, reverse, st, flow_allowed(h));
         };
         auto gs = [&](int iterations, int sweep) -> int {
             if (!point_block && !h->comm) {
@@ -1246,7 +1259,7 @@ static int relax(amg_hier *h, Level &L, Smoother &s, double *&x, double *&xalt, 
             if (s.sweep == AMG_SWEEP_FORWARD || s.sweep == AMG_SWEEP_SYMMETRIC) seq.push_back(0);
             if (s.sweep == AMG_SWEEP_BACKWARD || s.sweep == AMG_SWEEP_SYMMETRIC) seq.push_back(1);
         }
-        return block_gs_sweeps(*s.sched, s.Dinv, x, b, seq.data(), (int)seq.size(), st, !h->comm);
+        return block_gs_sweeps(*s.sched, s.Dinv, x, b, seq.data(), (int)seq.size(), st, flow_allowed(h));
     }
     }
     set_error("unknown smoother kind");
@@ -1825,7 +1838,7 @@ static int need_schedule(amg_hier *h, Level &L, Smoother &s)
                     AMG_HIP(hipMemcpy(ax.data(), L.A.Ax, sizeof(double) * ax.size(), hipMemcpyDeviceToHost));
                 }
                 L.sched_csr = std::make_shared<Schedule>();
-                CHK(build_csr_schedule(ap.data(), aj.data(), ax.data(), n, nullptr, n, *L.sched_csr, h->stream, !h->comm));
+                CHK(build_csr_schedule(ap.data(), aj.data(), ax.data(), n, nullptr, n, *L.sched_csr, h->stream, flow_allowed(h), L.A.ncols));
                 h->dev_bytes += L.sched_csr->level_copy_bytes + L.sched_csr->flow.bytes;
             }
             s.sched = L.sched_csr;
@@ -1864,7 +1877,7 @@ static int need_schedule(amg_hier *h, Level &L, Smoother &s)
             AMG_HIP(hipMemcpy(ax.data(), L.A.Ax, sizeof(double) * ax.size(), hipMemcpyDeviceToHost));
         }
         s.sched = std::make_shared<Schedule>();
-        CHK(build_csr_schedule(ap.data(), aj.data(), ax.data(), n, s.indices.data(), (int)s.indices.size(), *s.sched, h->stream, !h->comm));
+        CHK(build_csr_schedule(ap.data(), aj.data(), ax.data(), n, s.indices.data(), (int)s.indices.size(), *s.sched, h->stream, flow_allowed(h), L.A.ncols));
         h->dev_bytes += s.sched->level_copy_bytes + s.sched->flow.bytes;
     } else if (s.kind == AMG_SM_BLOCK_GAUSS_SEIDEL || s.kind == AMG_SM_BLOCK_JACOBI) {
         const DevBsr *Ab = s.Ablk_owned ? &s.Ablk : &L.Ab;
@@ -1884,7 +1897,7 @@ static int need_schedule(amg_hier *h, Level &L, Smoother &s)
             }
             s.sched = std::make_shared<Schedule>();
             CHK(build_block_schedule(bp.data(), bj.data(), Ab->nbrows, nullptr, Ab->nbrows, *s.sched, h->stream,
-                                     bx.data(), Ab->bs, false, !h->comm));
+                                     bx.data(), Ab->bs, false, flow_allowed(h)));
             h->dev_bytes += s.sched->level_copy_bytes + s.sched->bflow.bytes;
             if (!s.Ablk_owned) L.sched_bgs = s.sched;
         }

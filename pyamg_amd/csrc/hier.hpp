@@ -62,8 +62,9 @@ int build_levels(int n, const int *Ap, const int *Aj, const int *tasks, int ntas
                  std::vector<int> &level_ptr, std::vector<int> &order);
 // allow_flow: the dataflow form may be built (and, where the default picks it, replaces the level-ordered copies);
 // false for row-partitioned hierarchies (several ranks may share a device)
+// ncols > n: columns n .. ncols-1 exist but no listed row writes them (a partitioned level's halo): frozen operands
 int build_csr_schedule(const int *Ap, const int *Aj, const double *Ax, int n, const int *tasks,
-                       int ntasks, Schedule &S, hipStream_t st, bool allow_flow = true);
+                       int ntasks, Schedule &S, hipStream_t st, bool allow_flow = true, int ncols = 0);
 // block_flow: the schedule is for BLOCK Gauss-Seidel (relaxation.h:756-810) and may be served by the dataflow form alone
 int build_block_schedule(const int *Ap, const int *Aj, int nb, const int *tasks, int ntasks,
                          Schedule &S, hipStream_t st, const double *Ax = nullptr, int bs = 0, bool independent = false,

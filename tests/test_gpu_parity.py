@@ -1498,6 +1498,53 @@ def test_released_csr_sources_same_bits(monkeypatch):
     ml._invalidate_device()
 
 
+def test_dataflow_gauss_seidel_with_frozen_halo_columns(monkeypatch):
+    """the local operator of a rank of a partitioned solve: n rows, columns [owned | halo]; halo columns are operands no
+    local row writes (hybrid Gauss-Seidel: frozen during the sweep).  The dataflow form carries them behind the owned
+    unknowns in every iterate buffer: same bits as the level-scheduled sweep, forward, backward and fused, natural order
+    and an index list."""
+    import ctypes as C
+    import torch
+    from pyamg_amd import _lib
+    from pyamg_amd.aggregation import poisson as native
+    L = _lib.lib()
+    monkeypatch.setenv("AMG_DIST_FLOW", "1")
+    rng = np.random.RandomState(21)
+    Afull = sps.csr_matrix(native((30, 28, 26)))
+    n = 15000                                           # the first n rows: their columns reach up to one plane further
+    Aloc = Afull[:n].tocsr()
+    cols = np.unique(Aloc.indices)
+    halo = cols[cols >= n]
+    remap = np.full(Afull.shape[0], -1, dtype=np.int64)
+    remap[:n] = np.arange(n)
+    remap[halo] = n + np.arange(len(halo))
+    Aj = remap[Aloc.indices].astype(np.intc)
+    Ap, Ax = Aloc.indptr.astype(np.intc), np.ascontiguousarray(Aloc.data)
+    ncols = n + len(halo)
+    b = rng.rand(n)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    order = rng.permutation(n).astype(np.intc)
+    try:
+        for ordr in (None, order):
+            for seq in ([0], [1], [0, 1, 1, 0]):
+                sq = np.array(seq, dtype=np.uint8)
+                outs = []
+                for flow in (0, 2):
+                    L.amg_set_gs_flow(flow)
+                    mat = L.amg_mat_create(0, n, ncols, _lib.ip(Ap), _lib.ip(Aj), _lib.dp(Ax))
+                    _lib.check(L.amg_mat_build_gs(mat, None if ordr is None else _lib.ip(ordr), 0 if ordr is None else n))
+                    xd = torch.from_numpy(np.sin(np.arange(ncols, dtype=float))).cuda(); bd = torch.from_numpy(b).cuda()
+                    _lib.check(L.amg_mat_gs_sweeps(mat, C.c_void_p(xd.data_ptr()), C.c_void_p(bd.data_ptr()), sq.ctypes.data_as(C.c_void_p), len(seq), 0, st))
+                    torch.cuda.synchronize()
+                    outs.append(xd.cpu().numpy())
+                    L.amg_mat_destroy(mat)
+                assert np.array_equal(outs[0], outs[1]), (ordr is None, seq)
+                assert np.array_equal(outs[1][n:], np.sin(np.arange(n, ncols, dtype=float)))       # the halo is untouched
+        assert L.amg_gs_flow_status() == 0
+    finally:
+        L.amg_set_gs_flow(1)
+
+
 # ---------------------------------------------------------------------------
 # device-resident Krylov methods (pyamg_amd/krylov.py): acceleration, smoothers, coarse solvers
 # ---------------------------------------------------------------------------
