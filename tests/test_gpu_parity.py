@@ -1545,6 +1545,25 @@ def test_dataflow_gauss_seidel_with_frozen_halo_columns(monkeypatch):
         L.amg_set_gs_flow(1)
 
 
+def test_sor_and_multiple_iterations_through_the_dataflow_sweep():
+    """relaxation.sor (relaxation.py:108-169: a Gauss-Seidel sweep, then x = omega x + (1 - omega) x_old per iteration) and
+    gauss_seidel with iterations = 3 (six directional sweeps: two dataflow launches) as level smoothers of a 3-D hierarchy,
+    where the default picks the dataflow sweep: iterates bit-identical to the oracle"""
+    from pyamg_amd import _lib
+    from pyamg_amd.aggregation import poisson as native, smoothed_aggregation_solver
+    for pre, post in ((("sor", {"omega": 1.3, "sweep": "symmetric", "iterations": 2}), ("sor", {"omega": 0.8, "sweep": "backward"})),
+                      (("gauss_seidel", {"sweep": "symmetric", "iterations": 3}), ("gauss_seidel", {"sweep": "forward", "iterations": 5}))):
+        np.random.seed(1)
+        ml = smoothed_aggregation_solver(native((30, 28, 26)), presmoother=pre, postsmoother=post, max_coarse=30)
+        b = np.random.rand(ml.levels[0].A.shape[0])
+        res = []
+        x = ml.solve(b, tol=0.0, maxiter=3, residuals=res)
+        levels, M = _oracle_levels(ml)
+        xo, reso = oracle_lib.Hierarchy(levels, M).solve(b, tol=0.0, maxiter=3)
+        assert np.array_equal(x, xo), (pre[0], np.abs(x - xo).max())
+    assert _lib.lib().amg_gs_flow_status() == 0
+
+
 # ---------------------------------------------------------------------------
 # device-resident Krylov methods (pyamg_amd/krylov.py): acceleration, smoothers, coarse solvers
 # ---------------------------------------------------------------------------
