@@ -431,7 +431,13 @@ class multilevel_solver:
 
     def solve(self, b, x0=None, tol=1e-5, maxiter=100, cycle="V", accel=None, callback=None,
               residuals=None, return_residuals=False):
-        """Main solution call to execute multigrid cycling (multilevel.py:316-471)."""
+        """Main solution call to execute multigrid cycling (multilevel.py:316-471).
+
+        Extension: b (and x0) may be torch CUDA tensors (float64, contiguous, on the hierarchy's device): the solve then
+        never touches the host -- no PCIe copy of b / x0 in or x out (3 GB at 500^3) -- and returns a tensor.  Plain
+        cycling and accel='cg' (the device PCG); same iterates and history as with host vectors."""
+        if _is_device_tensor(b):
+            return self._solve_device_tensors(b, x0, tol, maxiter, cycle, accel, callback, residuals)
         b = np.asarray(b)
         if x0 is None:
             x = np.zeros_like(b)
@@ -488,6 +494,41 @@ class multilevel_solver:
         if return_residuals:
             return xout, residuals
         return xout
+
+    def _solve_device_tensors(self, b, x0, tol, maxiter, cycle, accel, callback, residuals):
+        import torch
+        cycle = str(cycle).upper()
+        if cycle not in _CYCLE:
+            raise TypeError("Unrecognized cycle type (%s)" % cycle)
+        if callback is not None or accel not in (None, "cg"):
+            raise NotImplementedError("device tensors: plain cycling and accel='cg' (no callback); pass host arrays otherwise")
+        if accel == "cg" and cycle == "AMLI":
+            raise ValueError("AMLI cycles require acceleration (accel) to be fgmres, or no acceleration")
+        n = self.levels[0].A.shape[0]
+        dev = self.device_hierarchy()
+        for t in (b,) if x0 is None else (b, x0):
+            if not _is_device_tensor(t) or t.dtype != torch.float64 or t.numel() != n or not t.is_contiguous() or t.device.index != self.device:
+                raise ValueError("device tensors must be contiguous float64 CUDA tensors of %d entries on device %d" % (n, self.device))
+        x = torch.zeros_like(b) if x0 is None else x0.clone()
+        x0_zero = x0 is None
+        torch.cuda.current_stream(b.device).synchronize()          # the library works on its own stream
+        if maxiter is None:
+            maxiter = int(1.3 * n) + 2 if accel == "cg" else 100
+        res = np.zeros(maxiter + 2, dtype=np.float64)
+        nres = _lib.C.c_int(0)
+        flags = _DEVICE_VECTORS | (_X0_ZERO if x0_zero else 0)
+        if accel == "cg":
+            info = _lib.C.c_int(0)
+            _lib.check(dev.L.amg_hier_pcg(dev.h, b.data_ptr(), x.data_ptr(), float(tol), int(maxiter), _CYCLE[cycle], _lib.dp(res),
+                                          _lib.C.byref(nres), _lib.C.byref(info), flags))
+            if info.value < 0:
+                warn("Indefinite matrix or preconditioner detected in CG, aborting")
+        else:
+            dev._check(dev.L.amg_hier_solve(dev.h, b.data_ptr(), x.data_ptr(), float(tol), int(maxiter), _CYCLE[cycle], _lib.dp(res),
+                                            _lib.C.byref(nres), flags))
+        if residuals is not None:
+            residuals[:] = [float(r) for r in res[:nres.value]]
+        return x
 
     def _solve_accel(self, b, x0, tol, maxiter, cycle, accel, callback, residuals):
         """Krylov acceleration (multilevel.py:381-422): the cycle is the preconditioner M;
@@ -550,6 +591,10 @@ class multilevel_solver:
             return accel(A, b, x0=x0, rtol=tol, maxiter=maxiter, M=M, callback=callback)[0]
         except TypeError:
             return accel(A, b, x0=x0, tol=tol, maxiter=maxiter, M=M, callback=callback)[0]
+
+
+def _is_device_tensor(v):
+    return hasattr(v, "data_ptr") and hasattr(v, "is_cuda") and bool(v.is_cuda)
 
 
 def coarse_grid_solver(solver):

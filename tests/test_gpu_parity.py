@@ -1564,6 +1564,31 @@ def test_sor_and_multiple_iterations_through_the_dataflow_sweep():
     assert _lib.lib().amg_gs_flow_status() == 0
 
 
+def test_solve_on_device_tensors_same_iterates_no_host_copies():
+    """multilevel_solver.solve with torch CUDA tensors for b / x0 (extension): nothing crosses PCIe, a tensor comes back;
+    iterates and history identical to the host-vector call -- plain V and W cycles, an initial guess, and accel='cg'"""
+    import torch
+    g = golden_io.load_hier("sa_cheb2_3d")
+    ml = golden_io.build_ml(g)
+    b = np.asarray(g["b"])
+    rng = np.random.RandomState(2)
+    x0 = rng.rand(len(b))
+    for kw in (dict(tol=1e-10, maxiter=12), dict(tol=0.0, maxiter=3, cycle="W"), dict(tol=1e-9, maxiter=20, accel="cg")):
+        for guess in (None, x0):
+            rh, rd = [], []
+            xh = ml.solve(b, x0=guess, residuals=rh, **kw)
+            bd = torch.from_numpy(b).cuda()
+            xd = ml.solve(bd, x0=None if guess is None else torch.from_numpy(guess).cuda(), residuals=rd, **kw)
+            assert isinstance(xd, torch.Tensor) and xd.is_cuda
+            assert np.array_equal(xd.cpu().numpy(), xh), (kw, guess is None)
+            assert rd == rh, (kw, guess is None)
+            assert np.array_equal(bd.cpu().numpy(), b)
+    with pytest.raises(ValueError):
+        ml.solve(torch.zeros(5, dtype=torch.float64, device="cuda"))
+    with pytest.raises(NotImplementedError):
+        ml.solve(torch.from_numpy(b).cuda(), accel="gmres")
+
+
 # ---------------------------------------------------------------------------
 # device-resident Krylov methods (pyamg_amd/krylov.py): acceleration, smoothers, coarse solvers
 # ---------------------------------------------------------------------------
