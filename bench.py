@@ -238,7 +238,9 @@ def partitioned_main(args, rank, local_rank, world, torch, dist):
         np.save(os.path.join(shared, "b.npy"), bfull)
         log("[bench] hierarchy shipped to %s in %.1fs" % (shared, time.time() - t0))
         shape_info = [[int(L["A"].shape[0]), int(L["A"].nnz)] for L in levels]
-        if not args.no_cpu_baseline:
+        # (the CPU baseline is timed at N = 1 only: with N > 1 the other ranks would sit idle through 10+ s of oracle;
+        #  --cpu-baseline-anyway asks for it)
+        if args.cpu_baseline_anyway and not args.no_cpu_baseline:
             cpu = cpu_baseline_of(ml, bfull, None)
         del ml, levels, bfull
     dist.barrier(group=host_group)
@@ -532,6 +534,7 @@ def main():
     ap.add_argument("--grid", type=int, default=None, help="grid points per axis (defaults: C1 500, C2 2000, C3 / C4 500, C5 360)")
     ap.add_argument("--smoother", default=None, help="C3: chebyshev (default) | jacobi | gauss_seidel; C4: hybrid_gs (default) | hybrid_gs_lex")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-anyway", action="store_true", help="N > 1: time the CPU oracle on rank 0 too (default: N = 1 only)")
     ap.add_argument("--no-value-index", action="store_true", help="skip the opt-in value-index extra measurement")
     ap.add_argument("--variant", type=int, default=None, help="CSR stream kernel load variant (0/1)")
     ap.add_argument("--xcd-chunk", type=int, default=None)

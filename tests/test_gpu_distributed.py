@@ -372,10 +372,11 @@ def test_bench_config_c4_runs_partitioned_hybrid_gauss_seidel(tmp_path):
                             "--warmup", "2"] + extra, env=env, capture_output=True, text=True, timeout=900)
         assert p.returncode == 0, p.stderr[-3000:]
         line = json.loads(p.stdout.strip().splitlines()[-1])
-        assert line["steps"] == 3 and line["roofline"]["frac"] > 0 and line["cpu_baseline"]["value"] > 0
+        assert line["steps"] == 3 and line["roofline"]["frac"] > 0
         if extra[0] == "--gpus":
             assert line["n_gpus"] == 2 and line["scaling"] == "strong" and "hybrid_gs" in line["config"]["workload"]
         else:
+            assert line["cpu_baseline"]["value"] > 0
             assert line["cpu_baseline"]["first_step_iterate_bit_identical_to_gpu"] is True
             assert "cpu_model" in line["cpu_baseline"]
 
@@ -395,6 +396,6 @@ def test_bench_gpus_2_runs_two_ranks(tmp_path):
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["steps"] == 3
     assert line["config"]["transport"] == "peer", line["config"]["parallelism"]
     assert line["roofline"]["frac"] > 0 and "traffic" in line["roofline"]
-    assert line["cpu_baseline"] is not None and line["cpu_baseline"]["value"] > 0
+    assert line["cpu_baseline"] is None            # the CPU oracle is timed at N = 1 only
     r = line["config"]["residuals"]            # (Chebyshev(2) cycles raise the residual before it decays, as the reference's do)
     assert all(np.isfinite(v) and v > 0 for v in r)
