@@ -638,7 +638,9 @@ int build_block_flow_form(BlockFlowForm &F, int nb, int bs, int ntasks, const st
     for (int l = 0; l < nl; ++l) {
         const int lo = level_ptr[(size_t)l], hi = level_ptr[(size_t)l + 1];
         for (int k = lo; k < hi; ++k) ord[(size_t)k] = k;
-        std::stable_sort(ord.begin() + lo, ord.begin() + hi, [&](int p, int q) { return cnt[(size_t)p] > cnt[(size_t)q]; });
+        // (by SLOTS PER LANE, not by length: rows of one class keep the schedule's order -- neighbours in the operator's numbering stay
+        //  neighbours in a chunk and their gathers share cache lines)
+        std::stable_sort(ord.begin() + lo, ord.begin() + hi, [&](int p, int q) { return (cnt[(size_t)p] + lpr - 1) / lpr > (cnt[(size_t)q] + lpr - 1) / lpr; });
     }
     for (int k = 0; k < nb; ++k) pos_of[(size_t)rows[(size_t)ord[(size_t)k]]] = k;
     std::vector<FlowChunk> meta;
@@ -798,7 +800,9 @@ int build_flow_form(FlowForm &F, int n, int ntasks, const std::vector<int> &leve
     for (int l = 0; l < nl; ++l) {
         const int lo = level_ptr[(size_t)l], hi = level_ptr[(size_t)l + 1];
         for (int k = lo; k < hi; ++k) ord[(size_t)k] = k;
-        std::stable_sort(ord.begin() + lo, ord.begin() + hi, [&](int p, int q) { return cnt[(size_t)p] > cnt[(size_t)q]; });
+        // (by SLOTS PER LANE, not by length: rows of one class keep the schedule's order -- neighbours in the operator's numbering stay
+        //  neighbours in a chunk and their gathers share cache lines)
+        std::stable_sort(ord.begin() + lo, ord.begin() + hi, [&](int p, int q) { return (cnt[(size_t)p] + lpr - 1) / lpr > (cnt[(size_t)q] + lpr - 1) / lpr; });
     }
     for (int k = 0; k < n; ++k) pos_of[(size_t)rowmap[(size_t)ord[(size_t)k]]] = k;
     std::vector<FlowChunk> meta;
