@@ -32,13 +32,33 @@
 #include "hier.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <thread>
 #include <vector>
 
 namespace amg {
 
 namespace {
+
+// host-side loops of the form builders over up to 16 threads: fn(first, last) on contiguous ranges of [0, n)
+template <class F> void flow_parallel(long n, long grain, F fn)
+{
+    unsigned hw = std::thread::hardware_concurrency();
+    static const int cap = std::getenv("AMG_SETUP_THREADS") ? std::atoi(std::getenv("AMG_SETUP_THREADS")) : 16;
+    long nt = std::min<long>(std::min<long>(hw ? hw : 1, std::max(1, cap)), (n + grain - 1) / std::max<long>(grain, 1));
+    if (nt <= 1) { fn(0L, n); return; }
+    std::vector<std::thread> th;
+    const long step = (n + nt - 1) / nt;
+    for (long t = 0; t < nt; ++t) {
+        const long lo = t * step, hi = std::min(n, lo + step);
+        if (lo >= hi) break;
+        th.emplace_back([=]() { fn(lo, hi); });
+    }
+    for (auto &t : th) t.join();
+}
 
 constexpr unsigned long long FLOW_SENT = 0x7FF4A5A55A5A0001ULL;    // a signalling NaN no arithmetic result can equal
 constexpr unsigned long long FLOW_QUIET = 0x0008000000000000ULL;
@@ -635,14 +655,16 @@ int build_block_flow_form(BlockFlowForm &F, int nb, int bs, int ntasks, const st
     const int NG = 64 / bs, R = 64 / (bs * lpr);                                // groups per wave, block rows per chunk
     if (R < 1) return 0;
     std::vector<int> ord((size_t)nb), pos_of((size_t)nb);
-    for (int l = 0; l < nl; ++l) {
-        const int lo = level_ptr[(size_t)l], hi = level_ptr[(size_t)l + 1];
-        for (int k = lo; k < hi; ++k) ord[(size_t)k] = k;
-        // (by SLOTS PER LANE, not by length: rows of one class keep the schedule's order -- neighbours in the operator's numbering stay
-        //  neighbours in a chunk and their gathers share cache lines)
-        std::stable_sort(ord.begin() + lo, ord.begin() + hi, [&](int p, int q) { return (cnt[(size_t)p] + lpr - 1) / lpr > (cnt[(size_t)q] + lpr - 1) / lpr; });
-    }
-    for (int k = 0; k < nb; ++k) pos_of[(size_t)rows[(size_t)ord[(size_t)k]]] = k;
+    flow_parallel(nl, 64, [&](long llo, long lhi) {
+        for (long l = llo; l < lhi; ++l) {
+            const int lo = level_ptr[(size_t)l], hi = level_ptr[(size_t)l + 1];
+            for (int k = lo; k < hi; ++k) ord[(size_t)k] = k;
+            // (by SLOTS PER LANE, not by length: rows of one class keep the schedule's order -- neighbours in the operator's
+            //  numbering stay neighbours in a chunk and their gathers share cache lines)
+            std::stable_sort(ord.begin() + lo, ord.begin() + hi, [&](int p, int q) { return (cnt[(size_t)p] + lpr - 1) / lpr > (cnt[(size_t)q] + lpr - 1) / lpr; });
+        }
+    });
+    flow_parallel(nb, 1 << 18, [&](long klo, long khi) { for (long k = klo; k < khi; ++k) pos_of[(size_t)rows[(size_t)ord[(size_t)k]]] = (int)k; });
     std::vector<FlowChunk> meta;
     long slot_rows = 0;
     for (int l = 0; l < nl; ++l) {
@@ -659,47 +681,58 @@ int build_block_flow_form(BlockFlowForm &F, int nb, int bs, int ntasks, const st
             meta.push_back(m);
         }
     }
-    std::vector<int> col((size_t)std::max(slot_rows, 1L) * NG, nb), rmap((size_t)nb), lev((size_t)nb), gf((size_t)nb, nb), gb((size_t)nb, nb);
-    std::vector<double> val((size_t)std::max(slot_rows, 1L) * bs * 64, 0.0);
-    for (int l = 0; l < nl; ++l)
-        for (int k = level_ptr[(size_t)l]; k < level_ptr[(size_t)l + 1]; ++k) lev[(size_t)k] = l;
-    for (const FlowChunk &m : meta)
-        for (int t = 0; t < m.nrows; ++t) {
-            const int kk = m.row0 + t;
-            const int k = ord[(size_t)kk], i = rows[(size_t)k];
-            rmap[(size_t)kk] = i;
-            const int lk = lev[(size_t)kk];
-            int j = 0, gfl = -1, gbl = nl;
-            for (int q = gp[(size_t)k]; q < gp[(size_t)k + 1]; ++q) {
-                const int cj = gj[(size_t)q];
-                if (cj == i) continue;
-                const int g = j / m.nslots, u = j % m.nslots;
-                const int pc = pos_of[(size_t)cj], lc = lev[(size_t)pc];
-                const int grp = t * lpr + g;                                    // lanes grp * bs .. grp * bs + bs - 1
-                col[((size_t)m.off + (size_t)u) * NG + (size_t)grp] = pc;
-                for (int r = 0; r < bs; ++r)
-                    for (int c = 0; c < bs; ++c)
-                        val[(((size_t)m.off + (size_t)u) * bs + (size_t)c) * 64 + (size_t)grp * bs + (size_t)r] = gx[(size_t)q * B2 + (size_t)r * bs + (size_t)c];
-                if (lc <= lk - 2 && lc > gfl) { gfl = lc; gf[(size_t)kk] = pc; }
-                if (lc >= lk + 2 && lc < gbl) { gbl = lc; gb[(size_t)kk] = pc; }
-                ++j;
+    // (every slot is written exactly once, padding included, by the thread that owns the chunk: no zero-fill pass)
+    const size_t ncol = (size_t)std::max(slot_rows, 1L) * NG, nval = (size_t)std::max(slot_rows, 1L) * bs * 64;
+    std::unique_ptr<int[]> col(new int[ncol]);
+    std::unique_ptr<double[]> val(new double[nval]);
+    std::vector<int> rmap((size_t)nb), lev((size_t)nb), gf((size_t)nb, nb), gb((size_t)nb, nb);
+    flow_parallel(nl, 64, [&](long llo, long lhi) {
+        for (long l = llo; l < lhi; ++l)
+            for (int k = level_ptr[(size_t)l]; k < level_ptr[(size_t)l + 1]; ++k) lev[(size_t)k] = (int)l;
+    });
+    flow_parallel((long)meta.size(), 256, [&](long clo, long chi) {
+        for (long cc = clo; cc < chi; ++cc) {
+            const FlowChunk &m = meta[(size_t)cc];
+            for (size_t w = (size_t)m.off * NG; w < ((size_t)m.off + (size_t)m.nslots) * NG; ++w) col[w] = nb;
+            for (size_t w = (size_t)m.off * bs * 64; w < ((size_t)m.off + (size_t)m.nslots) * bs * 64; ++w) val[w] = 0.0;
+            for (int t = 0; t < m.nrows; ++t) {
+                const int kk = m.row0 + t;
+                const int k = ord[(size_t)kk], i = rows[(size_t)k];
+                rmap[(size_t)kk] = i;
+                const int lk = lev[(size_t)kk];
+                int j = 0, gfl = -1, gbl = nl;
+                for (int q = gp[(size_t)k]; q < gp[(size_t)k + 1]; ++q) {
+                    const int cj = gj[(size_t)q];
+                    if (cj == i) continue;
+                    const int g = j / m.nslots, u = j % m.nslots;
+                    const int pc = pos_of[(size_t)cj], lc = lev[(size_t)pc];
+                    const int grp = t * lpr + g;                                // lanes grp * bs .. grp * bs + bs - 1
+                    col[((size_t)m.off + (size_t)u) * NG + (size_t)grp] = pc;
+                    for (int r = 0; r < bs; ++r)
+                        for (int c = 0; c < bs; ++c)
+                            val[(((size_t)m.off + (size_t)u) * bs + (size_t)c) * 64 + (size_t)grp * bs + (size_t)r] = gx[(size_t)q * B2 + (size_t)r * bs + (size_t)c];
+                    if (lc <= lk - 2 && lc > gfl) { gfl = lc; gf[(size_t)kk] = pc; }
+                    if (lc >= lk + 2 && lc < gbl) { gbl = lc; gb[(size_t)kk] = pc; }
+                    ++j;
+                }
             }
         }
+    });
     F.nb = nb; F.nchunks = (int)meta.size(); F.nlevels = nl; F.slot_rows = slot_rows;
     F.xstride = ((long)(nb + 1) * bs + 15) / 16 * 16;
     long acct = 0;
     FCHK(falloc(&F.rows, nb, &acct));
     FCHK(falloc(&F.meta, (long)meta.size(), &acct));
-    FCHK(falloc(&F.col, (long)col.size(), &acct));
-    FCHK(falloc(&F.val, (long)val.size(), &acct));
+    FCHK(falloc(&F.col, (long)ncol, &acct));
+    FCHK(falloc(&F.val, (long)nval, &acct));
     FCHK(falloc(&F.bp, (long)nb * bs, &acct));
     FCHK(falloc(&F.gate_f, nb, &acct));
     FCHK(falloc(&F.gate_b, nb, &acct));
     FCHK(falloc(&F.X, (FLOW_MAXSEQ + 1) * F.xstride, &acct));
     AMG_HIP(hipMemcpy(F.rows, rmap.data(), sizeof(int) * (size_t)nb, hipMemcpyHostToDevice));
     AMG_HIP(hipMemcpy(F.meta, meta.data(), sizeof(FlowChunk) * meta.size(), hipMemcpyHostToDevice));
-    AMG_HIP(hipMemcpy(F.col, col.data(), sizeof(int) * col.size(), hipMemcpyHostToDevice));
-    AMG_HIP(hipMemcpy(F.val, val.data(), sizeof(double) * val.size(), hipMemcpyHostToDevice));
+    AMG_HIP(hipMemcpy(F.col, col.get(), sizeof(int) * ncol, hipMemcpyHostToDevice));
+    AMG_HIP(hipMemcpy(F.val, val.get(), sizeof(double) * nval, hipMemcpyHostToDevice));
     AMG_HIP(hipMemcpy(F.gate_f, gf.data(), sizeof(int) * (size_t)nb, hipMemcpyHostToDevice));
     AMG_HIP(hipMemcpy(F.gate_b, gb.data(), sizeof(int) * (size_t)nb, hipMemcpyHostToDevice));
     F.bytes = acct;
@@ -771,40 +804,53 @@ int build_flow_form(FlowForm &F, int n, int ntasks, const std::vector<int> &leve
     // leaves a row with a zero diagonal untouched: such operators keep the level-scheduled kernels)
     std::vector<int> cnt((size_t)n), seen((size_t)n, 0);
     std::vector<double> dg((size_t)n, 0.0);
-    int longest = 0;
     for (int k = 0; k < n; ++k) {
         const int i = rowmap[(size_t)k];
         if (i < 0 || i >= n || seen[(size_t)i]) return 0;
         seen[(size_t)i] = 1;
-        int c = 0;
-        bool has_d = false;
-        double d = 0.0;
-        for (int q = gp[(size_t)k]; q < gp[(size_t)k + 1]; ++q) {
-            const int j = gj[(size_t)q];
-            if (j < 0 || j >= ncols) return 0;
-            if (j == i) { d = gx[(size_t)q]; has_d = true; }                   // the last diagonal entry wins (relaxation.h:51-52)
-            else ++c;
-        }
-        if (!has_d || d == 0.0) return 0;
-        cnt[(size_t)k] = c;
-        dg[(size_t)k] = d;
-        longest = std::max(longest, c);
     }
+    std::vector<int>().swap(seen);
+    std::atomic<int> longest_a(0), invalid(0);
+    flow_parallel(n, 1 << 16, [&](long klo, long khi) {
+        int lmax = 0;
+        for (long k = klo; k < khi; ++k) {
+            const int i = rowmap[(size_t)k];
+            int c = 0;
+            bool has_d = false;
+            double d = 0.0;
+            for (int q = gp[(size_t)k]; q < gp[(size_t)k + 1]; ++q) {
+                const int j = gj[(size_t)q];
+                if (j < 0 || j >= ncols) { invalid.store(1); return; }
+                if (j == i) { d = gx[(size_t)q]; has_d = true; }               // the last diagonal entry wins (relaxation.h:51-52)
+                else ++c;
+            }
+            if (!has_d || d == 0.0) { invalid.store(1); return; }
+            cnt[(size_t)k] = c;
+            dg[(size_t)k] = d;
+            lmax = std::max(lmax, c);
+        }
+        int cur = longest_a.load();
+        while (lmax > cur && !longest_a.compare_exchange_weak(cur, lmax)) {}
+    });
+    if (invalid.load()) return 0;
+    const int longest = longest_a.load();
     if (longest > FLOW_SEG * 64) return 0;
     int lpr = 1;
     while (lpr * FLOW_SEG < longest) lpr *= 2;
     F.lpr = lpr;
     const int R = 64 / lpr;                                                    // rows per chunk
-    // rows of a level sorted by length (longest first, ties in schedule order): chunks are nearly rectangular
+    // rows of a level sorted by length class (longest first, ties in schedule order): chunks are nearly rectangular
     std::vector<int> ord((size_t)n), pos_of((size_t)n);
-    for (int l = 0; l < nl; ++l) {
-        const int lo = level_ptr[(size_t)l], hi = level_ptr[(size_t)l + 1];
-        for (int k = lo; k < hi; ++k) ord[(size_t)k] = k;
-        // (by SLOTS PER LANE, not by length: rows of one class keep the schedule's order -- neighbours in the operator's numbering stay
-        //  neighbours in a chunk and their gathers share cache lines)
-        std::stable_sort(ord.begin() + lo, ord.begin() + hi, [&](int p, int q) { return (cnt[(size_t)p] + lpr - 1) / lpr > (cnt[(size_t)q] + lpr - 1) / lpr; });
-    }
-    for (int k = 0; k < n; ++k) pos_of[(size_t)rowmap[(size_t)ord[(size_t)k]]] = k;
+    flow_parallel(nl, 64, [&](long llo, long lhi) {
+        for (long l = llo; l < lhi; ++l) {
+            const int lo = level_ptr[(size_t)l], hi = level_ptr[(size_t)l + 1];
+            for (int k = lo; k < hi; ++k) ord[(size_t)k] = k;
+            // (by SLOTS PER LANE, not by length: rows of one class keep the schedule's order -- neighbours in the operator's
+            //  numbering stay neighbours in a chunk and their gathers share cache lines)
+            std::stable_sort(ord.begin() + lo, ord.begin() + hi, [&](int p, int q) { return (cnt[(size_t)p] + lpr - 1) / lpr > (cnt[(size_t)q] + lpr - 1) / lpr; });
+        }
+    });
+    flow_parallel(n, 1 << 18, [&](long klo, long khi) { for (long k = klo; k < khi; ++k) pos_of[(size_t)rowmap[(size_t)ord[(size_t)k]]] = (int)k; });
     std::vector<FlowChunk> meta;
     long slot_rows = 0;
     for (int l = 0; l < nl; ++l) {
@@ -821,37 +867,48 @@ int build_flow_form(FlowForm &F, int n, int ntasks, const std::vector<int> &leve
             meta.push_back(m);
         }
     }
-    std::vector<int> col((size_t)slot_rows * 64, ncols), rmap((size_t)n), lev((size_t)n), gf((size_t)n, ncols), gb((size_t)n, ncols);
-    std::vector<double> val((size_t)slot_rows * 64, 0.0), dgs((size_t)n);
-    for (int l = 0; l < nl; ++l)
-        for (int k = level_ptr[(size_t)l]; k < level_ptr[(size_t)l + 1]; ++k) lev[(size_t)k] = l;
-    for (const FlowChunk &m : meta)
-        for (int t = 0; t < m.nrows; ++t) {
-            const int kk = m.row0 + t;                                          // position in the form's numbering
-            const int k = ord[(size_t)kk], i = rowmap[(size_t)k];
-            rmap[(size_t)kk] = i;
-            dgs[(size_t)kk] = dg[(size_t)k];
-            const int lk = lev[(size_t)kk];
-            int j = 0, gfl = -1, gbl = nl;                                      // off-diagonal entries in stored order
-            for (int q = gp[(size_t)k]; q < gp[(size_t)k + 1]; ++q) {
-                const int cj = gj[(size_t)q];
-                if (cj == i) continue;
-                const int g = j / m.nslots, u = j % m.nslots;                   // lane g of the row's group, its slot u
-                const size_t at = ((size_t)m.off + (size_t)u) * 64 + (size_t)t * lpr + (size_t)g;
-                if (cj >= n) {                                                  // halo column: a frozen operand at its own position
-                    col[at] = cj;
+    // (the 12 B per slot are written exactly once, padding included, by the thread that owns the chunk: no zero-fill pass)
+    const size_t nslot = (size_t)std::max(slot_rows, 1L) * 64;
+    std::unique_ptr<int[]> col(new int[nslot]);
+    std::unique_ptr<double[]> val(new double[nslot]);
+    std::vector<int> rmap((size_t)n), lev((size_t)n), gf((size_t)n, ncols), gb((size_t)n, ncols);
+    std::vector<double> dgs((size_t)n);
+    flow_parallel(nl, 64, [&](long llo, long lhi) {
+        for (long l = llo; l < lhi; ++l)
+            for (int k = level_ptr[(size_t)l]; k < level_ptr[(size_t)l + 1]; ++k) lev[(size_t)k] = (int)l;
+    });
+    flow_parallel((long)meta.size(), 256, [&](long clo, long chi) {
+        for (long c = clo; c < chi; ++c) {
+            const FlowChunk &m = meta[(size_t)c];
+            for (size_t w = (size_t)m.off * 64; w < ((size_t)m.off + (size_t)m.nslots) * 64; ++w) { col[w] = ncols; val[w] = 0.0; }
+            for (int t = 0; t < m.nrows; ++t) {
+                const int kk = m.row0 + t;                                      // position in the form's numbering
+                const int k = ord[(size_t)kk], i = rowmap[(size_t)k];
+                rmap[(size_t)kk] = i;
+                dgs[(size_t)kk] = dg[(size_t)k];
+                const int lk = lev[(size_t)kk];
+                int j = 0, gfl = -1, gbl = nl;                                  // off-diagonal entries in stored order
+                for (int q = gp[(size_t)k]; q < gp[(size_t)k + 1]; ++q) {
+                    const int cj = gj[(size_t)q];
+                    if (cj == i) continue;
+                    const int g = j / m.nslots, u = j % m.nslots;               // lane g of the row's group, its slot u
+                    const size_t at = ((size_t)m.off + (size_t)u) * 64 + (size_t)t * lpr + (size_t)g;
+                    if (cj >= n) {                                              // halo column: a frozen operand at its own position
+                        col[at] = cj;
+                        val[at] = gx[(size_t)q];
+                        ++j;
+                        continue;
+                    }
+                    const int pc = pos_of[(size_t)cj], lc = lev[(size_t)pc];
+                    col[at] = pc;
                     val[at] = gx[(size_t)q];
+                    if (lc <= lk - 2 && lc > gfl) { gfl = lc; gf[(size_t)kk] = pc; }  // forward gate: the latest level at least two back
+                    if (lc >= lk + 2 && lc < gbl) { gbl = lc; gb[(size_t)kk] = pc; }  // backward gate
                     ++j;
-                    continue;
                 }
-                const int pc = pos_of[(size_t)cj], lc = lev[(size_t)pc];
-                col[at] = pc;
-                val[at] = gx[(size_t)q];
-                if (lc <= lk - 2 && lc > gfl) { gfl = lc; gf[(size_t)kk] = pc; }  // forward gate: the latest level at least two back
-                if (lc >= lk + 2 && lc < gbl) { gbl = lc; gb[(size_t)kk] = pc; }  // backward gate
-                ++j;
             }
         }
+    });
     F.n = n; F.ncols = ncols; F.nchunks = (int)meta.size(); F.nlevels = nl; F.slot_rows = slot_rows;
     F.xstride = ((long)ncols + 1 + 15) / 16 * 16;
     long acct = 0;
@@ -867,8 +924,8 @@ int build_flow_form(FlowForm &F, int n, int ntasks, const std::vector<int> &leve
     AMG_HIP(hipMemcpy(F.rowmap, rmap.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
     AMG_HIP(hipMemcpy(F.meta, meta.data(), sizeof(FlowChunk) * meta.size(), hipMemcpyHostToDevice));
     if (slot_rows > 0) {
-        AMG_HIP(hipMemcpy(F.col, col.data(), sizeof(int) * col.size(), hipMemcpyHostToDevice));
-        AMG_HIP(hipMemcpy(F.val, val.data(), sizeof(double) * val.size(), hipMemcpyHostToDevice));
+        AMG_HIP(hipMemcpy(F.col, col.get(), sizeof(int) * (size_t)slot_rows * 64, hipMemcpyHostToDevice));
+        AMG_HIP(hipMemcpy(F.val, val.get(), sizeof(double) * (size_t)slot_rows * 64, hipMemcpyHostToDevice));
     }
     AMG_HIP(hipMemcpy(F.diag, dgs.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
     AMG_HIP(hipMemcpy(F.gate_f, gf.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice));

@@ -398,6 +398,23 @@ void expand_bsr(int nbrows, int R, int C, const int *Ap, const int *Aj, const do
 }
 
 // ------------------------------------------------------------------ schedules
+// host-side loops of the schedule builders over up to 16 threads: fn(first, last) on contiguous ranges of [0, n)
+template <class F> static void host_parallel(long n, long grain, F fn)
+{
+    unsigned hw = std::thread::hardware_concurrency();
+    static const int cap = std::getenv("AMG_SETUP_THREADS") ? std::atoi(std::getenv("AMG_SETUP_THREADS")) : 16;
+    long nt = std::min<long>(std::min<long>(hw ? hw : 1, std::max(1, cap)), (n + grain - 1) / std::max<long>(grain, 1));
+    if (nt <= 1) { fn(0L, n); return; }
+    std::vector<std::thread> th;
+    const long step = (n + nt - 1) / nt;
+    for (long t = 0; t < nt; ++t) {
+        const long lo = t * step, hi = std::min(n, lo + step);
+        if (lo >= hi) break;
+        th.emplace_back([=]() { fn(lo, hi); });
+    }
+    for (auto &t : th) t.join();
+}
+
 void Schedule::release()
 {
     free_csr(G);
@@ -490,16 +507,18 @@ int build_csr_schedule(const int *Ap, const int *Aj, const double *Ax, int n, co
     gp[ntasks] = (int)nnz;
     std::vector<int> gj((size_t)nnz);
     std::vector<double> gx((size_t)nnz);
-    for (int k = 0; k < ntasks; ++k) {
-        int i = rowmap[k];
-        int len = Ap[i + 1] - Ap[i];
-        std::memcpy(gj.data() + gp[k], Aj + Ap[i], sizeof(int) * (size_t)len);
-        std::memcpy(gx.data() + gp[k], Ax + Ap[i], sizeof(double) * (size_t)len);
-        int d = -1;
-        for (int q = 0; q < len; ++q)
-            if (Aj[Ap[i] + q] == i) d = gp[k] + q;   // last diagonal entry wins, as relaxation.h:51-52
-        dpos[k] = d;
-    }
+    host_parallel(ntasks, 1 << 15, [&](long klo, long khi) {
+        for (long k = klo; k < khi; ++k) {
+            int i = rowmap[(size_t)k];
+            int len = Ap[i + 1] - Ap[i];
+            std::memcpy(gj.data() + gp[(size_t)k], Aj + Ap[i], sizeof(int) * (size_t)len);
+            std::memcpy(gx.data() + gp[(size_t)k], Ax + Ap[i], sizeof(double) * (size_t)len);
+            int d = -1;
+            for (int q = 0; q < len; ++q)
+                if (Aj[Ap[i] + q] == i) d = gp[(size_t)k] + q;   // last diagonal entry wins, as relaxation.h:51-52
+            dpos[(size_t)k] = d;
+        }
+    });
     CHK(upload_csr(S.G, ntasks, n, gp.data(), gj.data(), gx.data(), nullptr));
     S.gp_host = gp;
     CHK(dev_alloc(&S.rowmap, ntasks, (long *)nullptr));
@@ -800,11 +819,13 @@ int build_block_schedule(const int *Ap, const int *Aj, int nb, const int *tasks,
         gp[ntasks] = (int)nblk;
         std::vector<int> gj((size_t)nblk);
         std::vector<double> gx((size_t)(nblk * B2));
-        for (int k = 0; k < ntasks; ++k) {
-            int i = rows[k], len = Ap[i + 1] - Ap[i];
-            std::memcpy(gj.data() + gp[k], Aj + Ap[i], sizeof(int) * (size_t)len);
-            std::memcpy(gx.data() + (long)gp[k] * B2, Ax + (long)Ap[i] * B2, sizeof(double) * (size_t)(len * B2));
-        }
+        host_parallel(ntasks, 1 << 14, [&](long klo, long khi) {
+            for (long k = klo; k < khi; ++k) {
+                int i = rows[(size_t)k], len = Ap[i + 1] - Ap[i];
+                std::memcpy(gj.data() + gp[(size_t)k], Aj + Ap[i], sizeof(int) * (size_t)len);
+                std::memcpy(gx.data() + (long)gp[(size_t)k] * B2, Ax + (long)Ap[i] * B2, sizeof(double) * (size_t)(len * B2));
+            }
+        });
         // block Gauss-Seidel: the dataflow form (one persistent launch per smoother application) serves the schedule
         // alone; otherwise the level-ordered copy, and for the levels of a large operator its sliced block form
         if (block_flow && !independent && gs_flow_mode() != 0 && (bs == 2 || bs == 3))
