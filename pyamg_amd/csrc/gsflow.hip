@@ -103,13 +103,32 @@ struct FlowArgs {
 __device__ __forceinline__ int flow_slot(int b, int nw, int xcd)
 {
     if (!xcd || nw < 16) return b;
-    const int per = nw >> 3, rem = nw & 7;                 // XCD k holds per (+1 if k < rem) workgroups: b = 8 j + k
-    const int k = b & 7, j = b >> 3;
+    const int k = b & 7, j = b >> 3;                       // workgroup b = 8 j + k is the j-th of XCD k
+    if (xcd >= 2) {
+        // groups of xcd consecutive tasks, dealt to the XCDs round-robin: every dependency level is spread over all eight
+        // (each XCD has an eighth of the path to memory), neighbours within a group share their operands' lines
+        if (nw % (8 * xcd)) return b;
+        return ((j / xcd) * 8 + k) * xcd + j % xcd;
+    }
+    const int per = nw >> 3, rem = nw & 7;                 // xcd == 1: XCD k holds per (+1 if k < rem) consecutive slots
     return k * per + min(k, rem) + j;
 }
 
 __device__ __forceinline__ unsigned long long ald(const unsigned long long *p)
 {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// First read of an operand through the caches (L2 is per XCD and not coherent with the others'): an X slot goes from the
+// sentinel to its value exactly once per application, so a stale line can only show the sentinel, and a sentinel is polled
+// again with ald().  Operands that were final before this XCD first touched their line are L2 hits instead of one
+// fabric transaction per gather.
+#ifndef AMG_FLOW_PLAIN
+#define AMG_FLOW_PLAIN 1
+#endif
+__device__ __forceinline__ unsigned long long pld(const unsigned long long *p)
+{
+    if (AMG_FLOW_PLAIN) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -227,7 +246,7 @@ __global__ __launch_bounds__(64) void gs_flow_kernel(const FlowChunk *__restrict
             idx[u] = real ? idx[u] : a.n;
             const bool fresh = rev ? (idx[u] >= m.lvl_hi) : (idx[u] < m.lvl_lo);
             idx[u] += fresh ? xs : 0;
-            xb[u] = ald(Xo + idx[u]);
+            xb[u] = pld(Xo + idx[u]);
         }
         for (unsigned spin = 0;; ++spin) {
             bool bad = false;
@@ -328,65 +347,90 @@ __global__ __launch_bounds__(256) void bflow_gather_kernel(const int *rows, cons
 // waves per SIMD --, (8, 2), (8, 4), ... beyond.
 template <int BS, int SEG>
 struct BlockTask {
-    FlowChunk m;
     int bc[SEG];
     double v[SEG][BS];
     double bb;
-    int gate, orow, s;
-    bool valid;
+    double dinv[BS];            // leader lanes: row r of the block row's inverted diagonal block
+    int gate, orow;
 };
 
-template <int BS, int SEG, int LPR>
-__device__ __forceinline__ void bflow_load(BlockTask<BS, SEG> &T, int s, const FlowChunk &mpre, const int *__restrict__ col,
-                                            const double *__restrict__ val, const double *__restrict__ bp, const int *__restrict__ rows,
-                                            const int *__restrict__ gate_f, const int *__restrict__ gate_b, const BlockFlowArgs &a)
+// original block-row number and gate of a task's leader lanes (0 / the zero position elsewhere): requested one task before
+// the rest of the task's share, so that neither the Dinv request nor the first gate poll has to wait for an index
+struct BlockAhead { int orow, gate; };
+template <int BS, int LPR>
+__device__ __forceinline__ BlockAhead bflow_ahead(bool valid, int s, const FlowChunk &m, const int *__restrict__ rows,
+                                                  const int *__restrict__ gate_f, const int *__restrict__ gate_b, const BlockFlowArgs &a)
 {
-    constexpr int NG = 64 / BS, LW = BS * LPR, NBR = 64 / LW;
-    T.valid = s < a.nseq;
-    T.s = s;
-    if (!T.valid) return;
+    constexpr int LW = BS * LPR, NBR = 64 / LW;
     const int lane = threadIdx.x;
-    const int br = lane / LW, grp = lane / BS, r = lane - grp * BS;
+    const int br = lane / LW;
+    const bool leader = valid && br < m.nrows && br < NBR && (lane - br * LW) < BS;
     const bool rev = ((a.dirmask >> s) & 1u) != 0;
-    T.m = mpre;                                     // the chunk descriptor was requested one task ahead (scalar load)
-    const int seg = T.m.nslots;
+    BlockAhead h;
+    h.orow = 0; h.gate = a.nb;
+    if (leader) {
+        h.orow = rows[m.row0 + br];
+        h.gate = rev ? gate_b[m.row0 + br] : gate_f[m.row0 + br];
+    }
+    return h;
+}
+
+// block columns and values of task (s, m): the HBM stream
+template <int BS, int SEG, int LPR>
+__device__ __forceinline__ void bflow_load_matrix(BlockTask<BS, SEG> &T, bool valid, const FlowChunk &m, const int *__restrict__ col,
+                                                   const double *__restrict__ val)
+{
+    constexpr int NG = 64 / BS;
+    if (!valid) return;
+    const int lane = threadIdx.x;
+    const int grp = lane / BS;
+    const int seg = m.nslots;
     const int smax = seg > 0 ? seg - 1 : 0;
     const int gcl = min(grp, NG - 1);
 #pragma unroll
     for (int u = 0; u < SEG; ++u) {
-        const long su = (long)T.m.off + min(u, smax);
+        const long su = (long)m.off + min(u, smax);
         T.bc[u] = col[su * NG + gcl];
 #pragma unroll
         for (int cc = 0; cc < BS; ++cc) T.v[u][cc] = val[(su * BS + cc) * 64 + lane];
     }
-    const bool rowok = br < T.m.nrows && br < NBR;
+}
+
+// what the leader lanes of task (s, m) need besides: right-hand side, gate, their row of Dinv
+template <int BS, int SEG, int LPR>
+__device__ __forceinline__ void bflow_load_leader(BlockTask<BS, SEG> &T, bool valid, const FlowChunk &m, const BlockAhead &h,
+                                                   const double *__restrict__ bp, const BlockFlowArgs &a)
+{
+    constexpr int LW = BS * LPR, NBR = 64 / LW;
+    if (!valid) return;
+    const int lane = threadIdx.x;
+    const int br = lane / LW, grp = lane / BS, r = lane - grp * BS;
+    const bool rowok = br < m.nrows && br < NBR;
     const bool leader = rowok && (lane - br * LW) < BS;
-    const int kb = T.m.row0 + (rowok ? br : 0);
-    T.bb = 0.0; T.orow = 0; T.gate = a.nb;
+    const int kb = m.row0 + (rowok ? br : 0);
+    T.bb = 0.0; T.orow = h.orow; T.gate = h.gate;
+#pragma unroll
+    for (int cc = 0; cc < BS; ++cc) T.dinv[cc] = 0.0;
     if (leader) {
         T.bb = bp[(long)kb * BS + r];
-        T.gate = rev ? gate_b[kb] : gate_f[kb];
-        T.orow = rows[kb];
+#pragma unroll
+        for (int cc = 0; cc < BS; ++cc) T.dinv[cc] = a.Dinv[(long)h.orow * (BS * BS) + r * BS + cc];
     }
 }
 
+// first half of a task: waits for the operands and forms the per-block products vb[] (in stored order, from 0).
 // returns false when the wave ran out of its time budget
 template <int BS, int SEG, int LPR>
-__device__ __forceinline__ bool bflow_run(BlockTask<BS, SEG> &T, double *prod, long long t0, const BlockFlowArgs &a)
+__device__ __forceinline__ bool bflow_operands(BlockTask<BS, SEG> &T, int s, const FlowChunk &m, double (&vb)[SEG], long long t0,
+                                               const BlockFlowArgs &a)
 {
-    constexpr int NG = 64 / BS, LW = BS * LPR, NBR = 64 / LW;
+    constexpr int NG = 64 / BS;
     const int lane = threadIdx.x;
-    const int br = lane / LW, grp = lane / BS, r = lane - grp * BS;
-    const FlowChunk &m = T.m;
-    const int s = T.s, seg = m.nslots;
+    const int grp = lane / BS, r = lane - grp * BS;
+    const int seg = m.nslots;
     const bool rev = ((a.dirmask >> s) & 1u) != 0;
-    const bool last = s == a.nseq - 1;
-    const bool rowok = br < m.nrows && br < NBR;
-    const bool leader = rowok && (lane - br * LW) < BS;                  // g == 0: lanes (block row, 0, r)
-    const int kb = m.row0 + (rowok ? br : 0);
     const unsigned long long *Xo = a.X + (long)s * a.xstride;
-    unsigned long long *Xn = a.X + (long)(s + 1) * a.xstride;
-    const unsigned long long *gp_ = Xn + (long)T.gate * BS + r;
+    const unsigned long long *gp_ = a.X + (long)(s + 1) * a.xstride + (long)T.gate * BS + r;
     unsigned long long gv = ald(gp_);
     for (unsigned spin = 0; __any(gv == FLOW_SENT); ++spin) {
         __builtin_amdgcn_s_sleep(4);
@@ -408,7 +452,7 @@ __device__ __forceinline__ bool bflow_run(BlockTask<BS, SEG> &T, double *prod, l
         const bool fresh = rev ? (cb >= m.lvl_hi) : (cb < m.lvl_lo);
         idx[u] = cb * BS + (fresh ? xs : 0);
 #pragma unroll
-        for (int cc = 0; cc < BS; ++cc) xb[u][cc] = ald(Xo + idx[u] + cc);
+        for (int cc = 0; cc < BS; ++cc) xb[u][cc] = pld(Xo + idx[u] + cc);
     }
     for (unsigned spin = 0;; ++spin) {
         bool bad = false;
@@ -428,7 +472,6 @@ __device__ __forceinline__ bool bflow_run(BlockTask<BS, SEG> &T, double *prod, l
             for (int cc = 0; cc < BS; ++cc)
                 if (xb[u][cc] == FLOW_SENT) xb[u][cc] = ald(Xo + idx[u] + cc);
     }
-    double vb[SEG];
 #pragma unroll
     for (int u = 0; u < SEG; ++u) {
         double w = 0.0;
@@ -436,6 +479,22 @@ __device__ __forceinline__ bool bflow_run(BlockTask<BS, SEG> &T, double *prod, l
         for (int cc = 0; cc < BS; ++cc) w = w + T.v[u][cc] * __longlong_as_double((long long)xb[u][cc]);
         vb[u] = w;
     }
+    return true;
+}
+
+// second half: row sums in stored order, x_i = Dinv_i (b_i - rsum), store
+template <int BS, int SEG, int LPR>
+__device__ __forceinline__ void bflow_finish(const BlockTask<BS, SEG> &Q, int s, const FlowChunk &m, const double (&vb)[SEG], double *prod,
+                                             const BlockFlowArgs &a)
+{
+    constexpr int LW = BS * LPR, NBR = 64 / LW;
+    const int lane = threadIdx.x;
+    const int br = lane / LW, grp = lane / BS, r = lane - grp * BS;
+    const bool last = s == a.nseq - 1;
+    const bool rowok = br < m.nrows && br < NBR;
+    const bool leader = rowok && (lane - br * LW) < BS;
+    const int kb = m.row0 + (rowok ? br : 0);
+    unsigned long long *Xn = a.X + (long)(s + 1) * a.xstride;
     double rsum = 0.0;
     if constexpr (LPR == 1) {
 #pragma unroll
@@ -460,20 +519,18 @@ __device__ __forceinline__ bool bflow_run(BlockTask<BS, SEG> &T, double *prod, l
         flow_wave_sync();
     }
     // x_i = Dinv_i (b_i - rsum): the BS leaders of the block row exchange their entries of b - rsum
-    const double t = T.bb - rsum;
+    const double t = Q.bb - rsum;
     double vD = 0.0;
     const int base = br * LW;
 #pragma unroll
     for (int cc = 0; cc < BS; ++cc) {
         const double tc = __shfl(t, base + cc, 64);
-        const double d = leader ? a.Dinv[(long)T.orow * (BS * BS) + r * BS + cc] : 0.0;
-        vD = vD + d * tc;
+        vD = vD + Q.dinv[cc] * tc;
     }
     if (leader) {
         __hip_atomic_store(Xn + (long)kb * BS + r, (unsigned long long)__double_as_longlong(vD), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (last) a.x_out[(long)T.orow * BS + r] = vD;
+        if (last) a.x_out[(long)Q.orow * BS + r] = vD;
     }
-    return true;
 }
 
 template <int BS, int SEG, int LPR>
@@ -489,15 +546,34 @@ __global__ __launch_bounds__(64) void bgs_flow_kernel(const FlowChunk *__restric
     while (q >= a.nchunks) { q -= a.nchunks; ++s; }
     BlockTask<BS, SEG> T;
     auto chunk_of = [&](int ss, int qq) { return (((a.dirmask >> ss) & 1u) != 0) ? a.nchunks - 1 - qq : qq; };
-    FlowChunk mnext = meta[s < a.nseq ? chunk_of(s, q) : 0];
+    auto advance = [&](int &ss, int &qq) { qq += NW; while (qq >= a.nchunks) { qq -= a.nchunks; ++ss; } };
+    // task i = (s, q), descriptor m0, its share in T; m1 / h1: descriptor and leader indices of task i + 1; m2: descriptor of i + 2
+    int s1 = s, q1 = q;
+    advance(s1, q1);
+    FlowChunk m0 = meta[s < a.nseq ? chunk_of(s, q) : 0];
+    FlowChunk m1 = meta[s1 < a.nseq ? chunk_of(s1, q1) : 0];
+    bflow_load_matrix<BS, SEG, LPR>(T, s < a.nseq, m0, col, val);
+    bflow_load_leader<BS, SEG, LPR>(T, s < a.nseq, m0, bflow_ahead<BS, LPR>(s < a.nseq, s, m0, rows, gate_f, gate_b, a), bp, a);
+    BlockAhead h1 = bflow_ahead<BS, LPR>(s1 < a.nseq, s1, m1, rows, gate_f, gate_b, a);
+    __builtin_amdgcn_s_waitcnt(0x0F70);    // vmcnt(0): with nothing of the prologue pending, the loop's first poll is not made to wait for the share in flight
     while (s < a.nseq) {
-        const FlowChunk mcur = mnext;
-        int s2 = s, q2 = q + NW;
-        while (q2 >= a.nchunks) { q2 -= a.nchunks; ++s2; }
-        mnext = meta[s2 < a.nseq ? chunk_of(s2, q2) : 0];      // scalar load, not needed before the next task
-        bflow_load<BS, SEG, LPR>(T, s, mcur, col, val, bp, rows, gate_f, gate_b, a);
-        if (!bflow_run<BS, SEG, LPR>(T, prod, t0, a)) return;
-        s = s2; q = q2;
+        int s2 = s1, q2 = q1;
+        advance(s2, q2);
+        const FlowChunk m2 = meta[s2 < a.nseq ? chunk_of(s2, q2) : 0];      // scalar load, not needed before the products are formed
+        double vb[SEG];
+        if (!bflow_operands<BS, SEG, LPR>(T, s, m0, vb, t0, a)) return;
+        // the products are formed: T's matrix registers are free, and the next task's columns and values (HBM) travel while
+        // this one sums, solves and stores.  Requested any earlier they would sit in front of the operand polls (in-order
+        // returns); the compiler must neither lift them above the products nor sink the products below them
+#pragma unroll
+        for (int u = 0; u < SEG; ++u) asm volatile("" : "+v"(vb[u]));
+        __builtin_amdgcn_sched_barrier(0);
+        bflow_load_matrix<BS, SEG, LPR>(T, s1 < a.nseq, m1, col, val);
+        bflow_finish<BS, SEG, LPR>(T, s, m0, vb, prod, a);
+        __builtin_amdgcn_sched_barrier(0);
+        bflow_load_leader<BS, SEG, LPR>(T, s1 < a.nseq, m1, h1, bp, a);        // into the registers the store just freed
+        h1 = bflow_ahead<BS, LPR>(s2 < a.nseq, s2, m2, rows, gate_f, gate_b, a);
+        s = s1; q = q1; s1 = s2; q1 = q2; m0 = m1; m1 = m2;
     }
 }
 
@@ -524,18 +600,25 @@ int flow_status_word(int **out)
 
 // consecutive tasks on one XCD: measured -4 .. -7 % per sweep on the point operators of a 3-D SA hierarchy (128^3: 1.17 -> 1.12,
 // 1.40 -> 1.30, 1.94 -> 1.87 us per level; 200^3 cycle 16.9 -> 16.1 ms), level on the wide block levels of C5 (off there)
+// Task-to-XCD mapping (flow_slot): point sweeps 1 (consecutive slots per XCD; SA + symmetric GS at 200^3 16.8 -> 16.0 ms per
+// cycle), block sweeps groups of 64 tasks dealt round-robin (C5 at 360^3 with 8 waves per CU: 11.9 -> 11.5 ms per level-0
+// application; the contiguous mapping keeps only the XCDs of the current levels busy there: 4.99 vs 4.70 ms at 252^3)
 int flow_xcd(bool block)
 {
     static const int x = std::getenv("AMG_FLOW_XCD") ? std::atoi(std::getenv("AMG_FLOW_XCD")) : 1;
-    static const int xb = std::getenv("AMG_FLOW_XCD_BLOCK") ? std::atoi(std::getenv("AMG_FLOW_XCD_BLOCK")) : 0;
+    static const int xb = std::getenv("AMG_FLOW_XCD_BLOCK") ? std::atoi(std::getenv("AMG_FLOW_XCD_BLOCK")) : 64;
     return block ? xb : x;
 }
 
-// one-wave workgroups a compute unit is asked to hold at most (the occupancy query is the other bound)
-int flow_wpc()
+// one-wave workgroups a compute unit is asked to hold at most (the occupancy query is the other bound).  Block sweeps: 8 --
+// their time is bytes / 6.2 TB/s + levels x 1.7 us (profiles/r03_c5_traffic.txt), and waves beyond what covers one hop
+// only put their 8 KB shares in front of the operand polls of the level in progress
+int flow_wpc(bool block)
 {
     static const int w = std::getenv("AMG_FLOW_WPC") ? std::atoi(std::getenv("AMG_FLOW_WPC")) : 16;
-    return std::max(1, w);
+    static const int wb = std::getenv("AMG_FLOW_WPC_BLOCK") ? std::atoi(std::getenv("AMG_FLOW_WPC_BLOCK"))
+                                                            : (std::getenv("AMG_FLOW_WPC") ? w : 8);
+    return std::max(1, block ? wb : w);
 }
 
 template <int LPR>
@@ -552,7 +635,7 @@ int flow_waves_cap(bool bsr1)
         hipDeviceProp_t pr;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount;
         if (ncu < 1) ncu = 64;
-        c = std::max(16, ncu * std::min(nb, flow_wpc()) * 3 / 4);
+        c = std::max(16, ncu * std::min(nb, flow_wpc(false)) * 3 / 4);
     }
     return c;
 }
@@ -566,6 +649,7 @@ int launch_flow(const FlowForm &F, bool bsr1, const FlowArgs &a, hipStream_t st)
     nw = std::max<long>(nw, minw);
     nw = std::min<long>(nw, flow_waves_cap<LPR>(bsr1));
     nw = std::min<long>(nw, (long)a.nseq * F.nchunks);
+    if (a.xcd >= 2 && nw >= 8L * a.xcd) nw -= nw % (8L * a.xcd);
     if (bsr1) hipLaunchKernelGGL((gs_flow_kernel<FLOW_SEG, LPR, true>), dim3((unsigned)nw), dim3(64), 0, st, F.meta, F.col, F.val, F.diag, F.bp, F.rowmap, F.gate_f, F.gate_b, a);
     else hipLaunchKernelGGL((gs_flow_kernel<FLOW_SEG, LPR, false>), dim3((unsigned)nw), dim3(64), 0, st, F.meta, F.col, F.val, F.diag, F.bp, F.rowmap, F.gate_f, F.gate_b, a);
     hipError_t e = hipGetLastError();
@@ -583,7 +667,7 @@ int launch_bflow(const BlockFlowForm &F, const BlockFlowArgs &a, hipStream_t st)
         hipDeviceProp_t pr;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount;
         if (ncu < 1) ncu = 64;
-        cap = std::max(16, ncu * std::min(nb, flow_wpc()) * 3 / 4);
+        cap = std::max(16, ncu * std::min(nb, flow_wpc(true)) * 3 / 4);
     }
     const int la = g_flow_la > 0 ? g_flow_la : 4;
     long nw = (long)la * ((F.nchunks + std::max(1, F.nlevels) - 1) / std::max(1, F.nlevels));
@@ -591,6 +675,7 @@ int launch_bflow(const BlockFlowForm &F, const BlockFlowArgs &a, hipStream_t st)
     nw = std::max<long>(nw, minw);
     nw = std::min<long>(nw, cap);
     nw = std::min<long>(nw, (long)a.nseq * F.nchunks);
+    if (a.xcd >= 2 && nw >= 8L * a.xcd) nw -= nw % (8L * a.xcd);
     hipLaunchKernelGGL((bgs_flow_kernel<BS, SEG, LPR>), dim3((unsigned)nw), dim3(64), 0, st, F.meta, F.col, F.val, F.bp, F.rows, F.gate_f, F.gate_b, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "dataflow block Gauss-Seidel launch", __FILE__, __LINE__);
