@@ -268,3 +268,21 @@ def test_gmres_drivers_restart_breakdown_and_1x1_on_host_vectors():
         bd, xd = V.upload([2.0]), V.upload([0.0])
         assert method(V, bd, xd, tol=1e-8, restrt=3, maxiter=2) == 0
         assert V.download(xd)[0] == 0.5
+
+
+def test_blackbox_configuration_is_marked_as_substituted():
+    """pyamg_amd.blackbox does not reproduce the reference's configuration (blackbox.py:56-158); the
+    returned dictionary says so, and non-symmetric input is refused (the reference would use gauss_seidel_nr + gmres)"""
+    import scipy.sparse as sp
+    from pyamg_amd import blackbox
+    from pyamg_amd.gallery import poisson
+    A = poisson((12, 12), format="csr")
+    cfg = blackbox.solver_configuration(A, verb=False)
+    assert cfg["note"] == blackbox.SUBSTITUTED and "substituted" in cfg["note"]
+    assert cfg["strength"] == "symmetric" and cfg["smooth"] == ("jacobi", {"omega": 4.0 / 3.0})
+    assert cfg["presmoother"] == cfg["postsmoother"] == ("block_gauss_seidel", {"sweep": "symmetric", "iterations": 1})
+    assert cfg["B"].shape == (144, 1) and cfg["max_coarse"] == 500 and cfg["coarse_solver"] == "pinv"
+    assert "note" not in blackbox._setup_arguments(cfg)
+    N = (A + sp.diags([np.full(143, 0.5)], [1])).tocsr()
+    with pytest.raises(NotImplementedError):
+        blackbox.solver_configuration(N, verb=False)
