@@ -309,6 +309,7 @@ def partitioned_main(args, rank, local_rank, world, torch, dist):
         ms_resid = ms_resid.value
         form = Lb.amg_hier_operator_form(h, 0)
         moved = Lb.amg_hier_operator_bytes(h, 0, 1)
+        coded0 = Lb.amg_hier_value_index(h, 0, -1)
         overl = "interior rows overlap the exchange" if os.environ.get("AMG_DIST_OVERLAP", "1") != "0" else "plain exchange"
     else:
         S.set_problem(b, None)
@@ -329,6 +330,7 @@ def partitioned_main(args, rank, local_rank, world, torch, dist):
         ms_resid = e0.elapsed_time(e1) / 20
         form = S.operator_form(0)
         moved = None
+        coded0 = 0
         overl = "python driver"
     tw = torch.tensor([wall], dtype=torch.float64)
     dist.all_reduce(tw, op=dist.ReduceOp.MAX, group=host_group)
@@ -357,7 +359,7 @@ def partitioned_main(args, rank, local_rank, world, torch, dist):
                        "setup_seconds": setup_seconds(t_gen, t_setup),
                        "residuals": [r0, float(warm[-1]), float(timed[-1])]},
             "roofline": {"bound": "hbm",
-                         "kernel": {0: "csr_stream_kernel", 1: "csr_pattern_kernel", 2: "stencil2_kernel"}.get(form, "csr_stream_kernel") +
+                         "kernel": {0: "csr_stream_kernel", 1: "csr_pattern_kernel", 2: "stencil_kernel (one-byte value codes)" if coded0 else "stencil2_kernel"}.get(form, "csr_stream_kernel") +
                                    " (level-0 A-application on rank 0's row block)",
                          "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
@@ -473,7 +475,10 @@ def config_main(args, rank, local_rank, world, torch, dist, L):
         ms_resid = dev.time_spmv(0, 0, mode=1, reps=10)
         form = L.amg_hier_operator_form(h, 0)
         if kname is None:
-            kname = {0: "csr_stream_kernel<JACOBI>", 1: "csr_pattern_kernel<JACOBI>", 2: "stencil2_kernel<JACOBI>"}[form] + " (level-0 weighted-Jacobi sweep)"
+            coded = L.amg_hier_value_index(h, 0, -1)
+            kname = {0: "csr_stream_kernel<JACOBI>", 1: "csr_pattern_kernel<JACOBI>",
+                     2: "stencil_kernel<JACOBI>" if coded else "stencil2_kernel<JACOBI>"}[form] + " (level-0 weighted-Jacobi sweep%s)" % (
+                         ", one-byte value codes: %d distinct values" % coded if coded else "")
         # `achieved` prices the launch at the bytes the kernel's storage form streams where that is fewer than the CSR
         # bytes of SURVEY 8(d) (a Jacobi sweep from the stencil form: the same operands as r = b - A x); the CSR-priced
         # figure stays beside it.  The Gauss-Seidel kernels stream level-ordered CSR / BSR copies: algorithmic = moved.
@@ -535,7 +540,7 @@ def main():
     ap.add_argument("--smoother", default=None, help="C3: chebyshev (default) | jacobi | gauss_seidel; C4: hybrid_gs (default) | hybrid_gs_lex")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-anyway", action="store_true", help="N > 1: time the CPU oracle on rank 0 too (default: N = 1 only)")
-    ap.add_argument("--no-value-index", action="store_true", help="skip the opt-in value-index extra measurement")
+    ap.add_argument("--no-value-index", action="store_true", help="skip the extra measurement of the step with 8-byte level-0 values (value index off)")
     ap.add_argument("--variant", type=int, default=None, help="CSR stream kernel load variant (0/1)")
     ap.add_argument("--xcd-chunk", type=int, default=None)
     ap.add_argument("--tile-target", type=int, default=None)
@@ -645,37 +650,51 @@ def main():
     out = None
     if rank == 0:
         A0 = ml.levels[0].A
-        spmv_bytes = 12.0 * A0.nnz + 4.0 * (n + 1) + 8.0 * n + 8.0 * n + 8.0 * n   # bytes_spmv(A0) + 8 n
         reps = 20
-        ms_resid = dev.time_spmv(0, 0, mode=1, reps=reps)     # r = b - A x as the cycle runs it
+        NAMES = {0: "csr_stream_kernel", 1: "csr_pattern_kernel", 2: "stencil2_kernel", 3: "sell_kernel"}
+        PMC_KEYS = {"sell_kernel": "level1_residual", "stencil_kernel": "level0_coded", "stencil2_kernel": "level0_values"}
+
+        def residual_kernel(lvl):
+            """r = b - A x of level lvl as the cycle launches it: time, bytes of SURVEY 8(d), bytes its storage form streams"""
+            Al = ml.levels[lvl].A
+            nl = Al.shape[0]
+            ms = dev.time_spmv(lvl, 0, mode=1, reps=reps)
+            alg = 12.0 * Al.nnz + 4.0 * (nl + 1) + 8.0 * nl + 8.0 * nl + 8.0 * nl      # bytes_spmv(A) + 8 n
+            form = L.amg_hier_operator_form(h, lvl)
+            moved = L.amg_hier_operator_bytes(h, lvl, 1)
+            coded = L.amg_hier_value_index(h, lvl, -1)
+            name = NAMES[form] if not coded else "stencil_kernel"
+            # `achieved` / `frac` price the launch at the bytes this kernel's storage form actually streams (DESIGN.md
+            # section 4) -- the figure bounded by the HBM peak; `csr_equivalent_GBs` prices it at the CSR bytes of
+            # SURVEY.md 8(d) (12 B per stored entry), what the reference's csr_matvec would have to stream.
+            return {"kernel": "%s<RESIDUAL> (level-%d A-application, r = b - A x%s)" %
+                              (name, lvl, ", one-byte value codes: %d distinct values" % coded if coded else ""),
+                    "form": form, "value_index_distinct_values": coded,
+                    "ms_per_launch": round(ms, 4), "bytes_per_launch": moved,
+                    "achieved": round(moved / (ms * 1e-3) / 1e9, 1), "frac": round(moved / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "csr_equivalent_bytes_per_launch": alg, "csr_equivalent_GBs": round(alg / (ms * 1e-3) / 1e9, 1),
+                    "csr_equivalent_frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        k0 = residual_kernel(0)
+        k1 = residual_kernel(1) if len(ml.levels) > 2 else None
+        # every level's A is applied the same number of times per cycle (smoother applications + the residual), so the
+        # operator with the longer launch is the one the step spends most of its time in
+        dom, other = (k1, k0) if (k1 is not None and k1["ms_per_launch"] > k0["ms_per_launch"]) else (k0, k1)
         # (the plain CSR / offset-pattern kernels can only be timed beside it when the hierarchy kept the CSR arrays:
         #  AMG_RELEASE_SOURCES=0; by default a hierarchy of this size releases them -- 22 GB of HBM)
         try:
-            ms_resid_csr = dev.time_spmv(0, 0, mode=3, reps=reps) # the same through the plain CSR stream kernel
+            ms_resid_csr = dev.time_spmv(0, 0, mode=3, reps=reps) # level 0 through the plain CSR stream kernel
             ms_resid_pat = dev.time_spmv(0, 0, mode=5, reps=reps) # ... and through the offset-pattern kernel
         except Exception:       # noqa: BLE001
             ms_resid_csr = ms_resid_pat = None
         ms_matvec = dev.time_spmv(0, 0, mode=0, reps=reps)
         ms_P = dev.time_spmv(0, 1, mode=0, reps=reps)
         ms_R = dev.time_spmv(0, 2, mode=0, reps=reps)
-        ach = spmv_bytes / (ms_resid * 1e-3) / 1e9
-        form = L.amg_hier_operator_form(h, 0)
-        moved = L.amg_hier_operator_bytes(h, 0, 1)
-        kname = {0: "csr_stream_kernel", 1: "csr_pattern_kernel", 2: "stencil2_kernel"}[form]
-        # `achieved` prices the launch at the CSR bytes of SURVEY.md 8(d) (12 B per stored entry), the figure
-        # the reference's csr_matvec would have to stream; `moved_GBs` prices it at what this kernel's
-        # storage form actually streams -- that one is bounded by the HBM peak.
-        # `achieved` / `frac` price the launch at the bytes this kernel's storage form actually streams (DESIGN.md
-        # section 4) -- the figure bounded by the HBM peak; `csr_equivalent_GBs` prices it at the CSR bytes of
-        # SURVEY.md 8(d) (12 B per stored entry), what the reference's csr_matvec would have to stream.
-        ach_moved = moved / (ms_resid * 1e-3) / 1e9
-        roofline = {"bound": "hbm",
-                    "kernel": kname + " (level-0 A-application, r = b - A x)",
-                    "achieved": round(ach_moved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach_moved / HBM_PEAK_GBS, 4), "traffic": None,
-                    "bytes_per_launch": moved, "ms_per_launch": round(ms_resid, 4),
-                    "csr_equivalent_bytes_per_launch": spmv_bytes, "csr_equivalent_GBs": round(ach, 1),
-                    "csr_equivalent_frac": round(ach / HBM_PEAK_GBS, 4),
+        roofline = {"bound": "hbm", "kernel": dom["kernel"],
+                    "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"], "traffic": None,
+                    "bytes_per_launch": dom["bytes_per_launch"], "ms_per_launch": dom["ms_per_launch"],
+                    "csr_equivalent_bytes_per_launch": dom["csr_equivalent_bytes_per_launch"],
+                    "csr_equivalent_GBs": dom["csr_equivalent_GBs"], "csr_equivalent_frac": dom["csr_equivalent_frac"],
+                    "second_kernel": other,
                     "plain_csr_stream_ms_per_launch": None if ms_resid_csr is None else round(ms_resid_csr, 4),
                     "pattern_kernel_ms_per_launch": None if ms_resid_pat is None else round(ms_resid_pat, 4),
                     "hbm_resident_GB": round(dev.device_bytes() / 1e9, 2),
@@ -686,47 +705,52 @@ def main():
                     "cycle_moved_GBs": round(dev.cycle_bytes_moved("V") * (args.steps / (ev_ms * 1e-3)) / 1e9, 1),
                     "other_kernels_ms": {"A0_matvec": round(ms_matvec, 4), "P0_matvec": round(ms_P, 4),
                                          "R0_matvec": round(ms_R, 4)}}
-        # OPT-IN extra, reported beside the headline and never part of it: the level-0 operator of this
-        # benchmark has constant coefficients (2 distinct values), so its values can be one-byte codes into a
-        # dictionary (amg_hier_value_index).  Same doubles in every product -> the same iterates
-        # (tests/test_gpu_parity.py::test_value_index_is_lossless_and_opt_in); only timed here.
+        # The level-0 operator of this benchmark has constant coefficients (2 distinct values + the padding zero), so the
+        # library stores its values as one-byte codes into a dictionary (automatic since r3, amg_hier_value_index; the
+        # products use the same doubles: tests/test_gpu_parity.py::test_value_index_is_lossless_and_automatic).  What the
+        # same step costs with the 8-byte values -- the r1/r2 headline, and what a variable-coefficient operator of the
+        # same shape would get -- is timed here as an extra.
         value_index = None
-        if not args.no_value_index:
+        nd0 = L.amg_hier_value_index(h, 0, -1)
+        if nd0 > 0 and not args.no_value_index:
             try:
-                nd = L.amg_hier_value_index(h, 0, 1)
-                if nd > 0:
-                    res_vi = np.zeros(args.steps + 2); n_vi = C.c_int(0)
-                    for _ in range(2):          # first pass warms up / captures, second is timed
-                        _lib.check(L.amg_hier_solve(h, db, dx, 0.0, args.steps, 0, _lib.dp(res_vi), C.byref(n_vi),
-                                                    NO_EARLY_STOP | DEVICE_VECTORS))
-                    torch.cuda.synchronize()
-                    t0 = time.perf_counter()
+                L.amg_hier_value_index(h, 0, 0)
+                res_vi = np.zeros(args.steps + 2); n_vi = C.c_int(0)
+                for _ in range(2):          # first pass warms up / captures, second is timed
                     _lib.check(L.amg_hier_solve(h, db, dx, 0.0, args.steps, 0, _lib.dp(res_vi), C.byref(n_vi),
                                                 NO_EARLY_STOP | DEVICE_VECTORS))
-                    torch.cuda.synchronize()
-                    w_vi = time.perf_counter() - t0
-                    ms_vi = dev.time_spmv(0, 0, mode=1, reps=reps)
-                    value_index = {"distinct_values": int(nd), "value": round(args.steps / w_vi, 4),
-                                   "ms_per_step": round(1e3 * w_vi / args.steps, 4),
-                                   "level0_ms_per_launch": round(ms_vi, 4),
-                                   "level0_bytes_moved_per_launch": L.amg_hier_operator_bytes(h, 0, 1),
-                                   "cycle_bytes_moved": dev.cycle_bytes_moved("V"),
-                                   "note": "opt-in (amg_hier_value_index); lossless; not used for `value`"}
-                    L.amg_hier_value_index(h, 0, 0)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                _lib.check(L.amg_hier_solve(h, db, dx, 0.0, args.steps, 0, _lib.dp(res_vi), C.byref(n_vi),
+                                            NO_EARLY_STOP | DEVICE_VECTORS))
+                torch.cuda.synchronize()
+                w_vi = time.perf_counter() - t0
+                kv = residual_kernel(0)
+                value_index = {"level0_distinct_values": int(nd0),
+                               "off": {"value": round(args.steps / w_vi, 4), "ms_per_step": round(1e3 * w_vi / args.steps, 4),
+                                       "level0": kv, "cycle_bytes_moved": dev.cycle_bytes_moved("V")},
+                               "note": "automatic and lossless (same doubles in every product, bit-identical iterates); "
+                                       "`off` = the same step with level 0's 8-byte values, the r1/r2 headline configuration"}
             except Exception as e:      # noqa: BLE001 -- an extra must never take the bench line down
                 value_index = {"error": repr(e)}
-                L.amg_hier_value_index(h, 0, 0)
-        roofline["value_index_extra"] = value_index
-        for name in ("r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
-            pmc = os.path.join(ROOT, "profiles", name)
-            if os.path.exists(pmc):
-                pj = json.load(open(pmc))
-                if pj.get("grid") == args.grid and pj.get("form") == form:
-                    # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel (profiles/README.md): a COMMITTED
-                    # measurement of the same launch, not taken in this run (counters need rocprofv3 around the process)
-                    roofline["traffic"] = pj["traffic_bytes"]
-                    roofline["traffic_source"] = "from_file: profiles/%s (%s)" % (name, pj["source"])
-                    break
+            L.amg_hier_value_index(h, 0, 1)
+        elif nd0 > 0:
+            value_index = {"level0_distinct_values": int(nd0)}
+        roofline["value_index"] = value_index
+        pmc = os.path.join(ROOT, "profiles", "r03_pmc_summary.json")
+        if os.path.exists(pmc):
+            pj = json.load(open(pmc))
+            ents = pj.get("entries", {}) if pj.get("grid") == args.grid else {}
+            ent = ents.get(PMC_KEYS.get(dom["kernel"].split("<")[0]))
+            if ent is not None:
+                # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel (profiles/README.md): a COMMITTED
+                # measurement of the same launch, not taken in this run (counters need rocprofv3 around the process)
+                roofline["traffic"] = ent["traffic_bytes"]
+                roofline["traffic_source"] = "from_file: profiles/r03_pmc_summary.json entry %s (%s)" % (
+                    PMC_KEYS[dom["kernel"].split("<")[0]], pj["source"])
+            ent2 = ents.get(PMC_KEYS.get(other["kernel"].split("<")[0])) if other is not None else None
+            if ent2 is not None:
+                other["traffic"] = ent2["traffic_bytes"]
         cpu = None
         if not args.no_cpu_baseline:
             def gpu_first():

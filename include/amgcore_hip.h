@@ -243,11 +243,15 @@ int amg_hier_matvec(amg_hier *h, int lvl, int which, const double *x, double *y)
 double amg_hier_cycle_bytes(amg_hier *h, int cycle);
 /* storage form level lvl's A is applied from: 0 CSR, 1 offset-pattern, 2 stencil, 3 sliced (SELL-64-sigma) */
 int amg_hier_operator_form(amg_hier *h, int lvl);
-/* OPT-IN value index for a level whose A is in stencil form and holds at most 255 distinct values (constant-
- * coefficient stencils): one-byte codes into a dictionary instead of the 8-byte values; the products use the
- * same doubles, so results are bit-identical.  on != 0 builds/enables it and returns the number of distinct
- * values (0: not applicable, < 0: error); on == 0 returns to the plain values.  Never enabled by default. */
+/* Value index for a level whose A is in stencil form and holds at most 255 distinct values (constant-coefficient
+ * stencils): one-byte codes into a dictionary instead of the 8-byte values; the products use the same doubles, so
+ * results are bit-identical.  r3: built automatically when the operator is set (amg_set_value_index(0) or
+ * AMG_VALUE_INDEX=0 turns that off; an operator whose values do not compress keeps them).  This entry toggles one
+ * level: on > 0 builds/enables it and returns the number of distinct values (0: not applicable, < 0: error);
+ * on == 0 returns to the plain values; on < 0 queries (distinct values when in use, else 0). */
 int amg_hier_value_index(amg_hier *h, int lvl, int on);
+void amg_set_value_index(int on);       /* process-wide default for operators set afterwards */
+int amg_value_index_enabled(void);
 /* bytes of one r = b - A x on level lvl: moved = 0 the CSR figure of SURVEY.md 8(d), 1 what the form in use streams */
 double amg_hier_operator_bytes(amg_hier *h, int lvl, int moved);
 /* bytes one solve() iteration needs as this library runs it: offset-pattern operators without

@@ -155,6 +155,10 @@ def lib():
     L.amg_hier_cycle_bytes.restype = D
     L.amg_hier_value_index.argtypes = [V, I, I]
     L.amg_hier_value_index.restype = I
+    L.amg_set_value_index.argtypes = [I]
+    L.amg_set_value_index.restype = None
+    L.amg_value_index_enabled.argtypes = []
+    L.amg_value_index_enabled.restype = I
     L.amg_hier_operator_form.argtypes = [V, I]
     L.amg_hier_operator_form.restype = I
     L.amg_hier_operator_bytes.argtypes = [V, I, I]

@@ -1629,6 +1629,51 @@ void amg_hier_destroy(amg_hier *h)
     if (!(h)) { set_error("null hierarchy"); return AMG_EINVAL; }       \
     AMG_HIP(hipSetDevice((h)->device))
 
+/* Value index of an operator in stencil form (amg_dev.hpp, DevCsr::st_codes): scans the padded values on the device and,
+ * when there are at most 255 distinct ones, stores one-byte codes into a dictionary.  Returns the number of distinct values,
+ * 0 when not applicable (no stencil form, too many values), < 0 on error. */
+static int value_index_build(amg_hier *h, DevCsr &M)
+{
+    if (!M.st_vals) return 0;
+    if (M.st_codes) { M.st_vi_on = true; return M.st_ndict; }
+    const long count = (long)((M.nrows + 255) / 256) * M.st_nu * 256;
+    unsigned long long *table = nullptr;
+    int *ovf = nullptr;
+    if (dev_alloc(&table, 1024, nullptr) != 0 || dev_alloc(&ovf, 1, nullptr) != 0) return AMG_ENOMEM;
+    AMG_HIP(hipMemset(table, 0xFF, sizeof(unsigned long long) * 1024));
+    AMG_HIP(hipDeviceSynchronize());
+    int rc = launch_value_scan(M.st_vals, count, table, ovf, h->stream);
+    std::vector<unsigned long long> tb(1024);
+    int overflow = 0;
+    AMG_HIP(hipStreamSynchronize(h->stream));
+    AMG_HIP(hipMemcpy(tb.data(), table, sizeof(unsigned long long) * 1024, hipMemcpyDeviceToHost));
+    AMG_HIP(hipMemcpy(&overflow, ovf, sizeof(int), hipMemcpyDeviceToHost));
+    hipFree(table); hipFree(ovf);
+    if (rc != 0) return AMG_ESTATE;
+    std::vector<long long> bits;
+    for (unsigned long long v : tb) if (v != ~0ULL) bits.push_back((long long)v);
+    if (overflow || bits.empty() || bits.size() > 255) return 0;          // not a few-valued operator
+    std::sort(bits.begin(), bits.end());
+    std::vector<double> dict(256, 0.0);
+    for (size_t k = 0; k < bits.size(); ++k) std::memcpy(&dict[k], &bits[k], sizeof(double));
+    if (dev_alloc(&M.st_dict, 256, &h->dev_bytes) != 0) return AMG_ENOMEM;
+    AMG_HIP(hipMemcpy(M.st_dict, dict.data(), sizeof(double) * 256, hipMemcpyHostToDevice));
+    const long code_bytes = (long)((M.nrows + 255) / 256) * ((M.st_nu + 7) / 8) * 256 * 8;
+    if (dev_alloc(&M.st_codes, code_bytes, &h->dev_bytes) != 0) return AMG_ENOMEM;
+    M.st_ndict = (int)bits.size();
+    rc = launch_value_encode(M.st_vals, count, M.st_dict, M.st_ndict, M.st_codes, M.st_nu, h->stream);
+    AMG_HIP(hipStreamSynchronize(h->stream));
+    if (rc != 0) return AMG_ESTATE;
+    M.st_vi_on = true;
+    return M.st_ndict;
+}
+
+// r3: applied when an operator is set (amg_hier_set_matrix) unless AMG_VALUE_INDEX=0 / amg_set_value_index(0): an operator
+// whose values do not compress is left as it is (one scan of its values, ~1 ms per 5 GB)
+static int g_value_index_auto = std::getenv("AMG_VALUE_INDEX") ? std::atoi(std::getenv("AMG_VALUE_INDEX")) : 1;
+void amg_set_value_index(int on) { g_value_index_auto = on ? 1 : 0; }
+int amg_value_index_enabled(void) { return g_value_index_auto; }
+
 int amg_hier_set_matrix(amg_hier *h, int lvl, int which, int fmt, int nrows, int ncols, int R, int C,
                         const int *Ap, const int *Aj, const double *Ax, int on_device)
 {
@@ -1661,11 +1706,13 @@ int amg_hier_set_matrix(amg_hier *h, int lvl, int which, int fmt, int nrows, int
             if (last) AMG_HIP(hipMemcpy(hj.data(), Aj, sizeof(int) * hj.size(), hipMemcpyDeviceToHost));
             CHK(try_patterns(M, hp.data(), hj.data(), &h->dev_bytes));
             CHK(build_index16(M, hp.data(), &h->dev_bytes));
+            if (M.st_vals && g_value_index_auto && value_index_build(h, M) < 0) return AMG_ESTATE;
         }
     } else if (fmt == AMG_FMT_CSR || (R == 1 && C == 1)) {
         CHK(upload_csr(M, nrows, ncols, Ap, Aj, Ax, &h->dev_bytes));
         if (which == AMG_MAT_A) CHK(try_patterns(M, Ap, Aj, &h->dev_bytes));
         CHK(build_index16(M, Ap, &h->dev_bytes));
+        if (which == AMG_MAT_A && M.st_vals && g_value_index_auto && value_index_build(h, M) < 0) return AMG_ESTATE;
     } else if (which == AMG_MAT_A && R == C && bsr_spmv_enabled(R)) {
         // a level operator with square blocks that every application streams from the blocks themselves (8 B per
         // entry + 4 B per block): no scalar expansion -- at 3x3 blocks and 5*10^7 rows it would hold more than
@@ -2123,7 +2170,7 @@ long amg_hier_release_sources(amg_hier *h)
         const bool sm_jac = last ? true : (csr_free_smoother(L.sm[0], true) && csr_free_smoother(L.sm[1], true));
         DevCsr &A = L.A;
         if (A.Ap && !coarse_uses_A && !A.blk) {
-            const bool stencil_all = A.st_vals && A.st_nranges == 0 && !A.st_vi_on;
+            const bool stencil_all = A.st_vals && A.st_nranges == 0;
             const bool sliced_all = A.sl_val && A.sl_lo == 0 && A.sl_hi == A.nrows && l > 0;    // (level 0 needs the fused norm)
             if ((stencil_all && sm_jac) || (sliced_all && sm_poly)) freed += release_csr_arrays(A);
         }
@@ -2500,48 +2547,17 @@ static double cycle_bytes_impl(amg_hier *h, int cyc, bool moved)
     return total;
 }
 
-/* Value index of level lvl's operator (amg_dev.hpp, DevCsr::st_codes).  on != 0: build it if the operator is in
- * stencil form and holds at most 255 distinct values, and use it; returns the number of distinct values, 0
- * when not applicable.  on == 0: back to the 8-byte values. */
+/* on > 0: build (if need be) and use level lvl's value index, returns the number of distinct values (0: not applicable);
+ * on == 0: back to the 8-byte values; on < 0: query -- the number of distinct values when the index is in use, else 0. */
 int amg_hier_value_index(amg_hier *h, int lvl, int on)
 {
     ENTER(h);
     if (lvl < 0 || lvl >= h->nlevels) { set_error("bad level"); return AMG_EINVAL; }
     DevCsr &M = h->lv[lvl].A;
+    if (on < 0) return (M.st_vi_on && M.st_codes) ? M.st_ndict : 0;
     drop_graphs(h);
     if (!on) { M.st_vi_on = false; return 0; }
-    if (!M.st_vals) return 0;
-    if (M.st_codes) { M.st_vi_on = true; return M.st_ndict; }
-    const long count = (long)((M.nrows + 255) / 256) * M.st_nu * 256;
-    unsigned long long *table = nullptr;
-    int *ovf = nullptr;
-    if (dev_alloc(&table, 1024, nullptr) != 0 || dev_alloc(&ovf, 1, nullptr) != 0) return AMG_ENOMEM;
-    AMG_HIP(hipMemset(table, 0xFF, sizeof(unsigned long long) * 1024));
-    AMG_HIP(hipDeviceSynchronize());
-    int rc = launch_value_scan(M.st_vals, count, table, ovf, h->stream);
-    std::vector<unsigned long long> tb(1024);
-    int overflow = 0;
-    AMG_HIP(hipStreamSynchronize(h->stream));
-    AMG_HIP(hipMemcpy(tb.data(), table, sizeof(unsigned long long) * 1024, hipMemcpyDeviceToHost));
-    AMG_HIP(hipMemcpy(&overflow, ovf, sizeof(int), hipMemcpyDeviceToHost));
-    hipFree(table); hipFree(ovf);
-    if (rc != 0) return AMG_ESTATE;
-    std::vector<long long> bits;
-    for (unsigned long long v : tb) if (v != ~0ULL) bits.push_back((long long)v);
-    if (overflow || bits.empty() || bits.size() > 255) return 0;          // not a few-valued operator
-    std::sort(bits.begin(), bits.end());
-    std::vector<double> dict(256, 0.0);
-    for (size_t k = 0; k < bits.size(); ++k) std::memcpy(&dict[k], &bits[k], sizeof(double));
-    if (dev_alloc(&M.st_dict, 256, &h->dev_bytes) != 0) return AMG_ENOMEM;
-    AMG_HIP(hipMemcpy(M.st_dict, dict.data(), sizeof(double) * 256, hipMemcpyHostToDevice));
-    const long code_bytes = (long)((M.nrows + 255) / 256) * ((M.st_nu + 7) / 8) * 256 * 8;
-    if (dev_alloc(&M.st_codes, code_bytes, &h->dev_bytes) != 0) return AMG_ENOMEM;
-    M.st_ndict = (int)bits.size();
-    rc = launch_value_encode(M.st_vals, count, M.st_dict, M.st_ndict, M.st_codes, M.st_nu, h->stream);
-    AMG_HIP(hipStreamSynchronize(h->stream));
-    if (rc != 0) return AMG_ESTATE;
-    M.st_vi_on = true;
-    return M.st_ndict;
+    return value_index_build(h, M);
 }
 
 int amg_hier_operator_form(amg_hier *h, int lvl)

@@ -409,8 +409,11 @@ def test_plane_periodic_xcd_mapping_is_only_a_schedule():
     rng = np.random.RandomState(5)
     b = rng.rand(A.shape[0])
     got = {}
-    for stencil in (1, 0):                      # stencil form / offset-pattern form of level 0
-        _lib.lib().amg_set_stencil_form(stencil)
+    dev = ml.device_hierarchy()
+    assert _lib.lib().amg_hier_value_index(dev.h, 0, -1) == 3      # constant coefficients: coded values by default (r3)
+    for stencil in (1, 2, 0):                   # stencil form with coded values / with 8-byte values / offset-pattern form
+        _lib.lib().amg_set_stencil_form(1 if stencil else 0)
+        _lib.lib().amg_hier_value_index(dev.h, 0, 1 if stencil == 1 else 0)
         for period in (1, 0):
             _lib.lib().amg_set_xcd_period(period)
             res = []
@@ -455,13 +458,15 @@ def test_stencil_form_with_rows_left_to_the_pattern_kernel():
     rng = np.random.RandomState(11)
     b = rng.rand(A.shape[0])
     got = {}
-    for stencil in (1, 0):
-        _lib.lib().amg_set_stencil_form(stencil)
+    for stencil in (1, 2, 0):                   # coded values (if the operator has few) / 8-byte values / pattern form
+        _lib.lib().amg_set_stencil_form(1 if stencil else 0)
+        _lib.lib().amg_hier_value_index(dev.h, 0, 1 if stencil == 1 else 0)
         res = []
         x = ml.solve(b, tol=0.0, maxiter=4, residuals=res)
         got[stencil] = (x, np.array(res))
     _lib.lib().amg_set_stencil_form(1)
-    assert np.array_equal(got[0][0], got[1][0])
+    assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[2][0], got[1][0])
+    assert np.array_equal(got[2][1], got[1][1])
     assert np.allclose(got[0][1], got[1][1], rtol=1e-14)          # norms: partial sums grouped differently
     levels = []
     for lvl in ml.levels:
@@ -922,42 +927,57 @@ def test_bsr_native_operator_application():
         assert np.array_equal(got[0][0], got[2][0]) and np.allclose(got[0][1], got[2][1], rtol=1e-13), case
 
 
-def test_value_index_is_lossless_and_opt_in():
-    """amg_hier_value_index: a constant-coefficient stencil operator (2 distinct values + the padding zero)
-    gets one-byte codes into a dictionary; solves are bit-identical with it on and off; an operator with
-    variable coefficients is refused (returns 0) and keeps its values; nothing is indexed by default."""
+def test_value_index_is_lossless_and_automatic():
+    """Value index (amg_hier_value_index): a constant-coefficient stencil operator (2 distinct values + the padding zero)
+    gets one-byte codes into a dictionary when it is set (r3: automatic; r1-r2: opt-in); solves are bit-identical with it
+    on and off; an operator with variable coefficients keeps its values (the scan finds more than 255); with
+    amg_set_value_index(0) nothing is indexed."""
     import scipy.sparse as sp
     from pyamg_amd import _lib
     from pyamg_amd.aggregation import poisson as native, smoothed_aggregation_solver
     L = _lib.lib()
+    assert L.amg_value_index_enabled() == 1
     A = native((40, 41, 42))
     np.random.seed(0)
     sm = ("chebyshev", {"degree": 2})
     ml = smoothed_aggregation_solver(A, presmoother=sm, postsmoother=sm)
     dev = ml.device_hierarchy()
+    assert L.amg_hier_value_index(dev.h, 0, -1) == 3          # 6.0, -1.0 and the 0.0 of the padded slots
+    assert L.amg_hier_value_index(dev.h, 1, -1) == 0          # level 1 is not in stencil form
     rng = np.random.RandomState(9)
     b = rng.rand(A.shape[0])
-    res0 = []
-    x0 = ml.solve(b, tol=0.0, maxiter=4, residuals=res0)
-    moved_plain = dev.cycle_bytes_moved("V")
-    nd = L.amg_hier_value_index(dev.h, 0, 1)
-    assert nd == 3                                            # 6.0, -1.0 and the 0.0 of the padded slots
-    assert dev.cycle_bytes_moved("V") < moved_plain
-    assert np.array_equal(dev.matvec(0, 0, b), A * b)
     res1 = []
     x1 = ml.solve(b, tol=0.0, maxiter=4, residuals=res1)
-    assert np.array_equal(x0, x1) and np.array_equal(res0, res1)
+    assert np.array_equal(dev.matvec(0, 0, b), A * b)
+    moved_coded = dev.cycle_bytes_moved("V")
     assert L.amg_hier_value_index(dev.h, 0, 0) == 0
-    assert dev.cycle_bytes_moved("V") == moved_plain
-    assert L.amg_hier_value_index(dev.h, 1, 1) == 0           # level 1 is not in stencil form
+    assert L.amg_hier_value_index(dev.h, 0, -1) == 0
+    assert dev.cycle_bytes_moved("V") > moved_coded
+    assert np.array_equal(dev.matvec(0, 0, b), A * b)
+    res0 = []
+    x0 = ml.solve(b, tol=0.0, maxiter=4, residuals=res0)
+    assert np.array_equal(x0, x1) and np.array_equal(res0, res1)
+    assert L.amg_hier_value_index(dev.h, 0, 1) == 3
+    assert dev.cycle_bytes_moved("V") == moved_coded
+    assert L.amg_hier_value_index(dev.h, 1, 1) == 0
     # variable coefficients: far more than 255 distinct values
     W = sp.csr_matrix((rng.rand(A.nnz) + 1.0, A.indices, A.indptr), shape=A.shape)
     W = sp.csr_matrix(W + W.T); W.sort_indices()
     from pyamg_amd.util import _DeviceOperator
     op = _DeviceOperator(W)
     _lib.check(L.amg_hier_finalize(op.h))
-    assert L.amg_hier_operator_form(op.h, 0) == 2 and L.amg_hier_value_index(op.h, 0, 1) == 0
+    assert L.amg_hier_operator_form(op.h, 0) == 2 and L.amg_hier_value_index(op.h, 0, -1) == 0
+    assert L.amg_hier_value_index(op.h, 0, 1) == 0
     op.close()
+    # switched off for the process: operators set afterwards keep their values
+    L.amg_set_value_index(0)
+    try:
+        op = _DeviceOperator(A)
+        _lib.check(L.amg_hier_finalize(op.h))
+        assert L.amg_hier_operator_form(op.h, 0) == 2 and L.amg_hier_value_index(op.h, 0, -1) == 0
+        op.close()
+    finally:
+        L.amg_set_value_index(1)
 
 
 # ---------------------------------------------------------------------------
@@ -1803,6 +1823,7 @@ def test_stencil_two_rows_per_lane_same_bits():
     from pyamg_amd import _lib
     from pyamg_amd.aggregation import poisson as native, smoothed_aggregation_solver
     L = _lib.lib()
+    L.amg_set_value_index(0)            # the coded-value kernels keep one row per lane: compare the 8-byte-value kernels
     cheb = ("chebyshev", {"degree": 3})
     jac = ("jacobi", {"omega": 4.0 / 3.0, "iterations": 2})
     builds = [lambda: smoothed_aggregation_solver(native((33, 31, 29)), presmoother=cheb, postsmoother=cheb),
@@ -1823,6 +1844,7 @@ def test_stencil_two_rows_per_lane_same_bits():
             assert np.array_equal(out[0][1], out[2][1])
     finally:
         L.amg_set_stencil_pairs(1)
+        L.amg_set_value_index(1)
 
 
 @pytest.mark.gpu
