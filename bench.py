@@ -419,7 +419,7 @@ def config_main(args, rank, local_rank, world, torch, dist, L):
         kind, sweeps = "block_gs", 2
         what = ("anisotropic diffusion, P1 on a jittered Kuhn tetrahedral mesh, %d^3 = %.1fM unknowns, BSR 3x3 (%.1fM blocks), "
                 "block smoothed aggregation, symmetric block Gauss-Seidel pre/post" % (g, A.shape[0] / 1e6, len(A.indices) / 1e6))
-        kname = "bgs_flow_kernel<3, 2> (level-0 symmetric block Gauss-Seidel application: 2 directional sweeps as one persistent dataflow launch)"
+        kname = "bgs_flow_kernel<3, 5, 3> (level-0 symmetric block Gauss-Seidel application: 2 directional sweeps as one persistent dataflow launch)"
     else:
         raise ValueError(cfg)
     t2 = time.time()

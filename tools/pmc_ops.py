@@ -14,11 +14,16 @@ def summary(fetch, write, ops, out):
     """per kernel: mean FETCH_SIZE / WRITE_SIZE of its dispatches -> traffic = (2 FETCH + WRITE) KB (gfx950: FETCH_SIZE
     counts 64-byte units as 32, MI355X_MICROARCH.md; checked against sumsq_stage1 which reads 8 n bytes)"""
     def per_kernel(path, counter):
-        acc = collections.defaultdict(list)
+        # mean over the dispatches of a kernel's LARGEST grid: the same instantiation also runs on coarser levels and in the setup
+        acc = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(path)):
             if r["Counter_Name"] == counter:
-                acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
-        return {k: sum(v) / len(v) for k, v in acc.items()}
+                acc[r["Kernel_Name"]][int(r["Grid_Size"])].append(float(r["Counter_Value"]))
+        out = {}
+        for k, by_grid in acc.items():
+            v = by_grid[max(by_grid)]
+            out[k] = sum(v) / len(v)
+        return out
     F, W = per_kernel(fetch, "FETCH_SIZE"), per_kernel(write, "WRITE_SIZE")
     info = json.loads([l for l in open(ops) if l.startswith("{")][-1])
     entries = {}
@@ -27,11 +32,13 @@ def summary(fetch, write, ops, out):
         if not kf or kf[0] not in W:
             continue
         f, w = F[kf[0]], W[kf[0]]
-        entries[key] = {"kernel_name": kf[0].split("(")[0].replace("void amg::", "").replace("(anonymous namespace)::", ""),
+        short = kf[0].replace("void ", "").replace("(anonymous namespace)::", "").replace("amg::", "").split("(")[0]
+        entries[key] = {"kernel_name": short,
                         "what": e["what"], "fetch_size_kb": round(f, 2), "write_size_kb": round(w, 2),
                         "traffic_bytes": round((2.0 * f + w) * 1024.0, 2), "bytes_of_the_form": e["moved_bytes"],
                         "algorithmic_bytes": e["algorithmic_bytes"], "ms_per_launch_when_collected": e["ms"]}
-    cal = [v for k, v in F.items() if "sumsq_stage1" in k]
+    # calibration: the norm's first stage always launches the same grid; its largest reading is the level-0 vector (8 n bytes)
+    cal = [max(float(r["Counter_Value"]) for r in csv.DictReader(open(fetch)) if r["Counter_Name"] == "FETCH_SIZE" and "sumsq_stage1" in r["Kernel_Name"])]
     s = {"grid": info["grid"], "fetch_correction": 2.0, "entries": entries,
          "note": "traffic = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 B per launch; FETCH_SIZE doubled per MI355X_MICROARCH.md (calibrated in the "
                  "same pass: sumsq_stage1 reads %d B and reports %.2f KB); the counter includes Infinity-Cache hits, so this bounds HBM "
