@@ -1564,6 +1564,128 @@ struct StencilArgs {
     int off[STENCIL_MAX];
 };
 
+// what a stencil application does with a row's sum (shared by the 8-byte-value and the coded-value kernels)
+template <int MODE>
+__device__ __forceinline__ void stencil_epilogue(const StreamArgs &a, const StencilArgs &E, int i, int blk, int t, bool covered,
+                                                  double acc, double diag, double bval, double pre2, double *red)
+{
+    if (MODE == SM_RESIDUAL_SUMSQ) {
+        double sq = 0.0;
+        if (covered) {
+            double rr = bval - acc;
+            sq = rr * rr;
+            if (a.out) store_out(&a.out[i], rr);
+        }
+        double tot = block_reduce_sum(sq, red);
+        if (t == 0) a.out2[blk - E.blk_lo] = tot;
+        return;
+    }
+    if (!covered) return;
+    if (MODE == SM_MATVEC) {
+        store_out(&a.out[i], acc);
+    } else if (MODE == SM_MATVEC_ACC) {
+        store_out(&a.out[i], pre2 + acc);
+    } else if (MODE == SM_RESIDUAL) {
+        store_out(&a.out[i], bval - acc);
+    } else if (MODE == SM_POLY_STEP) {
+        double cr = a.c0 * bval;
+        a.out[i] = cr + acc;
+    } else if (MODE == SM_POLY_LAST) {
+        double cr = a.c0 * bval;
+        double h = cr + acc;
+        store_out(&a.out[i], pre2 + h);
+    } else if (MODE == SM_JACOBI) {
+        double told = pre2;
+        if (diag != 0.0) {
+            double q = (bval - acc) / diag;
+            double t1 = (1.0 - a.c0) * told;
+            double t2 = a.c0 * q;
+            a.out[i] = t1 + t2;
+        } else {
+            a.out[i] = told;
+        }
+    } else if (MODE == SM_JACOBI_BSR1) {
+        double told = pre2;
+        if (diag != 0.0) {
+            double t1 = (1.0 - a.c0) * told;
+            double t2 = (a.c0 * acc) / diag;
+            a.out[i] = t1 + t2;
+        } else {
+            a.out[i] = told;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Coded values (value index), stencils of up to 7 offsets (uint8 row masks): the level-0 kernel of every constant-coefficient configuration.
+// Same rows, same arithmetic as stencil_kernel<MODE, 8> with E.codes set, written as straight-line code: every request is
+// unconditional (a lane outside the row range works on the range's first row and stores nothing; an offset that leaves the
+// operand vector is clamped -- its mask bit is clear, the value is not used), the dictionary is requested first and written
+// to LDS after all other requests, so no wave waits for it alone, and absent slots are skipped by selects instead of branches.
+// ---------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(WG) void stencil_coded_kernel(StreamArgs a, StencilArgs E, int xcd_chunk)
+{
+    using MT = ModeTraits<MODE>;
+    __shared__ double red[8];
+    __shared__ double sdict[256];
+    const int t = threadIdx.x;
+    int blk;
+    if (E.period_blocks > 0) {
+        const int k = blockIdx.x & 7, s = blockIdx.x >> 3;
+        const int p = s / E.seg_blocks, j = s - p * E.seg_blocks;
+        const int q = k * E.seg_blocks + j;
+        blk = p * E.period_blocks + q;
+        if (q >= E.period_blocks || blk >= E.nblocks) return;
+    } else {
+        blk = remap_block(blockIdx.x, gridDim.x, xcd_chunk);
+    }
+    blk += E.blk_lo;
+    const int i = blk * WG + t;
+    const bool live = (i >= a.row_lo && i < a.row_hi);
+    double dv = 0.0;
+    if (t < E.ndict) dv = E.dict[t];
+    // lanes outside the range read what the nearest live lane of this block reads
+    const int ic = min(max(i, a.row_lo), a.row_hi - 1);
+    const int tc = ic - blk * WG;
+    const unsigned long long cw = stream_load(reinterpret_cast<const unsigned long long *>(E.codes) + (size_t)blk * WG + tc);
+    const int last = E.ncols - 1;
+    double xv[7];
+#pragma unroll
+    for (int u = 0; u < 7; ++u) xv[u] = a.xg[min(max(ic + E.off[u], 0), last)];   // (slots >= nu: offset 0, mask bit clear)
+    unsigned m = (unsigned)stream_load(static_cast<const unsigned char *>(E.mask) + ic);
+    double bval = 0.0, pre2 = 0.0;
+    if (MT::sub || MODE == SM_RESIDUAL || MODE == SM_RESIDUAL_SUMSQ || MODE == SM_POLY_STEP || MODE == SM_POLY_LAST || MODE == SM_JACOBI)
+        bval = stream_load(&a.b[ic]);
+    if (MODE == SM_MATVEC_ACC) pre2 = a.out[ic];
+    else if (MODE == SM_POLY_LAST || MODE == SM_JACOBI || MODE == SM_JACOBI_BSR1) pre2 = a.v2[ic];
+    if (t < E.ndict) sdict[t] = dv;
+    const bool covered = live && !(m & 0x80u);                    // top bit: the row is applied by the pattern kernel
+    if (!covered) m = 0;
+    __syncthreads();                                              // dictionary in LDS
+    double v[7];
+#pragma unroll
+    for (int u = 0; u < 7; ++u) v[u] = sdict[(unsigned)(cw >> (8 * u)) & 0xFFu];
+    const double gscale = a.gscale;
+    double acc = MT::sub ? bval : 0.0, diag = 0.0;
+#pragma unroll
+    for (int u = 0; u < 7; ++u) {
+        const bool on = ((m >> u) & 1u) != 0;                     // (bits >= nu are clear)
+        if (MT::jac) {
+            const bool isd = u == E.u0;
+            diag = (on && isd) ? v[u] : diag;
+            const double pr = v[u] * (gscale * xv[u]);
+            const double nx = MT::sub ? (acc - pr) : (acc + pr);
+            acc = (on && !isd) ? nx : acc;
+        } else {
+            const double pr = v[u] * (gscale * xv[u]);
+            const double nx = MT::sub ? (acc - pr) : (acc + pr);
+            acc = on ? nx : acc;
+        }
+    }
+    stencil_epilogue<MODE>(a, E, i, blk, t, covered, acc, diag, bval, pre2, red);
+}
+
 template <int MODE, int NUB>
 __global__ __launch_bounds__(WG) void stencil_kernel(StreamArgs a, StencilArgs E, int xcd_chunk)
 {
@@ -1635,51 +1757,7 @@ __global__ __launch_bounds__(WG) void stencil_kernel(StreamArgs a, StencilArgs E
         }
     }
 
-    if (MODE == SM_RESIDUAL_SUMSQ) {
-        double sq = 0.0;
-        if (covered) {
-            double rr = bval - acc;
-            sq = rr * rr;
-            if (a.out) store_out(&a.out[i], rr);
-        }
-        double tot = block_reduce_sum(sq, red);
-        if (t == 0) a.out2[blk - E.blk_lo] = tot;
-        return;
-    }
-    if (!covered) return;
-    if (MODE == SM_MATVEC) {
-        store_out(&a.out[i], acc);
-    } else if (MODE == SM_MATVEC_ACC) {
-        store_out(&a.out[i], pre2 + acc);
-    } else if (MODE == SM_RESIDUAL) {
-        store_out(&a.out[i], bval - acc);
-    } else if (MODE == SM_POLY_STEP) {
-        double cr = a.c0 * bval;
-        a.out[i] = cr + acc;
-    } else if (MODE == SM_POLY_LAST) {
-        double cr = a.c0 * bval;
-        double h = cr + acc;
-        store_out(&a.out[i], pre2 + h);
-    } else if (MODE == SM_JACOBI) {
-        double told = pre2;
-        if (diag != 0.0) {
-            double q = (bval - acc) / diag;
-            double t1 = (1.0 - a.c0) * told;
-            double t2 = a.c0 * q;
-            a.out[i] = t1 + t2;
-        } else {
-            a.out[i] = told;
-        }
-    } else if (MODE == SM_JACOBI_BSR1) {
-        double told = pre2;
-        if (diag != 0.0) {
-            double t1 = (1.0 - a.c0) * told;
-            double t2 = (a.c0 * acc) / diag;
-            a.out[i] = t1 + t2;
-        } else {
-            a.out[i] = told;
-        }
-    }
+    stencil_epilogue<MODE>(a, E, i, blk, t, covered, acc, diag, bval, pre2, red);
 }
 
 // ---------------------------------------------------------------------------
@@ -1852,6 +1930,7 @@ __global__ __launch_bounds__(WG2) void stencil2_kernel(StreamArgs a, StencilArgs
     (void)both;
 }
 
+static int g_stencil_coded = std::getenv("AMG_STENCIL_CODED") ? std::atoi(std::getenv("AMG_STENCIL_CODED")) : 1;   // 0: coded values through the generic kernel (A/B)
 static int g_stencil_pairs = 1;     // 1: two rows per lane (stencil2_kernel), 0: one row per lane
 void set_stencil_pairs(int on) { g_stencil_pairs = on; ++g_config_epoch; }
 
@@ -2010,6 +2089,8 @@ static int launch_stencil_mode(const StreamArgs &a, const DevCsr &M, hipStream_t
         hipLaunchKernelGGL((stencil2_kernel<MODE, 8>), dim3(grid), dim3(WG2), 0, st, b, E, g_xcd_chunk);
     else if (pairs)
         hipLaunchKernelGGL((stencil2_kernel<MODE, 16>), dim3(grid), dim3(WG2), 0, st, b, E, g_xcd_chunk);
+    else if (E.codes != nullptr && M.st_nu <= 7 && g_stencil_coded)
+        hipLaunchKernelGGL((stencil_coded_kernel<MODE>), dim3(grid), dim3(WG), 0, st, b, E, g_xcd_chunk);
     else if (M.st_nu <= 7)
         hipLaunchKernelGGL((stencil_kernel<MODE, 8>), dim3(grid), dim3(WG), 0, st, b, E, g_xcd_chunk);
     else if (M.st_nu <= 16)
