@@ -252,6 +252,13 @@ int amg_hier_operator_form(amg_hier *h, int lvl);
 int amg_hier_value_index(amg_hier *h, int lvl, int on);
 void amg_set_value_index(int on);       /* process-wide default for operators set afterwards */
 int amg_value_index_enabled(void);
+/* Setup-side (replaces the host sweeps behind pyamg/aggregation/aggregation.py:313-320 `relaxation_as_linear_operator(
+ * ('gauss_seidel', ...), A, 0) * B`, i.e. amg_core gauss_seidel of relaxation.h:34-62 on A x = 0): nsweeps Gauss-Seidel
+ * sweeps over level lvl's operator in its own row order, from the CSR arrays in HBM; dirs[k] != 0 = descending rows;
+ * b == NULL means a zero right-hand side; x (host) is updated in place; bit-identical to the sequential loop.
+ * AMG_ENOTIMPL: a row of more than 8 entries, or the CSR arrays are not on the device -- keep the host sweep. */
+int amg_hier_gs_natural(amg_hier *h, int lvl, double *x, const double *b, const unsigned char *dirs, int nsweeps);
+
 /* bytes of one r = b - A x on level lvl: moved = 0 the CSR figure of SURVEY.md 8(d), 1 what the form in use streams */
 double amg_hier_operator_bytes(amg_hier *h, int lvl, int moved);
 /* bytes one solve() iteration needs as this library runs it: offset-pattern operators without

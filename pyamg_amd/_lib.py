@@ -159,6 +159,8 @@ def lib():
     L.amg_set_value_index.restype = None
     L.amg_value_index_enabled.argtypes = []
     L.amg_value_index_enabled.restype = I
+    L.amg_hier_gs_natural.argtypes = [V, I, V, V, V, I]
+    L.amg_hier_gs_natural.restype = I
     L.amg_hier_operator_form.argtypes = [V, I]
     L.amg_hier_operator_form.restype = I
     L.amg_hier_operator_bytes.argtypes = [V, I, I]

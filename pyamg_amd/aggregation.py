@@ -434,6 +434,33 @@ def _improve(method, A, B):
         out[:, j] = x
         return ran
 
+    if desc["name"] == "gauss_seidel" and sweep_code is not None and use_device_for(A) \
+            and os.environ.get("AMG_SETUP_DEVICE_GS", "1") != "0":
+        # r3: the sweeps on the GPU, in the operator's own row order from its CSR arrays (csrc/gsflow.hip: gs_natural_kernel;
+        # the operator is in HBM for the spectral-radius estimate anyway) -- the sequential result bit for bit.  Operators
+        # with rows of more than 8 entries (coarse levels) keep the host sweeps below.
+        from . import _lib
+        from .util import device_operator
+        dirs = bytes(({0: [0], 1: [1], 2: [0, 1]}[sweep_code]) * its)
+        op = device_operator(A)
+        cols = []
+        for j in range(B.shape[1]):
+            x = np.array(B[:, j], dtype=np.float64, order="C")
+            rc = _lib.lib().amg_hier_gs_natural(op.h, 0, x.ctypes.data, None, dirs, len(dirs))
+            if rc != 0:
+                cols = None
+                if rc != _lib.AMG_ENOTIMPL:
+                    # e.g. the persistent kernel gave up waiting because another process holds part of the GPU: the host
+                    # sweeps below produce the same numbers (x is only written on success)
+                    import warnings
+                    warnings.warn("candidate improvement on the GPU failed (%s); using the host sweeps"
+                                  % _lib.lib().amg_last_error().decode(), RuntimeWarning)
+                break
+            cols.append(x)
+        if cols is not None:
+            for j, x in enumerate(cols):
+                out[:, j] = x
+            return out
     if n > 100000 and os.environ.get("AMG_SETUP_PIPELINED_GS", "1") != "0":
         # first column through the pipelined sweep; if the operator qualifies, so do the others
         if relax_column(0, True):

@@ -30,6 +30,7 @@ struct DevCsr {
     int *Aj = nullptr;
     double *Ax = nullptr;
     bool owned = true;
+    int longest_row = -1;          // entries of the longest row, found on first need (amg_hier_gs_natural)
     // The operator's own square blocks (a BSR level of the hierarchy), not owned: when set, applications
     // stream 8 B per entry + 4 B per block from there instead of 12 B per entry from the expanded CSR
     const DevBsr *blk = nullptr;
@@ -345,6 +346,10 @@ struct BlockFlowForm {
 int build_block_flow_form(BlockFlowForm &F, int nb, int bs, int ntasks, const std::vector<int> &level_ptr, const std::vector<int> &rows,
                           const std::vector<int> &gp, const std::vector<int> &gj, const std::vector<double> &gx);
 int block_flow_sweep(const BlockFlowForm &F, const double *Dinv, double *x, const double *b, const unsigned char *seq, int nseq, hipStream_t st);
+// Gauss-Seidel sweeps in the operator's own row order from its CSR arrays (gsflow.hip: gs_natural_kernel); -40: a row is too long
+int gs_natural_sweeps(const int *Ap, const int *Aj, const double *Ax, int n, int longest_row, double *x, const double *b,
+                      const unsigned char *dirs, int nsweeps, hipStream_t st, const int *order_fwd = nullptr, const int *order_bwd = nullptr,
+                      const int *tstart_fwd = nullptr, const int *tstart_bwd = nullptr, int ntasks_fwd = 0, int ntasks_bwd = 0);
 int gs_flow_mode();                     // 0 off, 1 where it measured faster (default), 2 wherever the form exists
 void set_gs_flow(int mode);
 void set_gs_flow_lookahead(int levels);

@@ -34,6 +34,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
 #include <memory>
 #include <thread>
@@ -577,6 +578,126 @@ __global__ __launch_bounds__(64) void bgs_flow_kernel(const FlowChunk *__restric
     }
 }
 
+// ---------------------------------------------------------------------------
+// Gauss-Seidel in the operator's OWN row order, straight from its CSR arrays: no level-ordered copy, no host-built
+// schedule -- for the setup's candidate improvement (aggregation.py:313-320: a few sweeps of A x = 0 over an operator that
+// is in HBM anyway for the spectral-radius estimate), where building a dataflow form would cost more than the sweeps.
+// A task is 64 consecutive rows of the sweep order, one per lane; tasks go to the resident one-wave workgroups in a given
+// order in which every task comes after all tasks it depends on (ascending if none is given), so the first unfinished
+// task of that order never waits for a wave that is not running.  (In ASCENDING order a lexicographic 3-D grid offers
+// only a handful of independent tasks among the few thousand resident ones -- a grid line waits for the line before it
+// -- and 500^3 did not finish a sweep in 20 s; amg_hier_gs_natural therefore cuts the tasks of a stencil-form operator
+// where the chain of neighbouring rows breaks (grid-line starts) and orders them by their dependency level, computed from
+// the stencil's offsets and row masks at TASK granularity.)  A lane (i) gathers its row (at most NAT_SEG
+// entries, checked on the host): operands the sweep has not reached are read from x_old (final: the previous sweep was
+// another launch), operands of earlier TASKS are polled in x_new (sentinel-prefilled), (ii) once those are there, waits in
+// LDS for the operands produced by earlier lanes of its own wave, then forms the row sum over the stored entries in
+// stored order with separate multiply and add -- relaxation.h:34-62 bit for bit -- and publishes x_i to LDS and memory.
+// On a 7-point grid operator the in-wave chain (x_{i-1}) makes a task ~64 LDS hand-offs long; tasks of different grid lines
+// overlap, a sweep over 125 M rows is a few milliseconds of dependency depth plus the stream of the CSR arrays.
+// ---------------------------------------------------------------------------
+constexpr int NAT_SEG = 8;
+struct NatArgs {
+    const int *Ap, *Aj;
+    const double *Ax, *b, *xold;
+    unsigned long long *xnew;
+    const int *order;              // tasks in the order they are taken (null: ascending); every task after all it depends on
+    const int *tstart;             // task q = positions [tstart[q], tstart[q + 1]) of the sweep, at most 64 (null: 64 q ...)
+    int *status;
+    long long budget;
+    int n, ntasks, reverse;
+};
+
+__global__ __launch_bounds__(64) void gs_natural_kernel(NatArgs a)
+{
+    __shared__ unsigned long long sx[64];
+    const int lane = threadIdx.x, NW = (int)gridDim.x;
+    const long long t0 = wall_clock64();
+    for (int slot = blockIdx.x; slot < a.ntasks; slot += NW) {
+        const int q = a.order ? a.order[slot] : slot;
+        const int p0 = a.tstart ? a.tstart[q] : q * 64, p = p0 + lane;          // positions in sweep order
+        const bool have = a.tstart ? (p < a.tstart[q + 1]) : (p < a.n);
+        const int i = have ? (a.reverse ? a.n - 1 - p : p) : 0;
+        sx[lane] = FLOW_SENT;
+        int start = 0, len = 0;
+        if (have) { start = a.Ap[i]; len = a.Ap[i + 1] - start; }
+        double v[NAT_SEG];
+        unsigned long long xb[NAT_SEG];
+        int cj[NAT_SEG], kind[NAT_SEG];                              // 0 none, 1 diagonal, 2 value in xb, 3 earlier task (poll), 4 earlier lane (LDS slot in cj)
+#pragma unroll
+        for (int e = 0; e < NAT_SEG; ++e) {
+            v[e] = 0.0; xb[e] = 0ULL; cj[e] = 0; kind[e] = 0;
+            if (e < len) {
+                const int j = a.Aj[start + e];
+                v[e] = a.Ax[start + e];
+                cj[e] = j;
+                if (j == i) kind[e] = 1;
+                else {
+                    const bool fresh = a.reverse ? (j > i) : (j < i);
+                    if (!fresh) { kind[e] = 2; xb[e] = (unsigned long long)__double_as_longlong(a.xold[j]); }
+                    else {
+                        const int pj = a.reverse ? a.n - 1 - j : j;
+                        if (pj >= p0) { kind[e] = 4; cj[e] = pj - p0; }
+                        else { kind[e] = 3; xb[e] = ald(a.xnew + j); }
+                    }
+                }
+            }
+        }
+        for (unsigned spin = 0;; ++spin) {                           // operands of earlier tasks
+            bool bad = false;
+#pragma unroll
+            for (int e = 0; e < NAT_SEG; ++e) bad |= (kind[e] == 3 && xb[e] == FLOW_SENT);
+            if (!__any(bad)) break;
+            __builtin_amdgcn_s_sleep(1);
+            if ((spin & 31u) == 31u && wall_clock64() - t0 > a.budget) {
+                if (lane == 0) __hip_atomic_store(a.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+#pragma unroll
+            for (int e = 0; e < NAT_SEG; ++e)
+                if (kind[e] == 3 && xb[e] == FLOW_SENT) xb[e] = ald(a.xnew + cj[e]);
+        }
+        const double bi = (have && a.b) ? a.b[i] : 0.0;
+        const double xo = have ? a.xold[i] : 0.0;
+        flow_wave_sync();                                            // every lane's slot holds the sentinel
+        bool done = !have;
+        unsigned long long res = 0ULL;
+        for (unsigned round = 0; round < 66u; ++round) {             // lane l's operands come from lanes < l: at most 64 rounds
+            if (!done) {
+                bool ready = true;
+#pragma unroll
+                for (int e = 0; e < NAT_SEG; ++e)
+                    if (kind[e] == 4) { xb[e] = sx[cj[e]]; ready = ready && (xb[e] != FLOW_SENT); }
+                if (ready) {
+                    double rsum = 0.0, diag = 0.0;
+#pragma unroll
+                    for (int e = 0; e < NAT_SEG; ++e) {
+                        if (kind[e] == 1) diag = v[e];
+                        else if (kind[e] != 0) rsum = rsum + v[e] * __longlong_as_double((long long)xb[e]);
+                    }
+                    double xi = xo;
+                    if (diag != 0.0) xi = (bi - rsum) / diag;
+                    unsigned long long u = (unsigned long long)__double_as_longlong(xi);
+                    if (u == FLOW_SENT) u |= FLOW_QUIET;
+                    res = u;
+                    sx[lane] = u;                                    // (to memory after the chain: a store per round would put
+                    done = true;                                     //  a memory round trip into every hand-off -- 0.64 s per sweep at 500^3)
+                }
+            }
+            flow_wave_sync();
+            if (!__any(!done)) break;
+        }
+        if (have) __hip_atomic_store(a.xnew + i, res, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        flow_wave_sync();                                            // all reads of sx done before the next task resets it
+    }
+}
+
+__global__ __launch_bounds__(256) void nat_fill_kernel(unsigned long long *p, long n)
+{
+    const long k = (long)blockIdx.x * 256 + threadIdx.x;
+    if (k < n) p[k] = FLOW_SENT;
+}
+
 int g_flow_mode = std::getenv("AMG_GS_FLOW") ? std::atoi(std::getenv("AMG_GS_FLOW")) : 1;   // A/B runs of tools without a knob of their own
 int g_flow_la = 0;              // look-ahead in levels; 0: default
 int *g_status = nullptr;        // device word, one per process and device (first use)
@@ -852,6 +973,54 @@ int block_flow_sweep(const BlockFlowForm &F, const double *Dinv, double *x, cons
 
 namespace {
 }  // namespace
+
+// nsweeps directional sweeps (dirs[k] != 0: descending rows) of A x = b (b may be null: zero) on device arrays; x is
+// updated in place.  Returns -40 when a row holds more than NAT_SEG entries (the caller falls back).
+int gs_natural_sweeps(const int *Ap, const int *Aj, const double *Ax, int n, int longest_row, double *x, const double *b,
+                      const unsigned char *dirs, int nsweeps, hipStream_t st, const int *order_fwd, const int *order_bwd,
+                      const int *tstart_fwd, const int *tstart_bwd, int ntasks_fwd, int ntasks_bwd)
+{
+    if (longest_row > NAT_SEG) return -40;
+    if (n <= 0 || nsweeps <= 0) return 0;
+    int *status = nullptr;
+    FCHK(flow_status_word(&status));
+    static int cap = 0;
+    if (cap == 0) {
+        int nb = 0, dev = 0, ncu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gs_natural_kernel, 64, 0) != hipSuccess || nb < 1) nb = 1;
+        hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount;
+        if (ncu < 1) ncu = 64;
+        cap = std::max(16, ncu * std::min(nb, 24) * 3 / 4);
+        if (std::getenv("AMG_NAT_WAVES") && std::atoi(std::getenv("AMG_NAT_WAVES")) > 0) cap = std::atoi(std::getenv("AMG_NAT_WAVES"));
+        if (std::getenv("AMG_SETUP_VERBOSE") && std::atoi(std::getenv("AMG_SETUP_VERBOSE")))
+            std::fprintf(stderr, "[setup]     natural-order Gauss-Seidel: %d one-wave workgroups (occupancy query %d per CU, %d CUs)\n", cap, nb, ncu);
+    }
+    double *tmp = nullptr;
+    hipError_t e = hipMalloc((void **)&tmp, sizeof(double) * (size_t)n);
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc (natural-order Gauss-Seidel buffer)", __FILE__, __LINE__);
+    double *cur = x, *nxt = tmp;
+    const int ntasks = (n + 63) / 64;
+    for (int k = 0; k < nsweeps; ++k) {
+        hipLaunchKernelGGL(nat_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (unsigned long long *)nxt, (long)n);
+        NatArgs a;
+        a.Ap = Ap; a.Aj = Aj; a.Ax = Ax; a.b = b; a.xold = cur; a.xnew = (unsigned long long *)nxt;
+        a.status = status; a.budget = 100000000LL * 20; a.n = n; a.reverse = dirs[k] != 0 ? 1 : 0;
+        a.order = a.reverse ? order_bwd : order_fwd;
+        a.tstart = a.reverse ? tstart_bwd : tstart_fwd;
+        a.ntasks = a.tstart ? (a.reverse ? ntasks_bwd : ntasks_fwd) : ntasks;
+        hipLaunchKernelGGL(gs_natural_kernel, dim3((unsigned)std::min(cap, a.ntasks)), dim3(64), 0, st, a);
+        e = hipGetLastError();
+        if (e != hipSuccess) { hipFree(tmp); return hip_fail(e, "natural-order Gauss-Seidel launch", __FILE__, __LINE__); }
+        std::swap(cur, nxt);
+    }
+    if (cur != x) e = hipMemcpyAsync(x, cur, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st);
+    hipError_t e2 = hipStreamSynchronize(st);
+    hipFree(tmp);
+    if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync", __FILE__, __LINE__);
+    if (e2 != hipSuccess) return hip_fail(e2, "hipStreamSynchronize", __FILE__, __LINE__);
+    return 0;
+}
 
 void FlowForm::release()
 {

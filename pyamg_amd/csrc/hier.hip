@@ -2613,6 +2613,142 @@ int amg_hier_time_spmv(amg_hier *h, int lvl, int which, int mode, int reps, doub
     return 0;
 }
 
+/* Setup-side: `nsweeps` Gauss-Seidel sweeps of A x = b (b == NULL: zero right-hand side) over level lvl's operator in ITS OWN
+ * row order, from the CSR arrays in HBM (gsflow.hip: gs_natural_kernel) -- relaxation.h:34-62 bit for bit; what the
+ * candidate improvement of aggregation.py:313-320 runs.  dirs[k] != 0: descending rows.  x (host, n doubles) is updated in
+ * place.  AMG_ENOTIMPL when the operator has a row of more than 8 entries or no CSR arrays on the device (the caller keeps
+ * its host sweep). */
+int amg_hier_gs_natural(amg_hier *h, int lvl, double *x, const double *b, const unsigned char *dirs, int nsweeps)
+{
+    ENTER(h);
+    if (lvl < 0 || lvl >= h->nlevels || !x || !dirs || nsweeps < 0) { set_error("bad natural-order Gauss-Seidel arguments"); return AMG_EINVAL; }
+    DevCsr &M = h->lv[lvl].A;
+    if (!M.Ap || !M.Aj || !M.Ax || M.nrows != M.ncols) { set_error("natural-order Gauss-Seidel: no square CSR operator on the device"); return AMG_ENOTIMPL; }
+    const int n = M.nrows;
+    if (M.longest_row < 0) {
+        std::vector<int> ap((size_t)n + 1);
+        AMG_HIP(hipMemcpy(ap.data(), M.Ap, sizeof(int) * ap.size(), hipMemcpyDeviceToHost));
+        int lr = 0;
+        for (int i = 0; i < n; ++i) lr = std::max(lr, ap[(size_t)i + 1] - ap[(size_t)i]);
+        M.longest_row = lr;
+    }
+    if (M.longest_row > 8) { set_error("natural-order Gauss-Seidel: rows of more than 8 entries"); return AMG_ENOTIMPL; }
+    // Tasks and their order.  An operator in stencil form (every row's columns are i + off[u], the row mask says which are
+    // stored): a task is a run of at most TASK_ROWS consecutive positions of the sweep, cut where a row does NOT take the value of
+    // its predecessor (offset -1 forward, +1 backward: a grid line starts there) -- so that the only chain between
+    // neighbouring tasks is the one inside a grid line.  The dependency level of a task then follows from the offsets:
+    // its rows minus a distance d >= 64 lie in a few earlier tasks (found with a pointer that only moves forward).  Tasks
+    // sorted by level (stable) = an order in which dependencies come first and the tasks of a level are independent.
+    // Without that structure only small operators are swept (ascending order offers too little to do, gsflow.hip).
+    const int ntasks64 = (n + 63) / 64;
+    // rows per task of a structured operator: a task is one chain of hand-offs (0.7 us each at 500^3), a sweep is
+    // (tasks per grid line + lines per plane + planes) of them; 32 rows leave about one task per resident wave and level
+    constexpr long TASK_ROWS = 32;
+    int *order_dev[2] = {nullptr, nullptr}, *tstart_dev[2] = {nullptr, nullptr};
+    int ntasks_dir[2] = {0, 0};
+    const bool structured = M.st_vals && M.st_nranges == 0 && M.st_nu <= 7;
+    if (!structured && ntasks64 > 4096) { set_error("natural-order Gauss-Seidel: large operator without stencil structure"); return AMG_ENOTIMPL; }
+    if (structured && ntasks64 > 64) {
+        std::vector<unsigned char> mk((size_t)n);
+        AMG_HIP(hipMemcpy(mk.data(), M.st_mask, (size_t)n, hipMemcpyDeviceToHost));
+        auto release = [&]() { for (int k = 0; k < 2; ++k) { if (order_dev[k]) hipFree(order_dev[k]); if (tstart_dev[k]) hipFree(tstart_dev[k]); order_dev[k] = tstart_dev[k] = nullptr; } };
+        for (int dir = 0; dir < 2; ++dir) {
+            bool wanted = false;
+            for (int k = 0; k < nsweeps; ++k) wanted |= ((dirs[k] != 0) == (dir == 1));
+            if (!wanted) continue;
+            int u_near = -1;                                       // the slot of offset -1 (forward) / +1 (backward)
+            std::vector<long> dist;                                // distances >= 2 to operands the sweep has already renewed
+            std::vector<int> dist_u;                               // ... and their slots
+            bool supported = true;
+            for (int u = 0; u < M.st_nu; ++u) {
+                const long o = M.st_off[u];
+                const long d = dir == 0 ? -o : o;
+                if (d <= 0) continue;
+                if (d == 1) u_near = u;
+                else {
+                    // a second short-range dependency (a grid whose lines are shorter than a task) chains neighbouring tasks
+                    // whatever the cuts: correct, but only small operators get through in reasonable time
+                    if (d < TASK_ROWS && ntasks64 > 4096) supported = false;
+                    dist.push_back(d);
+                    dist_u.push_back(u);
+                }
+            }
+            if (!supported) { release(); set_error("natural-order Gauss-Seidel: large stencil operator with several short-range offsets"); return AMG_ENOTIMPL; }
+            auto row_of = [&](long p) { return dir == 0 ? p : (long)n - 1 - p; };
+            std::vector<int> ts;
+            std::vector<unsigned char> any;                         // per task: the OR of its rows' masks (which offsets occur at all)
+            ts.reserve(2 * (size_t)ntasks64 + (size_t)ntasks64 / 4 + 2);
+            any.reserve(2 * (size_t)ntasks64 + (size_t)ntasks64 / 4 + 2);
+            for (long p = 0; p < n;) {
+                const long begin = p;
+                ts.push_back((int)begin);
+                unsigned char acc = mk[(size_t)row_of(p)];
+                ++p;
+                while (p < n && p - begin < TASK_ROWS) {
+                    const unsigned char m = mk[(size_t)row_of(p)];
+                    if (u_near >= 0 && !((m >> u_near) & 1u)) break;
+                    acc |= m;
+                    ++p;
+                }
+                any.push_back(acc);
+            }
+            const int nt = (int)ts.size();
+            ts.push_back(n);
+            std::vector<int> level((size_t)nt, 0);
+            std::vector<int> ptr(dist.size(), 0);
+            int top = 0;
+            for (int q = 0; q < nt; ++q) {
+                int lv = 0;
+                const long b0 = ts[(size_t)q], b1 = (long)ts[(size_t)q + 1] - 1;
+                if (q > 0 && u_near >= 0 && ((mk[(size_t)row_of(b0)] >> u_near) & 1u)) lv = level[(size_t)q - 1] + 1;
+                for (size_t k = 0; k < dist.size(); ++k) {
+                    // (a task whose rows do not store that offset -- the first line of a grid plane, the first plane -- does not
+                    //  depend on what lies that far back: assuming it did would chain the planes one after the other)
+                    if (!((any[(size_t)q] >> dist_u[k]) & 1u)) continue;
+                    const long lo = b0 - dist[k], hi = std::min(b1 - dist[k], b0 - 1);      // (positions >= b0 are lanes of this task)
+                    if (hi < 0) continue;
+                    int &t = ptr[k];
+                    const long lo0 = std::max(lo, 0L);
+                    while (ts[(size_t)t + 1] <= lo0) ++t;          // the task that holds position lo0
+                    for (int tt = t; tt < q && ts[(size_t)tt] <= hi; ++tt) lv = std::max(lv, level[(size_t)tt] + 1);
+                }
+                level[(size_t)q] = lv;
+                top = std::max(top, lv);
+            }
+            std::vector<int> first((size_t)top + 2, 0), order((size_t)nt);
+            for (int q = 0; q < nt; ++q) ++first[(size_t)level[(size_t)q] + 1];
+            for (int l = 0; l <= top; ++l) first[(size_t)l + 1] += first[(size_t)l];
+            for (int q = 0; q < nt; ++q) order[(size_t)first[(size_t)level[(size_t)q]]++] = q;
+            hipError_t eo = hipMalloc((void **)&order_dev[dir], sizeof(int) * (size_t)nt);
+            if (eo == hipSuccess) eo = hipMalloc((void **)&tstart_dev[dir], sizeof(int) * ((size_t)nt + 1));
+            if (eo == hipSuccess) eo = hipMemcpy(order_dev[dir], order.data(), sizeof(int) * (size_t)nt, hipMemcpyHostToDevice);
+            if (eo == hipSuccess) eo = hipMemcpy(tstart_dev[dir], ts.data(), sizeof(int) * ((size_t)nt + 1), hipMemcpyHostToDevice);
+            if (eo != hipSuccess) { release(); return hip_fail(eo, "natural-order Gauss-Seidel: task order to the device", __FILE__, __LINE__); }
+            ntasks_dir[dir] = nt;
+        }
+    }
+    double *dx = nullptr, *db = nullptr;
+    int rc = 0;
+    hipError_t e = hipMalloc((void **)&dx, sizeof(double) * (size_t)std::max(n, 1));
+    if (e == hipSuccess) e = hipMemcpy(dx, x, sizeof(double) * (size_t)n, hipMemcpyHostToDevice);
+    if (e == hipSuccess && b) {
+        e = hipMalloc((void **)&db, sizeof(double) * (size_t)std::max(n, 1));
+        if (e == hipSuccess) e = hipMemcpy(db, b, sizeof(double) * (size_t)n, hipMemcpyHostToDevice);
+    }
+    if (e != hipSuccess) rc = hip_fail(e, "natural-order Gauss-Seidel: vectors to the device", __FILE__, __LINE__);
+    if (rc == 0) rc = gs_natural_sweeps(M.Ap, M.Aj, M.Ax, n, M.longest_row, dx, db, dirs, nsweeps, h->stream, order_dev[0], order_dev[1],
+                                        tstart_dev[0], tstart_dev[1], ntasks_dir[0], ntasks_dir[1]);
+    if (rc == 0 && gs_flow_status() != 0) { set_error("natural-order Gauss-Seidel gave up waiting for an operand"); rc = AMG_ESTATE; }
+    if (rc == 0) {
+        e = hipMemcpy(x, dx, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = hip_fail(e, "natural-order Gauss-Seidel: result to the host", __FILE__, __LINE__);
+    }
+    if (dx) hipFree(dx);
+    if (db) hipFree(db);
+    for (int k = 0; k < 2; ++k) { if (order_dev[k]) hipFree(order_dev[k]); if (tstart_dev[k]) hipFree(tstart_dev[k]); }
+    return rc == -40 ? AMG_ENOTIMPL : rc;
+}
+
 // ---- setup-time helper: Arnoldi on a stored operator (pyamg/util/linalg.py:173-279) ----------
 // Krylov basis of M = diag(dinv) * A_lvl (dinv == NULL: M = A_lvl) from the start vector v0,
 // modified Gram-Schmidt exactly in the reference's order; H is (maxiter+1) x maxiter row-major on

@@ -1062,10 +1062,16 @@ def test_setup_time_device_copies_are_released(monkeypatch):
     """the HBM copies made for setup-time estimates (operator + Krylov basis) must be gone after
     setup -- HBM in use returns to the hierarchy's own footprint."""
     import torch
-    from pyamg_amd import util
+    from pyamg_amd import _lib, util
     monkeypatch.setattr(util, "DEVICE_RHO_MIN_ROWS", 1000)
     A = poisson((96, 96, 24))
     np.random.seed(0)
+    # (the runtime's own first-use allocations -- queue, code objects: ~160 MB -- must not be counted when this test is the
+    # first of the process to touch the library)
+    warm = util._DeviceOperator(poisson((40, 40, 40)))
+    x = np.zeros(64000)
+    _lib.lib().amg_hier_gs_natural(warm.h, 0, x.ctypes.data, None, bytes([0]), 1)
+    warm.close()
     torch.cuda.synchronize()
     free0 = torch.cuda.mem_get_info()[0]
     ml = pyamg_amd.smoothed_aggregation_solver(A, presmoother=("chebyshev", {"degree": 2}),
@@ -1961,3 +1967,106 @@ def test_sliced_block_form_same_bits_as_block_stream(monkeypatch):
             assert np.array_equal(out[0][1], out[1][1]), bs
     finally:
         L.amg_set_sell_form(1)
+
+
+@pytest.mark.gpu
+def test_natural_order_gauss_seidel_from_csr_same_bits(monkeypatch):
+    """amg_hier_gs_natural (csrc/gsflow.hip: gs_natural_kernel): Gauss-Seidel sweeps in the operator's own row order straight
+    from its CSR arrays in HBM -- what the setup's candidate improvement (aggregation.py:313-320) runs.  Against the sequential
+    host loop (relaxation.h:34-62 restated in setup_host.cpp, itself checked against the reference's fixtures): random
+    unsymmetric operators of at most 8 entries per row in random stored order, with missing and zero diagonals, sizes that
+    are not multiples of the 64-row tasks, forward / backward / symmetric sweeps, zero and non-zero right-hand sides; a
+    grid operator large enough for several resident waves per dependency chain; refusal of long rows; and the setup with
+    the device sweeps builds the same hierarchy bit for bit."""
+    import ctypes as C
+    import scipy.sparse as sp
+    from pyamg_amd import _lib, aggregation
+    from pyamg_amd.aggregation import poisson as native, smoothed_aggregation_solver
+    from pyamg_amd.util import _DeviceOperator
+    L = _lib.lib()
+    H = aggregation.host_lib()
+    ip, dp = C.POINTER(C.c_int), C.POINTER(C.c_double)
+
+    def host_sweeps(A, x, b, dirs):
+        Ap = np.ascontiguousarray(A.indptr, dtype=np.intc); Aj = np.ascontiguousarray(A.indices, dtype=np.intc)
+        Ax = np.ascontiguousarray(A.data, dtype=np.float64)
+        n = A.shape[0]
+        for d in dirs:
+            if d:
+                H.amgsetup_gauss_seidel(Ap.ctypes.data_as(ip), Aj.ctypes.data_as(ip), Ax.ctypes.data_as(dp), x.ctypes.data_as(dp),
+                                        b.ctypes.data_as(dp), n - 1, -1, -1)
+            else:
+                H.amgsetup_gauss_seidel(Ap.ctypes.data_as(ip), Aj.ctypes.data_as(ip), Ax.ctypes.data_as(dp), x.ctypes.data_as(dp),
+                                        b.ctypes.data_as(dp), 0, n, 1)
+
+    def device_sweeps(A, x, b, dirs):
+        op = _DeviceOperator(A)
+        try:
+            _lib.check(L.amg_hier_finalize(op.h))
+            return L.amg_hier_gs_natural(op.h, 0, x.ctypes.data, None if b is None else b.ctypes.data, bytes(dirs), len(dirs))
+        finally:
+            op.close()
+
+    rng = np.random.RandomState(21)
+    for case, n in enumerate((1, 63, 64, 65, 1000, 4097, 20011)):
+        rows, cols, vals = [], [], []
+        for i in range(n):
+            k = rng.randint(0, 8)
+            near = rng.rand() < 0.7
+            cand = (i + rng.randint(-70, 71, size=k)) if near else rng.randint(0, n, size=k)
+            c = np.unique(np.clip(cand, 0, n - 1))
+            c = c[c != i]
+            if rng.rand() < 0.9:
+                c = np.append(c, i)                                  # most rows have a diagonal entry ...
+            rng.shuffle(c)                                           # ... somewhere in the stored order
+            c = c[:8]
+            rows += [i] * len(c); cols += list(c)
+            v = rng.rand(len(c)) - 0.3
+            v[(c == i)] = 0.0 if rng.rand() < 0.05 else 4.0 + rng.rand()
+            vals += list(v)
+        A = sp.csr_matrix((vals, (rows, cols)), shape=(n, n))       # (coo -> csr sorts columns: unsort below)
+        A.sort_indices()
+        if n > 1:                                                    # random stored order inside every row
+            for i in range(n):
+                s, e = A.indptr[i], A.indptr[i + 1]
+                perm = rng.permutation(e - s)
+                A.indices[s:e] = A.indices[s:e][perm]; A.data[s:e] = A.data[s:e][perm]
+        assert np.diff(A.indptr).max() <= 8
+        for dirs, with_b in (([0], True), ([1], False), ([0, 1] * 2, True), ([1, 0, 0], False)):
+            b = rng.rand(n) if with_b else None
+            x0 = rng.rand(n)
+            xh = x0.copy(); host_sweeps(A, xh, b if with_b else np.zeros(n), dirs)
+            xd = x0.copy()
+            assert device_sweeps(A, xd, b, dirs) == 0, (case, dirs)
+            assert np.array_equal(xh, xd), (case, n, dirs)
+    # a grid operator: chains of dependent lanes, tasks of neighbouring grid lines overlapping
+    # (lines of 67 / 130 / 61 rows: tasks cut at the line starts and taken in dependency-level order; lines shorter than a
+    #  task chain neighbouring tasks through the second short offset)
+    for dims in ((41, 47, 67), (130, 130), (47, 53, 61), (3, 5, 700)):
+        A = native(dims)
+        b = np.zeros(A.shape[0])
+        x0 = rng.rand(A.shape[0])
+        xh = x0.copy(); host_sweeps(A, xh, b, [0, 1] * 4)
+        xd = x0.copy()
+        assert device_sweeps(A, xd, None, [0, 1] * 4) == 0, dims
+        assert np.array_equal(xh, xd), dims
+    # rows of more than 8 entries are refused, x untouched
+    A9 = sp.csr_matrix(np.ones((12, 12)))
+    xd = np.arange(12.0)
+    assert device_sweeps(A9, xd, None, [0]) == _lib.AMG_ENOTIMPL and np.array_equal(xd, np.arange(12.0))
+    # the setup: candidate improvement on the device vs on the host
+    A = native((40, 48, 112))                                        # 215 k rows: above the device threshold of the setup
+    sm = ("jacobi", {"omega": 4.0 / 3.0})
+    built = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("AMG_SETUP_DEVICE_GS", flag)
+        np.random.seed(5)
+        ml = smoothed_aggregation_solver(A, presmoother=sm, postsmoother=sm)
+        built[flag] = ml
+    monkeypatch.delenv("AMG_SETUP_DEVICE_GS")
+    assert len(built["1"].levels) == len(built["0"].levels)
+    for l1, l0 in zip(built["1"].levels, built["0"].levels):
+        assert np.array_equal(l1.B, l0.B)
+        assert np.array_equal(l1.A.indptr, l0.A.indptr) and np.array_equal(l1.A.indices, l0.A.indices) and np.array_equal(l1.A.data, l0.A.data)
+        if hasattr(l1, "P"):
+            assert np.array_equal(l1.P.data, l0.P.data) and np.array_equal(l1.P.indices, l0.P.indices)
