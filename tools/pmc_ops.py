@@ -67,7 +67,7 @@ ops = collections.OrderedDict()
 nd = L.amg_hier_value_index(dev.h, 0, -1)
 if nd > 0:
     ops["level0_coded"] = {"what": "level-0 r = b - A x, stencil form with one-byte value codes (%d distinct values)" % nd,
-                           "kernel_match": ["stencil_kernel<2, 8>"], "ms": dev.time_spmv(0, 0, mode=1, reps=4),
+                           "kernel_match": ["stencil_coded_kernel<2>"], "ms": dev.time_spmv(0, 0, mode=1, reps=4),
                            "algorithmic_bytes": spmv(A0) + 8.0 * A0.shape[0], "moved_bytes": L.amg_hier_operator_bytes(dev.h, 0, 1)}
     L.amg_hier_value_index(dev.h, 0, 0)
 ops["level0_values"] = {"what": "level-0 r = b - A x, stencil form with 8-byte values", "kernel_match": ["stencil2_kernel<2, 8>"],
