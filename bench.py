@@ -539,7 +539,9 @@ def config_main(args, rank, local_rank, world, torch, dist, L):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)      # ~0.9 s timed at 500^3 (20 steps = 0.37 s was short)
+    ap.add_argument("--steps", type=int, default=None)    # default 50: ~0.6 s timed at 500^3 (20 steps = 0.37 s was short);
+                                                          # C1 200, C2 500: their steps are 6 / 0.4 ms, and a 20 ms region reads a single
+                                                          # host-side stall of the same length as half the rate (seen on C2: 0.41 / 0.88 ms)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="C3", choices=["C1", "C2", "C3", "C4", "C5"], help="BASELINE.json configuration (default: the metric's)")
     ap.add_argument("--grid", type=int, default=None, help="grid points per axis (defaults: C1 500, C2 2000, C3 / C4 500, C5 360)")
@@ -557,6 +559,8 @@ def main():
         args.grid = {"C1": 500, "C2": 2000, "C3": 500, "C4": 500, "C5": 360}[args.config]
     if args.smoother is None:
         args.smoother = "hybrid_gs" if args.config == "C4" else "chebyshev"
+    if args.steps is None:
+        args.steps = {"C1": 200, "C2": 500}.get(args.config, 50)
 
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args)           # before anything touches the GPU
