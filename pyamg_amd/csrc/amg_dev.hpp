@@ -78,7 +78,7 @@ struct DevCsr {
     // contiguous row ranges that the offset-pattern kernel applies after the stencil launch.
     int st_nranges = 0;
     int st_range[8][2] = {{0}};
-    // Value index on top of the stencil form (opt-in, amg_hier_value_index): when the operator holds at
+    // Value index on top of the stencil form (automatic since r3, amg_hier_value_index / amg_set_value_index): when the operator holds at
     // most 255 distinct values (constant-coefficient stencils), slot u of row i stores a one-byte code
     // into a dictionary kept in LDS instead of the 8-byte value -- the product uses the very same double.
     unsigned char *st_codes = nullptr;   // 8 slots per 64-bit word: [nblocks256][ceil(st_nu / 8)][256] words

@@ -2081,7 +2081,7 @@ static int launch_stencil_mode(const StreamArgs &a, const DevCsr &M, hipStream_t
     // Measured (tools/pairs_size_ab.py, tools/pairs_ab.py): faster from ~30 M rows up with stencils of up to 7 offsets
     // (500^3: 1.74 vs 1.82 ms); slower on small levels (4 M rows, Jacobi mode: +12 %) and with the 16-slot
     // instantiation on coarse levels (+40 % at 10 us), where a launch has too few waves to need fewer instructions.
-    // g_stencil_pairs = 2 forces it.  (The opt-in value index keeps one row per lane: measured faster there.)
+    // g_stencil_pairs = 2 forces it.  (Coded values -- the value index -- keep one row per lane: measured faster there; stencil_coded_kernel.)
     const bool big = (long)(a.row_hi - a.row_lo) >= 30000000L && M.st_nu <= 7;
     const bool pairs = (g_stencil_pairs >= 2 || (g_stencil_pairs == 1 && big)) && M.st_nu <= 16 && E.codes == nullptr &&
                        (((uintptr_t)b.b | (uintptr_t)b.out | (uintptr_t)b.v2 | (uintptr_t)b.xg) & 15u) == 0;
