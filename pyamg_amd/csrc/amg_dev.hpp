@@ -183,7 +183,7 @@ int launch_stencil_build(const DevCsr &M, const int *dict_slot, const unsigned *
 // value index: distinct values of st_vals into a 1024-slot table (EMPTY = all ones), then the byte codes
 int launch_value_scan(const double *vals, long count, unsigned long long *table, int *overflow, hipStream_t st);
 int launch_value_encode(const double *vals, long count, const double *dict_sorted, int ndict, unsigned char *codes, int nu,
-                        hipStream_t st);
+                        hipStream_t st, const unsigned char *mask8 = nullptr, long nrows = 0);
 int config_epoch();                      // bumped by every set_* knob below
 void bump_config_epoch();
 // Gauss-Seidel: runs of dependency levels of at most gs_chain_max_rows() rows swept by ONE workgroup in

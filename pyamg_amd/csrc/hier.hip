@@ -1661,7 +1661,9 @@ static int value_index_build(amg_hier *h, DevCsr &M)
     const long code_bytes = (long)((M.nrows + 255) / 256) * ((M.st_nu + 7) / 8) * 256 * 8;
     if (dev_alloc(&M.st_codes, code_bytes, &h->dev_bytes) != 0) return AMG_ENOMEM;
     M.st_ndict = (int)bits.size();
-    rc = launch_value_encode(M.st_vals, count, M.st_dict, M.st_ndict, M.st_codes, M.st_nu, h->stream);
+    AMG_HIP(hipMemsetAsync(M.st_codes, 0xFF, (size_t)code_bytes, h->stream));      // slots the stencil does not have: absent (255)
+    rc = launch_value_encode(M.st_vals, count, M.st_dict, M.st_ndict, M.st_codes, M.st_nu, h->stream,
+                             M.st_nu <= 7 ? static_cast<const unsigned char *>(M.st_mask) : nullptr, M.nrows);
     AMG_HIP(hipStreamSynchronize(h->stream));
     if (rc != 0) return AMG_ESTATE;
     M.st_vi_on = true;

@@ -1555,6 +1555,7 @@ struct StencilArgs {
     const unsigned char *codes;          // value index: one byte per slot instead of vals (null = off)
     const double *dict;                  // its dictionary (<= 256 doubles), copied to LDS by every workgroup
     int ndict;
+    int ranges;                          // != 0: some rows are left to the pattern kernel (their mask has the top bit set)
     const void *mask;                    // uint8 per row in the NUB == 8 instantiation (|U| <= 7), else uint32;
                                          // top bit set = the row is applied by the pattern kernel instead
     int nu, u0;
@@ -1653,15 +1654,17 @@ __global__ __launch_bounds__(WG) void stencil_coded_kernel(StreamArgs a, Stencil
     double xv[7];
 #pragma unroll
     for (int u = 0; u < 7; ++u) xv[u] = a.xg[min(max(ic + E.off[u], 0), last)];   // (slots >= nu: offset 0, mask bit clear)
-    unsigned m = (unsigned)stream_load(static_cast<const unsigned char *>(E.mask) + ic);
+    // which slots a row stores is in its codes (255 = absent: value_encode_kernel); the row mask is only read where some
+    // rows are left to the pattern kernel (top bit)
+    unsigned m = 0;
+    if (E.ranges) m = (unsigned)stream_load(static_cast<const unsigned char *>(E.mask) + ic);      // (uniform)
     double bval = 0.0, pre2 = 0.0;
     if (MT::sub || MODE == SM_RESIDUAL || MODE == SM_RESIDUAL_SUMSQ || MODE == SM_POLY_STEP || MODE == SM_POLY_LAST || MODE == SM_JACOBI)
         bval = stream_load(&a.b[ic]);
     if (MODE == SM_MATVEC_ACC) pre2 = a.out[ic];
     else if (MODE == SM_POLY_LAST || MODE == SM_JACOBI || MODE == SM_JACOBI_BSR1) pre2 = a.v2[ic];
     if (t < E.ndict) sdict[t] = dv;
-    const bool covered = live && !(m & 0x80u);                    // top bit: the row is applied by the pattern kernel
-    if (!covered) m = 0;
+    const bool covered = live && !(m & 0x80u);
     __syncthreads();                                              // dictionary in LDS
     double v[7];
 #pragma unroll
@@ -1670,7 +1673,7 @@ __global__ __launch_bounds__(WG) void stencil_coded_kernel(StreamArgs a, Stencil
     double acc = MT::sub ? bval : 0.0, diag = 0.0;
 #pragma unroll
     for (int u = 0; u < 7; ++u) {
-        const bool on = ((m >> u) & 1u) != 0;                     // (bits >= nu are clear)
+        const bool on = covered && ((unsigned)(cw >> (8 * u)) & 0xFFu) != 255u;      // (slots >= nu and unstored slots: 255)
         if (MT::jac) {
             const bool isd = u == E.u0;
             diag = (on && isd) ? v[u] : diag;
@@ -1989,8 +1992,10 @@ __global__ void value_scan_kernel(const double *vals, long count, unsigned long 
     }
 }
 // vals are [block][slot][256]; the code of (block, slot, t) goes to byte (slot & 7) of word [block][slot >> 3][t]
+// mask8 != null (stencils of up to 7 offsets): a slot the row does not store gets the reserved code 255, so that a kernel
+// can tell "absent" (skip the term) from a stored 0.0 (add it) without reading the row mask (stencil_coded_kernel)
 __global__ void value_encode_kernel(const double *vals, long count, const double *dict, int ndict, unsigned char *codes,
-                                    int nu)
+                                    int nu, const unsigned char *mask8, long nrows)
 {
     const int nw = (nu + 7) >> 3;
     for (long k = blockIdx.x * (long)blockDim.x + threadIdx.x; k < count; k += (long)gridDim.x * blockDim.x) {
@@ -2005,6 +2010,11 @@ __global__ void value_encode_kernel(const double *vals, long count, const double
         const long blk = k / ((long)nu * WG);
         const int rem = (int)(k - blk * (long)nu * WG);
         const int slot = rem / WG, t = rem - slot * WG;
+        if (mask8) {
+            const long row = blk * WG + t;
+            const unsigned m = row < nrows ? mask8[row] : 0u;
+            if ((m & 0x80u) || !((m >> slot) & 1u)) at = 255;
+        }
         codes[((blk * nw + (slot >> 3)) * WG + t) * 8 + (slot & 7)] = (unsigned char)at;
     }
 }
@@ -2016,9 +2026,9 @@ int launch_value_scan(const double *vals, long count, unsigned long long *table,
     return 0;
 }
 int launch_value_encode(const double *vals, long count, const double *dict_sorted, int ndict, unsigned char *codes, int nu,
-                        hipStream_t st)
+                        hipStream_t st, const unsigned char *mask8, long nrows)
 {
-    hipLaunchKernelGGL(value_encode_kernel, dim3(8192), dim3(256), 0, st, vals, count, dict_sorted, ndict, codes, nu);
+    hipLaunchKernelGGL(value_encode_kernel, dim3(8192), dim3(256), 0, st, vals, count, dict_sorted, ndict, codes, nu, mask8, nrows);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "value encode launch", __FILE__, __LINE__);
     return 0;
@@ -2064,6 +2074,7 @@ static int launch_stencil_mode(const StreamArgs &a, const DevCsr &M, hipStream_t
     StencilArgs E;
     E.vals = M.st_vals; E.mask = M.st_mask; E.nu = M.st_nu; E.u0 = M.st_u0;
     E.codes = (M.st_vi_on && M.st_codes) ? M.st_codes : nullptr; E.dict = M.st_dict; E.ndict = M.st_ndict;
+    E.ranges = M.st_nranges;
     E.blk_lo = a.row_lo / WG; E.nblocks = nb; E.ncols = M.ncols;
     E.period_blocks = E.seg_blocks = 0;
     for (int u = 0; u < STENCIL_MAX; ++u) E.off[u] = M.st_off[u];
@@ -2083,7 +2094,8 @@ static int launch_stencil_mode(const StreamArgs &a, const DevCsr &M, hipStream_t
     // instantiation on coarse levels (+40 % at 10 us), where a launch has too few waves to need fewer instructions.
     // g_stencil_pairs = 2 forces it.  (Coded values -- the value index -- keep one row per lane: measured faster there; stencil_coded_kernel.)
     const bool big = (long)(a.row_hi - a.row_lo) >= 30000000L && M.st_nu <= 7;
-    const bool pairs = (g_stencil_pairs >= 2 || (g_stencil_pairs == 1 && big)) && M.st_nu <= 16 && E.codes == nullptr &&
+    static const int pairs_coded = std::getenv("AMG_STENCIL_PAIRS_CODED") ? std::atoi(std::getenv("AMG_STENCIL_PAIRS_CODED")) : 0;   // (A/B)
+    const bool pairs = (g_stencil_pairs >= 2 || (g_stencil_pairs == 1 && big)) && M.st_nu <= 16 && (E.codes == nullptr || pairs_coded) &&
                        (((uintptr_t)b.b | (uintptr_t)b.out | (uintptr_t)b.v2 | (uintptr_t)b.xg) & 15u) == 0;
     if (pairs && M.st_nu <= 7)
         hipLaunchKernelGGL((stencil2_kernel<MODE, 8>), dim3(grid), dim3(WG2), 0, st, b, E, g_xcd_chunk);
