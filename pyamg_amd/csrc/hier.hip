@@ -2500,8 +2500,13 @@ static double bytes_spmv_moved(const DevCsr &M)
 {
     if (M.blk && M.blk->Ap && (!M.Ap || bsr_spmv_enabled(M.blk->bs))) return bytes_spmv(M);
     if (M.st_vals && (stencil_enabled() || !M.Ap))     // padded values (or one-byte codes) + one mask word per row; no row pointer
-        return ((M.st_vi_on && M.st_codes) ? 8.0 * (double)((M.st_nu + 7) / 8) : 8.0 * (double)M.st_nu) * 256.0 * (double)((M.nrows + 255) / 256) + (M.st_nu <= 7 ? 1.0 : 4.0) * M.nrows +
+    {
+        const bool coded = M.st_vi_on && M.st_codes;
+        // (the coded kernel of stencils with <= 7 offsets finds "absent" in the codes and reads no row mask unless rows are left to the pattern kernel)
+        const double mask_bytes = (coded && M.st_nu <= 7 && M.st_nranges == 0) ? 0.0 : (M.st_nu <= 7 ? 1.0 : 4.0);
+        return (coded ? 8.0 * (double)((M.st_nu + 7) / 8) : 8.0 * (double)M.st_nu) * 256.0 * (double)((M.nrows + 255) / 256) + mask_bytes * M.nrows +
                8.0 * M.ncols + 8.0 * M.nrows;
+    }
     if (!M.pat && M.sl_val && (sell_enabled() || !M.Ap) && M.sl_lo == 0 && M.sl_hi == M.nrows)    // padded entries, slot bookkeeping (row id + length), slice offsets; no row pointer
     {
         // (16-bit column codes: 2 B instead of 4 B per entry of a coded slice, + its 16 window origins)
